@@ -1,0 +1,154 @@
+// oracle/ref_shim.cc -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin C-ABI wrapper around the *unmodified* reference sources, compiled where
+// they lie under /root/reference/src by oracle/Makefile into
+// oracle/_ref/libtimg_ref.so.  Nothing from the reference is copied into this
+// repository; this file only *calls* the reference's public C++ interfaces:
+//
+//   timg::ImageScaler::Create / Scale           (src/image-scaler.h:33-39,
+//                                                src/image-scaler.cc:75-98 STB back-end)
+//   timg::Framebuffer::AlphaComposeBackground   (src/framebuffer.h:103-106,
+//                                                src/framebuffer.cc:108-150)
+//   timg::UnicodeBlockCanvas::Send              (src/unicode-block-canvas.cc:323-403)
+//   timg::TerminalCanvas prefix machinery       (src/terminal-canvas.cc:53-99)
+//
+// The escape bytes of a canvas are captured by pointing the reference's own
+// BufferedWriteSequencer at a memfd and reading it back after the sequencer's
+// destructor has flushed.
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "buffered-write-sequencer.h"
+#include "framebuffer.h"
+#include "image-scaler.h"
+#include "unicode-block-canvas.h"
+
+using timg::Framebuffer;
+using timg::rgba_t;
+
+static rgba_t unpack(uint32_t c) {  // memory order r,g,b,a (little endian u32)
+    rgba_t r;
+    memcpy(&r, &c, 4);
+    return r;
+}
+
+extern "C" {
+
+// in_fmt: 0 = RGBA (ColorFmt::kRGBA), 1 = BGRA-in-memory (ColorFmt::kRGB32)
+int ref_scale(const uint8_t *src, int sw, int sh, int in_fmt, uint8_t *dst,
+              int dw, int dh) {
+    Framebuffer in(sw, sh);
+    memcpy((void *)in.begin(), src, (size_t)sw * sh * 4);
+    Framebuffer out(dw, dh);
+    auto scaler = timg::ImageScaler::Create(
+        sw, sh,
+        in_fmt == 0 ? timg::ImageScaler::ColorFmt::kRGBA
+                    : timg::ImageScaler::ColorFmt::kRGB32,
+        dw, dh);
+    if (!scaler) return -1;
+    scaler->Scale(in, &out);
+    memcpy(dst, out.begin(), (size_t)dw * dh * 4);
+    return 0;
+}
+
+// In-place on fb (w*h*4 bytes). has_getter==0 models "-b none" (null function).
+// Returns the number of times the bg getter was invoked (laziness check).
+int ref_alpha_compose(uint8_t *fb, int w, int h, int has_getter, uint32_t bg,
+                      uint32_t pattern, int pw, int ph, int start_row) {
+    Framebuffer f(w, h);
+    memcpy((void *)f.begin(), fb, (size_t)w * h * 4);
+    int calls = 0;
+    Framebuffer::bgcolor_query getter;
+    if (has_getter) {
+        getter = [&calls, bg]() {
+            ++calls;
+            return unpack(bg);
+        };
+    }
+    f.AlphaComposeBackground(getter, unpack(pattern), pw, ph, start_row);
+    memcpy(fb, f.begin(), (size_t)w * h * 4);
+    return calls;
+}
+
+// A persistent canvas so that multi-Send sequences (frame-diff mode) can be
+// replayed.  Output of every Send accumulates in a memfd.
+struct RefCanvas {
+    int fd;
+    volatile sig_atomic_t interrupt = 0;
+    std::unique_ptr<timg::BufferedWriteSequencer> seq;
+    std::unique_ptr<timg::UnicodeBlockCanvas> canvas;
+};
+
+void *ref_block_canvas_new(int quarter, int upper_block, int color256) {
+    RefCanvas *c = new RefCanvas();
+    c->fd        = memfd_create("timg_ref", 0);
+    c->seq.reset(new timg::BufferedWriteSequencer(c->fd, false, 4, true,
+                                                  c->interrupt));
+    c->canvas.reset(new timg::UnicodeBlockCanvas(c->seq.get(), quarter != 0,
+                                                 upper_block != 0,
+                                                 color256 != 0));
+    return c;
+}
+
+void ref_block_canvas_send(void *h, int x, int dy, const uint8_t *fb, int w,
+                           int ht) {
+    RefCanvas *c = (RefCanvas *)h;
+    Framebuffer f(w, ht);
+    memcpy((void *)f.begin(), fb, (size_t)w * ht * 4);
+    // The reference allocates one scratch row behind the image
+    // (src/framebuffer.cc:57-62) and AppendDoubleRow<2> reads one pixel into
+    // it for odd widths (src/unicode-block-canvas.cc:242-243).  Its content is
+    // indeterminate in the reference; pin it to transparent-black here.
+    memset((void *)f.end(), 0, (size_t)w * 4);
+    c->canvas->Send(x, dy, f, timg::SeqType::FrameImmediate, {});
+}
+
+// Flushes, copies everything written so far into out (up to cap); returns the
+// total size written so far.
+long ref_block_canvas_read(void *h, char *out, long cap) {
+    RefCanvas *c = (RefCanvas *)h;
+    c->seq->Flush();
+    off_t size = lseek(c->fd, 0, SEEK_END);
+    if (out && cap > 0) {
+        long n = size < cap ? size : cap;
+        if (pread(c->fd, out, n, 0) != n) return -1;
+    }
+    return (long)size;
+}
+
+void ref_block_canvas_free(void *h) {
+    RefCanvas *c = (RefCanvas *)h;
+    c->canvas.reset();
+    c->seq.reset();
+    close(c->fd);
+    delete c;
+}
+
+// One-shot convenience: single Send(x, dy=0) on a fresh canvas.
+long ref_block_encode(const uint8_t *fb, int w, int h, int quarter,
+                      int upper_block, int color256, int x, char *out,
+                      long cap) {
+    void *c = ref_block_canvas_new(quarter, upper_block, color256);
+    ref_block_canvas_send(c, x, 0, fb, w, h);
+    long n = ref_block_canvas_read(c, out, cap);
+    ref_block_canvas_free(c);
+    return n;
+}
+
+int ref_cell_height_for_pixels(int quarter, int pixels) {
+    volatile sig_atomic_t intr = 0;
+    timg::BufferedWriteSequencer seq(-1, false, 1, true, intr);
+    timg::UnicodeBlockCanvas c(&seq, quarter != 0, false, false);
+    return c.cell_height_for_pixels(pixels);
+}
+
+uint8_t ref_as_256_term_color(uint32_t c) { return unpack(c).As256TermColor(); }
+
+}  // extern "C"

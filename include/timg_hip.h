@@ -1,0 +1,186 @@
+/* include/timg_hip.h -- C-ABI of libtimg_hip.so, the MI355X (gfx950) twin of
+ * hzeller/timg's per-pixel rendering hot path.
+ *
+ * This is the drop-in boundary: plain C types, opaque handles, caller-owned
+ * buffers, no exceptions, no C++ or torch types.  Every entry point returns
+ * 0 on success and a negative timg_hip_status on failure (the reference's
+ * "return nullptr / false and let the caller fall back" convention,
+ * SURVEY.md 8b); timg_hip_last_error() gives the text.  The library fails
+ * loudly when no HIP device is usable -- there is no CPU fallback in here.
+ *
+ * Each function names the reference interface it replaces (paths relative to
+ * the hzeller/timg tree).  INTEGRATION.md shows the C++ twins
+ * (HipImageScaler, HipUnicodeBlockCanvas, HipSixelCanvas) a maintainer adds on
+ * the reference side to bind these.
+ *
+ * Pixel format everywhere: RGBA8, memory order r,g,b,a (timg::rgba_t,
+ * src/framebuffer.h:26-28), rows `stride` bytes apart (stride 0 = 4*width).
+ * Colours passed by value are packed r | g<<8 | b<<16 | a<<24.
+ * `stream` is a hipStream_t (NULL = the context's own stream); work is
+ * enqueued on it and, unless stated otherwise, NOT synchronised: device
+ * pointers are valid to consume on the same stream, host pointers force a
+ * synchronisation before return.
+ */
+#ifndef TIMG_HIP_H
+#define TIMG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TIMG_HIP_OK          = 0,
+    TIMG_HIP_ERR_ARG     = -1, /* bad argument */
+    TIMG_HIP_ERR_DEVICE  = -2, /* HIP runtime error / no device */
+    TIMG_HIP_ERR_NOMEM   = -3,
+    TIMG_HIP_ERR_SMALL   = -4, /* caller's output capacity too small */
+    TIMG_HIP_ERR_UNSUPP  = -5, /* geometry outside what the kernels cover */
+} timg_hip_status;
+
+typedef struct timg_hip_ctx timg_hip_ctx;
+typedef struct timg_hip_scaler timg_hip_scaler;
+
+/* ---- context ----------------------------------------------------------- */
+int timg_hip_init(int device, timg_hip_ctx **out);
+void timg_hip_destroy(timg_hip_ctx *ctx);
+const char *timg_hip_last_error(const timg_hip_ctx *ctx); /* ctx may be NULL */
+/* Library/ABI version (major<<16 | minor). */
+int timg_hip_version(void);
+
+/* Buffers owned by the library (hipMalloc / hipHostMalloc). Convenience for
+ * hosts that have no HIP binding of their own (Python tests, the C++ twins). */
+int timg_hip_malloc(timg_hip_ctx *ctx, size_t bytes, void **dev_ptr);
+int timg_hip_free(timg_hip_ctx *ctx, void *dev_ptr);
+int timg_hip_memcpy_h2d(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream);
+int timg_hip_memcpy_d2h(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream);
+int timg_hip_sync(timg_hip_ctx *ctx, void *stream);
+
+/* ---- scaler: timg::ImageScaler ------------------------------------------
+ * Replaces ImageScaler::Create (src/image-scaler.h:33-35, src/image-scaler.cc:
+ * 101-116) and ImageScaler::Scale (src/image-scaler.h:39; STB back-end
+ * src/image-scaler.cc:83-92).  Creating a scaler builds the resampling plan
+ * (stb_image_resize2-compatible coefficient tables) once on the host and
+ * uploads it; Scale is then pure device work. */
+#define TIMG_HIP_FMT_RGBA 0 /* ImageScaler::ColorFmt::kRGBA */
+#define TIMG_HIP_FMT_BGRA 1 /* ImageScaler::ColorFmt::kRGB32 (b,g,r,a in memory) */
+#define TIMG_HIP_FILTER_STB_DEFAULT 0 /* bit-exact with the STB back-end */
+#define TIMG_HIP_FILTER_TRIANGLE    2 /* bilinear weights, same machinery */
+
+int timg_hip_scaler_create(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt,
+                           int out_w, int out_h, int filter,
+                           timg_hip_scaler **out);
+void timg_hip_scaler_destroy(timg_hip_scaler *s);
+
+/* Background description for the fused Framebuffer::AlphaComposeBackground
+ * (src/framebuffer.h:103-106, src/framebuffer.cc:108-150).  enabled==0 models
+ * a null bgcolor_query ("-b none"); bg alpha 0 means "do not blend"
+ * (framebuffer.cc:120-121); pattern alpha 0 / pw<=0 / ph<=0 / pattern==bg
+ * selects the solid fast path (framebuffer.cc:124-132). */
+typedef struct {
+    int enabled;
+    uint32_t bg;      /* what bgcolor_getter() returns */
+    uint32_t pattern; /* DisplayOptions::bg_pattern_color */
+    int pattern_w, pattern_h;
+    int start_row;
+} timg_hip_blend;
+
+/* Scale n_frames frames of the scaler's geometry, optionally followed by the
+ * fused alpha compose.  src/dst may each live on the device (`*_on_device`)
+ * or on the host (staged through pinned memory; then the call synchronises).
+ * Frame i starts at src + i*src_frame_stride (0 = in_h*src_stride).
+ * any_transparent (optional, host int[n_frames]) receives whether the scaled
+ * frame held a pixel with alpha<255 at/after blend.start_row before blending
+ * -- the laziness condition of AlphaComposeBackground (framebuffer.cc:113-117);
+ * asking for it synchronises. */
+int timg_hip_scale_blend(timg_hip_ctx *ctx, timg_hip_scaler *s,
+                         const uint8_t *src, int src_stride,
+                         size_t src_frame_stride, int src_on_device,
+                         uint8_t *dst, int dst_stride, size_t dst_frame_stride,
+                         int dst_on_device, int n_frames,
+                         const timg_hip_blend *blend_or_null,
+                         int *any_transparent_or_null, void *stream);
+
+/* Force a kernel family for A/B measurements and parity tests:
+ * 0 = auto, 1 = generic gather kernel, 2 = streaming kernel (fails with
+ * TIMG_HIP_ERR_UNSUPP when the plan is outside its coverage). */
+int timg_hip_scaler_set_kernel(timg_hip_scaler *s, int which);
+/* Introspection: info[0]=vertical_first [1]=h_widest [2]=v_is_gather
+ * [3]=v_widest [4]=h_filter [5]=v_filter [6]=streaming kernel applicable
+ * [7]=max active output rows per input row. */
+int timg_hip_scaler_info(const timg_hip_scaler *s, int info[8]);
+/* Algorithmic HBM bytes of one frame (read source once + write result once,
+ * SURVEY.md 8d). */
+size_t timg_hip_scaler_algorithmic_bytes(const timg_hip_scaler *s);
+
+/* ---- standalone alpha compose -------------------------------------------
+ * Framebuffer::AlphaComposeBackground in place on n_frames frames
+ * (src/framebuffer.cc:108-150; used for the sixel pad rows by
+ * src/sixel-canvas.cc:115-118). */
+int timg_hip_alpha_compose(timg_hip_ctx *ctx, uint8_t *fb, int w, int h,
+                           int stride, size_t frame_stride, int on_device,
+                           int n_frames, const timg_hip_blend *blend,
+                           int *any_transparent_or_null, void *stream);
+
+/* ---- auto-crop bounding box ----------------------------------------------
+ * The reduction behind --auto-crop (GraphicsMagick img.trim() in
+ * src/graphics-magick-source.cc:238-240; "parity unpinned"):
+ * bounding box of pixels that differ (RGBA, fuzz 0) from the top-left corner
+ * pixel after removing crop_border pixels on every side.  out_xywh is a host
+ * int[4] per frame {x, y, w, h} in source coordinates; an all-border frame
+ * yields w=h=0. */
+int timg_hip_autocrop_bbox(timg_hip_ctx *ctx, const uint8_t *src, int w, int h,
+                           int stride, size_t frame_stride, int on_device,
+                           int n_frames, int crop_border, int *out_xywh,
+                           void *stream);
+
+/* ---- block canvas: timg::UnicodeBlockCanvas ------------------------------
+ * Replaces the pixel work of UnicodeBlockCanvas::Send
+ * (src/unicode-block-canvas.cc:323-403: FindBestGlyph :163-227,
+ * AppendDoubleRow :231-321).  Produces, per frame, exactly the bytes Send
+ * appends after its cursor prefix for a first Send at indent x (no frame-diff:
+ * emit_difference is false in grid mode and for a first frame, :344-346).
+ * The prefix itself (TerminalCanvas::AppendPrefixToBuffer,
+ * src/terminal-canvas.cc:58-64) stays host-side. */
+#define TIMG_HIP_BLOCK_QUARTER   1 /* -p quarter, else -p half */
+#define TIMG_HIP_BLOCK_UPPER     2 /* TIMG_USE_UPPER_BLOCK */
+#define TIMG_HIP_BLOCK_COLOR256  4 /* --color8 */
+
+/* Worst-case bytes of one frame (RequestBuffers, :405-424). */
+size_t timg_hip_block_max_bytes(int w, int h);
+
+/* fb: n_frames frames (device or host).  out: n_frames slots of out_cap bytes
+ * each (device or host); out_len: host size_t[n_frames].  x_indent is Send's
+ * `x` argument in pixels (:334 halves it for quarter blocks). Synchronises. */
+int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
+                          int stride, size_t frame_stride, int fb_on_device,
+                          int n_frames, int flags, int x_indent, char *out,
+                          size_t out_cap, int out_on_device, size_t *out_len,
+                          void *stream);
+
+/* ---- sixel canvas: timg::SixelCanvas -------------------------------------
+ * Replaces the two libsixel calls of SixelCanvas::Send
+ * (src/sixel-canvas.cc:137-145: sixel_dither_initialize + sixel_encode) and
+ * the padding that precedes them (:111-120).  Per frame: pad to a multiple of
+ * 6 rows, blend the pad rows only, <=256-colour adaptive palette (15-bit
+ * histogram + median cut, LARGE_LUM / REP_AVERAGE_COLORS), exact nearest
+ * colour + Floyd-Steinberg diffusion, band/colour RLE.  Output per frame:
+ * cursor-mode string (:66-79) + DCS..ST + "\r" or "\n".  Palette choice is
+ * within a stated Delta-E of the CPU restatement (libsixel is un-vendored:
+ * parity unpinned). */
+#define TIMG_HIP_SIXEL_BROKEN_CURSOR 1 /* SixelOptions::known_broken_cursor_placement */
+
+size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
+
+int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
+                          int stride, size_t frame_stride, int fb_on_device,
+                          int n_frames, int flags, const timg_hip_blend *pad_blend,
+                          char *out, size_t out_cap, int out_on_device,
+                          size_t *out_len, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMG_HIP_H */

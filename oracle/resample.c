@@ -887,3 +887,67 @@ int oracle_scale_plan_info(int sw, int sh, int dw, int dh, int filter,
     plan_free(&p);
     return 0;
 }
+
+/* Test introspection: dump the normalised tap tables of a plan so that the
+ * product's independently built tables can be compared on a CPU-only box.
+ * header: {vertical_first, both_point, h_sequential, h_stride}.  h_taps is
+ * {n0,count} per output column, h_coeff count floats per column at stride
+ * h_stride; v_cnt per output row, v_rows/v_coeff flattened in accumulation
+ * order.  Returns the number of vertical contributions or -1. */
+int oracle_scale_plan_dump(int sw, int sh, int dw, int dh, int filter,
+                           int *header, int *h_taps, float *h_coeff,
+                           int h_coeff_cap, int *v_cnt, int *v_rows,
+                           float *v_coeff, int v_cap) {
+    plan_t p;
+    if (plan_build(&p, sw, sh, dw, dh, filter) != 0) return -1;
+    header[0] = p.vertical_first;
+    header[1] = p.both_point;
+    header[2] = p.h.coeff_width <= 3;
+    header[3] = p.h.coeff_width;
+    int total = 0, ok = 1;
+    if ((long)dw * p.h.coeff_width > h_coeff_cap) ok = 0;
+    for (int x = 0; ok && x < dw; x++) {
+        int cnt = p.h.contrib[x].n1 - p.h.contrib[x].n0 + 1;
+        if (cnt < 1) cnt = 1;
+        h_taps[2 * x]     = p.h.contrib[x].n0;
+        h_taps[2 * x + 1] = cnt;
+        memcpy(h_coeff + (size_t)x * p.h.coeff_width,
+               p.h.coeff + (size_t)x * p.h.coeff_width,
+               (size_t)p.h.coeff_width * sizeof(float));
+    }
+    for (int y = 0; ok && y < dh; y++) {
+        const sampler_t *s = &p.v;
+        int n              = 0;
+        if (s->is_gather) {
+            int n0 = s->contrib[y].n0, n1 = s->contrib[y].n1;
+            const float *c = s->coeff + (size_t)y * s->coeff_width;
+            int cnt        = n1 - n0 + 1;
+            if (cnt < 1) cnt = 1;
+            int copy = (cnt == 1) && (c[0] >= (1.0f - 0.000001f)) &&
+                       (c[0] <= (1.0f + 0.000001f));
+            for (int k = 0; k < cnt; k++) {
+                if (total >= v_cap) { ok = 0; break; }
+                v_rows[total]  = n0 + k;
+                v_coeff[total] = copy ? 1.0f : c[k];
+                total++;
+                n++;
+            }
+        } else {
+            int margin = s->pixel_margin;
+            for (int iy = -margin; iy < s->in_size + margin; iy++) {
+                const contrib_t *sc = p.v_scatter + (iy + margin);
+                if (sc->n1 < sc->n0 || y < sc->n0 || y > sc->n1) continue;
+                if (total >= v_cap) { ok = 0; break; }
+                v_rows[total]  = clamp_idx(iy, s->in_size);
+                v_coeff[total] = p.v_scatter_coeff[(size_t)(iy + margin) *
+                                                       p.v_scatter_width +
+                                                   (y - sc->n0)];
+                total++;
+                n++;
+            }
+        }
+        v_cnt[y] = n;
+    }
+    plan_free(&p);
+    return ok ? total : -1;
+}

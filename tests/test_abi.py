@@ -1,0 +1,64 @@
+"""CPU-only: the C-ABI library loads without a GPU, exports every symbol
+include/timg_hip.h declares, sizes its buffers like the reference, and fails
+loudly (no CPU fallback) when no device is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import timg_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "timg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(timg_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = timg_amd.load_library()
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/timg_hip.h but not exported"
+
+
+def test_version_and_buffer_size_rules(oracle):
+    lib = timg_amd.load_library()
+    assert lib.timg_hip_version() >> 16 == 1
+    for w, h in [(1, 1), (67, 50), (100, 56), (801, 451)]:
+        assert lib.timg_hip_block_max_bytes(w, h) == oracle.block_max_bytes(w, h)
+        r6 = (h + 5) - (h + 5) % 6  # round_to_sixel, src/sixel-canvas.cc:91-94
+        assert lib.timg_hip_sixel_max_bytes(w, h) == 1024 + w * r6 * 5
+
+
+def test_init_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(timg_amd.TimgHipError) as e:
+        timg_amd.TimgHip(0)
+    assert e.value.code == -2 and "device" in str(e.value).lower()
+
+
+def test_null_arguments_are_rejected_not_crashing():
+    lib = timg_amd.load_library()
+    assert lib.timg_hip_init(0, None) == -1
+    assert lib.timg_hip_scaler_create(None, 1, 1, 0, 1, 1, 0, None) == -1
+    assert lib.timg_hip_sync(None, None) == -1
+    lib.timg_hip_destroy(None)
+    lib.timg_hip_scaler_destroy(None)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped library must not link or dlopen anything under oracle/."""
+    needed = os.popen(f"readelf -d {timg_amd.lib_path()} 2>/dev/null").read()
+    assert "oracle" not in needed and "timg_ref" not in needed
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "timg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cc", ".h")):
+                body = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "libtimg_oracle" not in body and "oracle_lib" not in body, f

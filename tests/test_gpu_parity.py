@@ -1,0 +1,147 @@
+"""-m gpu: the HIP path, called through the C-ABI, against the oracle on the
+same seeded inputs.  Bit-exact for scale, blend and block bytes."""
+import numpy as np
+import pytest
+
+import timg_amd
+from timg_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BG, PAT = (30, 30, 46, 255), (200, 190, 180, 255)
+
+SCALE_CASES = [
+    # (kind, sw, sh, dw, dh)  -- covers V-first gather, H-first gather, scatter,
+    # enlarging, point axes, odd sizes, identity
+    ("alpha", 640, 480, 67, 50),
+    ("noise", 640, 480, 67, 50),
+    ("alpha", 64, 48, 20, 15),
+    ("noise", 50, 40, 120, 90),
+    ("alpha", 64, 64, 64, 64),
+    ("alpha", 64, 48, 64, 20),
+    ("alpha", 64, 48, 20, 48),
+    ("noise", 500, 400, 13, 11),
+    ("alpha", 1000, 1000, 100, 100),
+    ("noise", 37, 29, 111, 87),
+    ("alpha", 300, 300, 7, 3),
+    ("alpha", 1920, 1080, 200, 56),
+    ("noise", 17, 1000, 5, 20),
+    ("photo", 1280, 720, 400, 225),
+    ("alpha", 1, 1, 5, 5),
+    ("alpha", 5, 5, 1, 1),
+]
+
+
+@pytest.mark.parametrize("kind,sw,sh,dw,dh", SCALE_CASES)
+@pytest.mark.parametrize("kernel", [1, 0])
+def test_scale_bit_exact(hip, oracle, kind, sw, sh, dw, dh, kernel):
+    src = synth.make(kind, sw, sh, seed=sw * 7 + dh)
+    got = hip.scale(src, dw, dh, kernel=kernel)
+    want = oracle.scale(src, dw, dh)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} differing bytes"
+
+
+def test_scale_bgra_input(hip, oracle):
+    src = synth.alpha(200, 150, seed=3)
+    assert np.array_equal(hip.scale(src, 77, 41, in_fmt=1), oracle.scale(src, 77, 41, in_fmt=1))
+
+
+def test_scale_triangle_filter(hip, oracle):
+    src = synth.alpha(320, 240, seed=4)
+    for dw, dh in [(100, 75), (500, 300)]:
+        assert np.array_equal(hip.scale(src, dw, dh, filter=2), oracle.scale(src, dw, dh, filter=2))
+
+
+@pytest.mark.parametrize("pattern,pw,ph", [((0, 0, 0, 0), 0, 0), (PAT, 1, 1), (PAT, 9, 10), (PAT, 10, 9)])
+@pytest.mark.parametrize("start_row", [0, 7])
+def test_fused_blend_bit_exact(hip, oracle, pattern, pw, ph, start_row):
+    src = synth.alpha(400, 300, seed=11)
+    blend = timg_amd.Blend.make(BG, pattern, pw, ph, start_row)
+    got = hip.scale(src, 133, 100, blend=blend)
+    want, calls = oracle.alpha_compose(oracle.scale(src, 133, 100), BG, pattern, pw, ph, start_row)
+    assert calls == 1
+    assert np.array_equal(got, want)
+
+
+def test_blend_lazy_flag_and_disabled(hip, oracle):
+    opaque = synth.photo(200, 100, seed=1)
+    sc = hip.scaler(200, 100, 50, 25)
+    dst = np.empty((25, 50, 4), np.uint8)
+    flags = hip.scale_blend(sc, opaque, dst, 1, timg_amd.Blend.make(BG), want_transparent=True)
+    assert flags == [0]  # the reference would never have called the bg getter
+    transparent = synth.alpha(200, 100, seed=1)
+    flags = hip.scale_blend(sc, transparent, dst, 1, timg_amd.Blend.make((0, 0, 0, 0)),
+                            want_transparent=True)
+    assert flags == [1]
+    assert np.array_equal(dst, oracle.scale(transparent, 50, 25))  # bg alpha 0: untouched
+    sc.close()
+
+
+def test_standalone_alpha_compose(hip, oracle):
+    fb = synth.alpha(123, 77, seed=5)
+    for start_row in (0, 70, 77):
+        for pattern, pw, ph in [((0, 0, 0, 0), 0, 0), (PAT, 5, 3)]:
+            mine = fb.copy()
+            hip.alpha_compose(mine, 123, 77, timg_amd.Blend.make(BG, pattern, pw, ph, start_row))
+            want, _ = oracle.alpha_compose(fb, BG, pattern, pw, ph, start_row)
+            assert np.array_equal(mine, want)
+
+
+def test_batched_device_resident_frames(hip, oracle):
+    n, sw, sh, dw, dh = 5, 320, 180, 100, 56
+    frames = np.stack([synth.alpha(sw, sh, seed=i) for i in range(n)])
+    dsrc = hip.upload(frames)
+    ddst = hip.malloc(n * dw * dh * 4)
+    sc = hip.scaler(sw, sh, dw, dh)
+    blend = timg_amd.Blend.make(BG, PAT, 4, 4)
+    hip.scale_blend(sc, dsrc, ddst, n, blend)
+    hip.sync()
+    out = hip.download(ddst, n * dw * dh * 4).reshape(n, dh, dw, 4)
+    for i in range(n):
+        want, _ = oracle.alpha_compose(oracle.scale(frames[i], dw, dh), BG, PAT, 4, 4)
+        assert np.array_equal(out[i], want), i
+    hip.free(dsrc)
+    hip.free(ddst)
+    sc.close()
+
+
+BLOCK_SIZES = [(67, 50), (100, 28 * 2), (33, 21), (1, 1), (2, 3), (200, 56), (65, 7), (129, 64)]
+
+
+@pytest.mark.parametrize("w,h", BLOCK_SIZES)
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 5, 6])
+def test_block_bytes_exact(hip, oracle, w, h, flags):
+    for kind, seed in [("noise", 1), ("alpha", 2), ("photo", 3)]:
+        fb = synth.make(kind, w, h, seed + w)
+        if kind == "photo":  # long runs of identical colours exercise the elision
+            fb[..., :3] = (fb[..., :3] // 64) * 64
+        got = hip.block_encode(fb, w, h, flags=flags, x_indent=0)[0]
+        want = oracle.block_encode(fb, quarter=bool(flags & 1), upper=bool(flags & 2),
+                                   color256=bool(flags & 4))
+        assert got == want, (kind, len(got), len(want))
+
+
+def test_block_indent_and_batch(hip, oracle):
+    w, h, n = 100, 56, 6
+    frames = np.stack([synth.alpha(w, h, seed=20 + i) for i in range(n)])
+    for flags, x in [(1, 200), (0, 37), (1, 1)]:
+        outs = hip.block_encode(frames, w, h, flags=flags, x_indent=x, n_frames=n)
+        for i in range(n):
+            assert outs[i] == oracle.block_encode(frames[i], quarter=bool(flags & 1), x=x), i
+
+
+def test_block_output_too_small_is_reported(hip):
+    fb = synth.noise(64, 64, 1)
+    with pytest.raises(timg_amd.TimgHipError) as e:
+        hip.block_encode(fb, 64, 64, flags=1, out_cap=100)
+    assert e.value.code == -4
+
+
+def test_autocrop_bbox(hip):
+    fb = np.zeros((90, 160, 4), np.uint8)
+    fb[...] = (10, 20, 30, 255)
+    fb[17:60, 33:120] = (200, 0, 0, 255)
+    assert hip.autocrop_bbox(fb, 160, 90).tolist() == [[33, 17, 87, 43]]
+    assert hip.autocrop_bbox(fb, 160, 90, crop_border=40).tolist() == [[0, 0, 0, 0]]
+    blank = np.zeros((20, 30, 4), np.uint8)
+    assert hip.autocrop_bbox(blank, 30, 20).tolist() == [[0, 0, 0, 0]]

@@ -1,0 +1,555 @@
+// timg_amd/csrc/block_canvas.hip -- device twin of the pixel work in
+// timg::UnicodeBlockCanvas::Send (src/unicode-block-canvas.cc:323-403).
+//
+// The reference walks cells left to right carrying state (last emitted
+// foreground, previous background).  Rows never share state (locals at
+// :235-240), so the encode splits into:
+//   K1 PickCells   one thread per character cell: FindBestGlyph (:163-227)
+//   K2 ScanRows    one wave per text row: who has to emit fg/bg (:270-297),
+//                  byte length per cell, exclusive prefix inside the row
+//   K3 ScanFrames  one workgroup per frame: row offsets, frame length
+//   K4 EmitCells   one thread per cell: write its bytes at its offset
+// Byte-exact with the reference for a first Send (no frame-diff).
+#include <cstring>
+
+#include "context.h"
+#include "pixel_math.h"
+
+namespace timg_amd {
+namespace {
+
+enum : uint32_t {
+    kBackground = 0,
+    kTopLeft,
+    kTopRight,
+    kBotLeft,
+    kBotRight,
+    kLeftBar,
+    kTopLeftBotRight,
+    kLowerBlock,
+    kUpperBlock,
+};
+
+struct BlockGeom {
+    int w, h;            // framebuffer size in pixels
+    int quarter, upper, color256;
+    int cells;           // character cells per text row
+    int rows;            // text rows: (h + 1) / 2
+    int row_offset;      // -1 when an odd height shifts everything down (:356-358)
+    int indent;          // Send's x in character cells
+    int indent_len;      // strlen("\033[<indent>C") or 0
+    size_t stride, frame_stride;
+};
+
+struct CellRec {  // 16 bytes
+    uint32_t fg, bg;
+    uint32_t meta;  // block | emit_fg << 8 | emit_bg << 9
+    uint32_t off;   // byte offset inside the text row
+};
+
+struct Lin {
+    float r, g, b, a;
+};
+
+__device__ __forceinline__ Lin ToLin(uint32_t px) {  // LinearColor(rgba_t)
+    const uint32_t r = px & 0xffu, g = (px >> 8) & 0xffu, b = (px >> 16) & 0xffu;
+    Lin l;
+    l.r = (float)(r * r);
+    l.g = (float)(g * g);
+    l.b = (float)(b * b);
+    l.a = (float)(px >> 24);
+    return l;
+}
+
+__device__ __forceinline__ uint32_t Repack(const Lin &l) {  // framebuffer.h:150-152
+    return GammaByte(l.r) | (GammaByte(l.g) << 8) | (GammaByte(l.b) << 16) |
+           (((uint32_t)l.a & 0xffu) << 24);
+}
+
+__device__ __forceinline__ float Dist(const Lin &avg, const Lin &m) {
+    const float dr = m.r - avg.r, dg = m.g - avg.g, db = m.b - avg.b;
+    return dr * dr + dg * dg + db * db;
+}
+
+// avd() of src/framebuffer.h:177-194 for 2, 3 and 4 members: running sum from
+// zero in argument order, divide by the count, then summed squared distances.
+__device__ __forceinline__ float Avd2(Lin *res, const Lin &a, const Lin &b) {
+    res->r = ((0.0f + a.r) + b.r) / 2.0f;
+    res->g = ((0.0f + a.g) + b.g) / 2.0f;
+    res->b = ((0.0f + a.b) + b.b) / 2.0f;
+    res->a = ((0.0f + a.a) + b.a) / 2.0f;
+    float s = 0.0f;
+    s += Dist(*res, a);
+    s += Dist(*res, b);
+    return s;
+}
+__device__ __forceinline__ float Avd3(Lin *res, const Lin &a, const Lin &b, const Lin &c) {
+    res->r = (((0.0f + a.r) + b.r) + c.r) / 3.0f;
+    res->g = (((0.0f + a.g) + b.g) + c.g) / 3.0f;
+    res->b = (((0.0f + a.b) + b.b) + c.b) / 3.0f;
+    res->a = (((0.0f + a.a) + b.a) + c.a) / 3.0f;
+    float s = 0.0f;
+    s += Dist(*res, a);
+    s += Dist(*res, b);
+    s += Dist(*res, c);
+    return s;
+}
+__device__ __forceinline__ float Avd4(Lin *res, const Lin &a, const Lin &b, const Lin &c,
+                                      const Lin &d) {
+    res->r = ((((0.0f + a.r) + b.r) + c.r) + d.r) / 4.0f;
+    res->g = ((((0.0f + a.g) + b.g) + c.g) + d.g) / 4.0f;
+    res->b = ((((0.0f + a.b) + b.b) + c.b) + d.b) / 4.0f;
+    res->a = ((((0.0f + a.a) + b.a) + c.a) + d.a) / 4.0f;
+    float s = 0.0f;
+    s += Dist(*res, a);
+    s += Dist(*res, b);
+    s += Dist(*res, c);
+    s += Dist(*res, d);
+    return s;
+}
+
+__device__ __forceinline__ bool Transparent(uint32_t px) { return (px >> 24) < 0x60u; }
+
+// Pixel (row, x) as the reference's pointer arithmetic sees it: rows outside
+// the image are the zeroed empty_line_ (:363-365), and column `w` of an odd-width
+// quarter-block frame is whatever follows in memory -- the next row's first
+// pixel, or the framebuffer's scratch row, pinned to 0.
+__device__ __forceinline__ uint32_t FetchPx(const uint8_t *frame, const BlockGeom &g, int row,
+                                            int x) {
+    if (row < 0 || row >= g.h) return 0u;
+    if (x >= g.w) {
+        row += 1;
+        x = 0;
+        if (row >= g.h) return 0u;
+    }
+    return *reinterpret_cast<const uint32_t *>(frame + (size_t)row * g.stride + (size_t)x * 4);
+}
+
+__global__ void __launch_bounds__(256)
+PickCellsKernel(const uint8_t *fb, BlockGeom g, CellRec *cells) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int trow = blockIdx.y;
+    const int f    = blockIdx.z;
+    if (cell >= g.cells) return;
+    const uint8_t *frame = fb + (size_t)f * g.frame_stride;
+    const int top_row    = 2 * trow + g.row_offset;
+    CellRec rec;
+    rec.off = 0;
+    if (!g.quarter) {
+        const uint32_t top = FetchPx(frame, g, top_row, cell);
+        const uint32_t bot = FetchPx(frame, g, top_row + 1, cell);
+        if (top == bot || (Transparent(top) && Transparent(bot))) {
+            rec.fg   = top;
+            rec.bg   = bot;
+            rec.meta = kBackground;
+        } else if (g.upper) {
+            rec.fg   = top;
+            rec.bg   = bot;
+            rec.meta = kUpperBlock;
+        } else {
+            rec.fg   = bot;
+            rec.bg   = top;
+            rec.meta = kLowerBlock;
+        }
+    } else {
+        const int x       = cell * 2;
+        const uint32_t p0 = FetchPx(frame, g, top_row, x);
+        const uint32_t p1 = FetchPx(frame, g, top_row, x + 1);
+        const uint32_t p2 = FetchPx(frame, g, top_row + 1, x);
+        const uint32_t p3 = FetchPx(frame, g, top_row + 1, x + 1);
+        const Lin tl = ToLin(p0), tr = ToLin(p1), bl = ToLin(p2), br = ToLin(p3);
+        const bool t_top = Transparent(p0) && Transparent(p1);
+        const bool t_bot = Transparent(p2) && Transparent(p3);
+        if (t_top && t_bot) {
+            rec.fg   = p2;
+            rec.bg   = p0;
+            rec.meta = kBackground;
+        } else if (t_top) {
+            Lin avg;
+            Avd2(&avg, bl, br);
+            rec.fg   = Repack(avg);
+            rec.bg   = p0;
+            rec.meta = kLowerBlock;
+        } else if (t_bot) {
+            Lin avg;
+            Avd2(&avg, tl, tr);
+            rec.fg   = Repack(avg);
+            rec.bg   = p2;
+            rec.meta = kUpperBlock;
+        } else {
+            Lin best_fg = {0, 0, 0, 0}, best_bg = {0, 0, 0, 0};
+            uint32_t best_block = kBackground;
+            float best          = 1e12f;
+            bool done           = false;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (done) continue;
+                Lin fg, bg;
+                float d;
+                uint32_t block = b;
+                switch (b) {
+                case 0: d = Avd4(&bg, tl, tr, bl, br); fg = bg; break;
+                case 1: d = Avd3(&bg, tr, bl, br); fg = tl; break;
+                case 2: d = Avd3(&bg, tl, bl, br); fg = tr; break;
+                case 3: d = Avd3(&bg, tl, tr, br); fg = bl; break;
+                case 4: d = Avd3(&bg, tl, tr, bl); fg = br; break;
+                case 5: d = Avd2(&bg, tr, br) + Avd2(&fg, tl, bl); break;
+                case 6: d = Avd2(&bg, tr, bl) + Avd2(&fg, tl, br); break;
+                default:
+                    if (g.upper) {
+                        block = kUpperBlock;
+                        d     = Avd2(&bg, bl, br) + Avd2(&fg, tl, tr);
+                    } else {
+                        block = kLowerBlock;
+                        d     = Avd2(&bg, tl, tr) + Avd2(&fg, bl, br);
+                    }
+                    break;
+                }
+                if (d < best) {
+                    best_fg    = fg;
+                    best_bg    = bg;
+                    best_block = block;
+                    if (d < 1.0f)
+                        done = true;  // "essentially zero": stop searching (:222)
+                    else
+                        best = d;
+                }
+            }
+            rec.fg   = Repack(best_fg);
+            rec.bg   = Repack(best_bg);
+            rec.meta = best_block;
+        }
+    }
+    cells[((size_t)f * g.rows + trow) * g.cells + cell] = rec;
+}
+
+__device__ __forceinline__ uint32_t DigitsLen(uint32_t v) {  // "ddd;" length
+    return v >= 100 ? 4u : (v >= 10 ? 3u : 2u);
+}
+
+__device__ __forceinline__ uint32_t Term256(uint32_t px) {  // framebuffer.h:37-52
+    const uint32_t r = px & 0xffu, g = (px >> 8) & 0xffu, b = (px >> 16) & 0xffu;
+    if (r == g && g == b) return 232u + (r * 23u / 255u);
+    auto cube = [](uint32_t v) -> uint32_t {
+        return v < 0x5f / 2            ? 0
+               : v < (0x5f + 0x87) / 2 ? 1
+               : v < (0x87 + 0xaf) / 2 ? 2
+               : v < (0xaf + 0xd7) / 2 ? 3
+               : v < (0xd7 + 0xff) / 2 ? 4
+                                       : 5;
+    };
+    return 16u + 36u * cube(r) + 6u * cube(g) + cube(b);
+}
+
+__device__ __forceinline__ uint32_t ColorLen(uint32_t px, int color256) {
+    if (color256) return DigitsLen(Term256(px));
+    return DigitsLen(px & 0xffu) + DigitsLen((px >> 8) & 0xffu) + DigitsLen((px >> 16) & 0xffu);
+}
+
+// One wave (64 lanes) per text row.
+__global__ void __launch_bounds__(64)
+ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
+    const int lane = threadIdx.x;
+    const int trow = blockIdx.x;
+    const int f    = blockIdx.y;
+    CellRec *row   = cells + ((size_t)f * g.rows + trow) * g.cells;
+
+    // carried across 64-cell chunks
+    bool have_fg      = false;  // a non-background cell was seen: last_fg valid
+    uint32_t last_fg  = 0;
+    bool have_bg      = false;
+    uint32_t prev_bg  = 0;
+    uint32_t base_off = (uint32_t)g.indent_len;
+
+    for (int c0 = 0; c0 < g.cells; c0 += 64) {
+        const int i      = c0 + lane;
+        const bool live  = i < g.cells;
+        CellRec rec      = live ? row[i] : CellRec{0, 0, 0, 0};
+        const bool nonbg = live && (rec.meta & 0xffu) != kBackground;
+
+        // fg of the nearest earlier non-background cell (the reference's
+        // last_foreground: it only changes when a non-background cell emits,
+        // and then equals that cell's fg, :270-279).
+        int src = nonbg ? lane : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(src, d);
+            if (lane >= d) src = src > o ? src : o;
+        }
+        int prev_src = __shfl_up(src, 1);
+        if (lane == 0) prev_src = -1;
+        const uint32_t fg_from_lane = __shfl(rec.fg, prev_src < 0 ? 0 : prev_src);
+        const bool prev_known       = prev_src >= 0 || have_fg;
+        const uint32_t prev_fg      = prev_src >= 0 ? fg_from_lane : last_fg;
+        const bool emit_fg          = nonbg && (!prev_known || rec.fg != prev_fg);
+
+        uint32_t left_bg = __shfl_up(rec.bg, 1);
+        bool left_known  = true;
+        if (lane == 0) {
+            left_bg    = prev_bg;
+            left_known = have_bg;
+        }
+        const bool emit_bg = live && (!left_known || rec.bg != left_bg);
+
+        uint32_t len = 0;
+        if (live) {
+            if (emit_fg || emit_bg) len += 2;  // ESC [
+            if (emit_fg) len += 5 + ColorLen(rec.fg, g.color256);
+            if (emit_bg) len += Transparent(rec.bg) ? 3u : 5u + ColorLen(rec.bg, g.color256);
+            len += (rec.meta & 0xffu) == kBackground ? 1u : 3u;
+        }
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (live) {
+            rec.off  = base_off + incl - len;
+            rec.meta = (rec.meta & 0xffu) | (emit_fg ? 0x100u : 0u) | (emit_bg ? 0x200u : 0u);
+            row[i]   = rec;
+        }
+        // carry
+        const int last_lane   = (g.cells - c0) >= 64 ? 63 : (g.cells - c0 - 1);
+        base_off += __shfl(incl, last_lane);
+        const int chunk_src   = __shfl(src, last_lane);
+        const uint32_t cfg    = __shfl(rec.fg, chunk_src < 0 ? 0 : chunk_src);
+        if (chunk_src >= 0) {
+            have_fg = true;
+            last_fg = cfg;
+        }
+        prev_bg = __shfl(rec.bg, last_lane);
+        have_bg = true;
+    }
+    if (lane == 0) row_len[(size_t)f * g.rows + trow] = base_off + 5;  // + "\033[0m\n"
+}
+
+// One workgroup per frame: exclusive scan of the row lengths (in place ->
+// row offsets) and the frame total.
+__global__ void __launch_bounds__(256)
+ScanFramesKernel(BlockGeom g, uint32_t *row_len, unsigned long long *frame_len) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t carry;
+    const int f    = blockIdx.x;
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    uint32_t *rl   = row_len + (size_t)f * g.rows;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < g.rows; r0 += 256) {
+        const int r      = r0 + tid;
+        const uint32_t v = r < g.rows ? rl[r] : 0u;
+        uint32_t incl    = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int k = 0; k < wv; ++k) before += wave_tot[k];
+        if (r < g.rows) rl[r] = before + incl - v;
+        __syncthreads();
+        if (tid == 255) carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) frame_len[f] = carry;
+}
+
+__device__ __forceinline__ char *PutNum(char *p, uint32_t v) {  // "ddd;"
+    if (v >= 100) {
+        *p++ = (char)('0' + v / 100);
+        v %= 100;
+        *p++ = (char)('0' + v / 10);
+        *p++ = (char)('0' + v % 10);
+    } else if (v >= 10) {
+        *p++ = (char)('0' + v / 10);
+        *p++ = (char)('0' + v % 10);
+    } else {
+        *p++ = (char)('0' + v);
+    }
+    *p++ = ';';
+    return p;
+}
+
+__device__ __forceinline__ char *PutColor(char *p, uint32_t px, int color256) {
+    if (color256) return PutNum(p, Term256(px));
+    p = PutNum(p, px & 0xffu);
+    p = PutNum(p, (px >> 8) & 0xffu);
+    return PutNum(p, (px >> 16) & 0xffu);
+}
+
+__constant__ unsigned char kGlyphBytes[9][3] = {
+    {' ', 0, 0},        {0xe2, 0x96, 0x98}, {0xe2, 0x96, 0x9d}, {0xe2, 0x96, 0x96},
+    {0xe2, 0x96, 0x97}, {0xe2, 0x96, 0x8c}, {0xe2, 0x96, 0x9a}, {0xe2, 0x96, 0x84},
+    {0xe2, 0x96, 0x80},
+};
+
+__global__ void __launch_bounds__(256)
+EmitCellsKernel(BlockGeom g, const CellRec *cells, const uint32_t *row_off, char *out,
+                size_t out_cap) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int trow = blockIdx.y;
+    const int f    = blockIdx.z;
+    if (cell >= g.cells) return;
+    const size_t row_index = (size_t)f * g.rows + trow;
+    const CellRec rec      = cells[row_index * g.cells + cell];
+    const size_t row_base  = row_off[row_index];
+    char *frame_out        = out + (size_t)f * out_cap;
+
+    char buf[48];
+    char *p              = buf;
+    const uint32_t block = rec.meta & 0xffu;
+    const bool emit_fg = rec.meta & 0x100u, emit_bg = rec.meta & 0x200u;
+    if (emit_fg || emit_bg) {
+        *p++ = '\033';
+        *p++ = '[';
+    }
+    if (emit_fg) {
+        *p++ = '3'; *p++ = '8'; *p++ = ';'; *p++ = g.color256 ? '5' : '2'; *p++ = ';';
+        p = PutColor(p, rec.fg, g.color256);
+    }
+    if (emit_bg) {
+        if (Transparent(rec.bg)) {
+            *p++ = '4'; *p++ = '9'; *p++ = ';';
+        } else {
+            *p++ = '4'; *p++ = '8'; *p++ = ';'; *p++ = g.color256 ? '5' : '2'; *p++ = ';';
+            p = PutColor(p, rec.bg, g.color256);
+        }
+    }
+    if (emit_fg || emit_bg) p[-1] = 'm';
+    if (block == kBackground) {
+        *p++ = ' ';
+    } else {
+        *p++ = (char)kGlyphBytes[block][0];
+        *p++ = (char)kGlyphBytes[block][1];
+        *p++ = (char)kGlyphBytes[block][2];
+    }
+    const size_t at = row_base + rec.off;
+    const int n     = (int)(p - buf);
+    for (int i = 0; i < n; ++i)
+        if (at + i < out_cap) frame_out[at + i] = buf[i];
+
+    if (cell == 0 && g.indent_len > 0) {  // "\033[<indent>C", :260-263
+        char ib[16];
+        int k        = 0;
+        ib[k++]      = '\033';
+        ib[k++]      = '[';
+        char digits[12];
+        int nd       = 0;
+        uint32_t v   = (uint32_t)g.indent;
+        do {
+            digits[nd++] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        while (nd) ib[k++] = digits[--nd];
+        ib[k++] = 'C';
+        for (int i = 0; i < k; ++i)
+            if (row_base + i < out_cap) frame_out[row_base + i] = ib[i];
+    }
+    if (cell == g.cells - 1) {  // "\033[0m\n", :313-318
+        const char tail[5] = {'\033', '[', '0', 'm', '\n'};
+        const size_t e     = at + n;
+        for (int i = 0; i < 5; ++i)
+            if (e + i < out_cap) frame_out[e + i] = tail[i];
+    }
+}
+
+}  // namespace
+}  // namespace timg_amd
+
+using namespace timg_amd;
+
+extern "C" {
+
+size_t timg_hip_block_max_bytes(int w, int h) {
+    // RequestBuffers (:405-424): cursor-up + per text row (cursor-right +
+    // width * widest cell + end of line)
+    const size_t max_pixel = 2 + 5 + 11 + 1 + 5 + 11 + 1 + 3;
+    const size_t rows      = (size_t)(h + 1) / 2;
+    return 8 + rows * (8 + (size_t)w * max_pixel + 5);
+}
+
+int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                          size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                          int x_indent, char *out, size_t out_cap, int out_on_device,
+                          size_t *out_len, void *stream) {
+    if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0 || x_indent < 0)
+        return TIMG_HIP_ERR_ARG;
+    if (stride == 0) stride = w * 4;
+    if (stride < w * 4 || (stride & 3) || ((uintptr_t)fb & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride/alignment");
+    if (frame_stride == 0) frame_stride = (size_t)stride * h;
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->Stream(stream);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+
+    BlockGeom g;
+    g.w            = w;
+    g.h            = h;
+    g.quarter      = (flags & TIMG_HIP_BLOCK_QUARTER) != 0;
+    g.upper        = (flags & TIMG_HIP_BLOCK_UPPER) != 0;
+    g.color256     = (flags & TIMG_HIP_BLOCK_COLOR256) != 0;
+    g.cells        = g.quarter ? (w + 1) / 2 : w;
+    g.rows         = (h + 1) / 2;
+    g.row_offset   = ((h & 1) && !g.upper) ? -1 : 0;
+    g.indent       = g.quarter ? x_indent / 2 : x_indent;
+    g.indent_len   = 0;
+    if (g.indent > 0) {
+        char tmp[32];
+        g.indent_len = snprintf(tmp, sizeof(tmp), "\033[%dC", g.indent);
+    }
+    g.stride       = (size_t)stride;
+    g.frame_stride = frame_stride;
+
+    const size_t fb_bytes = frame_stride * (size_t)(n_frames - 1) + (size_t)stride * h;
+    const uint8_t *dfb    = fb;
+    if (!fb_on_device) {
+        TIMG_HIP_TRY(ctx, ctx->dev[0].Reserve(fb_bytes));
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].ptr, fb, fb_bytes, hipMemcpyHostToDevice, st));
+        dfb = (const uint8_t *)ctx->dev[0].ptr;
+    }
+    char *dout = out;
+    if (!out_on_device) {
+        TIMG_HIP_TRY(ctx, ctx->dev[1].Reserve(out_cap * (size_t)n_frames));
+        dout = (char *)ctx->dev[1].ptr;
+    }
+    const size_t n_rows  = (size_t)g.rows * n_frames;
+    const size_t n_cells = n_rows * g.cells;
+    TIMG_HIP_TRY(ctx, ctx->dev[3].Reserve(n_cells * sizeof(CellRec)));
+    TIMG_HIP_TRY(ctx, ctx->dev[4].Reserve(n_rows * sizeof(uint32_t)));
+    TIMG_HIP_TRY(ctx, ctx->dev[2].Reserve(sizeof(unsigned long long) * n_frames));
+    TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * n_frames));
+    CellRec *cells              = (CellRec *)ctx->dev[3].ptr;
+    uint32_t *row_len           = (uint32_t *)ctx->dev[4].ptr;
+    unsigned long long *flen    = (unsigned long long *)ctx->dev[2].ptr;
+    unsigned long long *flen_h  = (unsigned long long *)ctx->pin[0].ptr;
+
+    const dim3 cell_grid((g.cells + 255) / 256, g.rows, n_frames);
+    hipLaunchKernelGGL(PickCellsKernel, cell_grid, dim3(256), 0, st, dfb, g, cells);
+    hipLaunchKernelGGL(ScanRowsKernel, dim3(g.rows, n_frames), dim3(64), 0, st, g, cells, row_len);
+    hipLaunchKernelGGL(ScanFramesKernel, dim3(n_frames), dim3(256), 0, st, g, row_len, flen);
+    hipLaunchKernelGGL(EmitCellsKernel, cell_grid, dim3(256), 0, st, g, cells, row_len, dout,
+                       out_cap);
+    TIMG_HIP_TRY(ctx, hipGetLastError());
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(flen_h, flen, sizeof(unsigned long long) * n_frames,
+                                     hipMemcpyDeviceToHost, st));
+    TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    size_t worst = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        out_len[i] = (size_t)flen_h[i];
+        if (out_len[i] > worst) worst = out_len[i];
+    }
+    if (worst > out_cap)
+        return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %zu bytes, out_cap is %zu", worst, out_cap);
+    if (!out_on_device) {
+        for (int i = 0; i < n_frames; ++i)
+            TIMG_HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * out_cap, dout + (size_t)i * out_cap,
+                                             out_len[i], hipMemcpyDeviceToHost, st));
+        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    return TIMG_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// timg_amd/csrc/capi.hip -- C-ABI of libtimg_hip.so (include/timg_hip.h):
+// context, memory helpers, the ImageScaler twin and the standalone alpha
+// compose.  Canvas entry points live in block_canvas.hip / sixel_canvas.hip.
+#include <cstring>
+#include <new>
+
+#include "context.h"
+
+using timg_amd::DevBlend;
+using timg_amd::DevPlan;
+using timg_amd::FrameBatch;
+
+static thread_local std::string g_global_error;
+
+namespace timg_amd {
+hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
+                             const FrameBatch &batch, hipStream_t stream);
+bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not);
+void ReleaseStreamSchedule(timg_hip_scaler *s);
+}  // namespace timg_amd
+
+DevBlend MakeDevBlend(const timg_hip_blend *b) {
+    DevBlend d;
+    memset(&d, 0, sizeof(d));
+    d.pw = d.ph = 1;
+    if (!b) return d;
+    d.start_row = b->start_row < 0 ? 0 : b->start_row;
+    if (!b->enabled) return d;
+    const uint32_t bg = b->bg, pat = b->pattern;
+    if ((bg >> 24) == 0) return d;  // "nothing to do", src/framebuffer.cc:120-121
+    d.enabled = 1;
+    auto lin = [](uint32_t c, float out[3]) {
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t v = (c >> (8 * i)) & 0xffu;
+            out[i]           = (float)(v * v);
+        }
+    };
+    lin(bg, d.bg);
+    lin(pat, d.pat);
+    // src/framebuffer.cc:124-125
+    d.checker = !((pat >> 24) == 0 || pat == bg || b->pattern_w <= 0 || b->pattern_h <= 0);
+    if (d.checker) {
+        d.pw = b->pattern_w;
+        d.ph = b->pattern_h;
+    }
+    return d;
+}
+
+extern "C" {
+
+int timg_hip_version(void) { return (1 << 16) | 0; }
+
+const char *timg_hip_last_error(const timg_hip_ctx *ctx) {
+    return ctx ? ctx->last_error.c_str() : g_global_error.c_str();
+}
+
+int timg_hip_init(int device, timg_hip_ctx **out) {
+    if (!out) return TIMG_HIP_ERR_ARG;
+    *out      = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_global_error = std::string("no HIP device: ") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "count is 0");
+        return TIMG_HIP_ERR_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_global_error = "device index out of range";
+        return TIMG_HIP_ERR_ARG;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_global_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return TIMG_HIP_ERR_DEVICE;
+    }
+    timg_hip_ctx *ctx = new (std::nothrow) timg_hip_ctx();
+    if (!ctx) return TIMG_HIP_ERR_NOMEM;
+    ctx->device = device;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_global_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return TIMG_HIP_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        ctx->cu_count = prop.multiProcessorCount;
+    *out = ctx;
+    return TIMG_HIP_OK;
+}
+
+void timg_hip_destroy(timg_hip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->dev) b.Release();
+    for (auto &b : ctx->pin) b.Release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int timg_hip_malloc(timg_hip_ctx *ctx, size_t bytes, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return TIMG_HIP_ERR_ARG;
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dev_ptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return ctx->Fail(TIMG_HIP_ERR_NOMEM, "hipMalloc(%zu)", bytes);
+    if (e != hipSuccess) return ctx->FailHip(e, "hipMalloc");
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_free(timg_hip_ctx *ctx, void *dev_ptr) {
+    if (!ctx) return TIMG_HIP_ERR_ARG;
+    TIMG_HIP_TRY(ctx, hipFree(dev_ptr));
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_memcpy_h2d(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream) {
+    if (!ctx) return TIMG_HIP_ERR_ARG;
+    hipStream_t st = ctx->Stream(stream);
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st));
+    TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_memcpy_d2h(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream) {
+    if (!ctx) return TIMG_HIP_ERR_ARG;
+    hipStream_t st = ctx->Stream(stream);
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st));
+    TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_sync(timg_hip_ctx *ctx, void *stream) {
+    if (!ctx) return TIMG_HIP_ERR_ARG;
+    TIMG_HIP_TRY(ctx, hipStreamSynchronize(ctx->Stream(stream)));
+    return TIMG_HIP_OK;
+}
+
+// ---- scaler ------------------------------------------------------------------
+
+int timg_hip_scaler_create(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, int out_w,
+                           int out_h, int filter, timg_hip_scaler **out) {
+    if (!ctx || !out) return TIMG_HIP_ERR_ARG;
+    *out = nullptr;
+    if (in_fmt != TIMG_HIP_FMT_RGBA && in_fmt != TIMG_HIP_FMT_BGRA)
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "unknown input format %d", in_fmt);
+    if (filter != TIMG_HIP_FILTER_STB_DEFAULT && filter != TIMG_HIP_FILTER_TRIANGLE)
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "unknown filter %d", filter);
+    timg_hip_scaler *s = new (std::nothrow) timg_hip_scaler();
+    if (!s) return TIMG_HIP_ERR_NOMEM;
+    s->ctx = ctx;
+    if (!timg_amd::BuildResamplePlan(in_w, in_h, in_fmt, out_w, out_h, filter, &s->plan)) {
+        delete s;
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad geometry %dx%d -> %dx%d", in_w, in_h, out_w,
+                         out_h);
+    }
+    const timg_amd::ResamplePlan &p = s->plan;
+    // One device allocation, sections 16-byte aligned.
+    auto align = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_ht = 0;
+    const size_t o_hc = align(o_ht + p.h_taps.size() * sizeof(int2));
+    const size_t o_vr = align(o_hc + p.h_coeff.size() * sizeof(float));
+    const size_t o_vi = align(o_vr + p.v_runs.size() * sizeof(int2));
+    const size_t o_vc = align(o_vi + p.v_rows.size() * sizeof(int));
+    const size_t total = align(o_vc + p.v_coeff.size() * sizeof(float));
+    std::vector<char> host(total, 0);
+    memcpy(&host[o_ht], p.h_taps.data(), p.h_taps.size() * sizeof(int2));
+    memcpy(&host[o_hc], p.h_coeff.data(), p.h_coeff.size() * sizeof(float));
+    memcpy(&host[o_vr], p.v_runs.data(), p.v_runs.size() * sizeof(int2));
+    memcpy(&host[o_vi], p.v_rows.data(), p.v_rows.size() * sizeof(int));
+    memcpy(&host[o_vc], p.v_coeff.data(), p.v_coeff.size() * sizeof(float));
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&s->tables, total);
+    if (e == hipSuccess) e = hipMemcpy(s->tables, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (s->tables) (void)hipFree(s->tables);
+        delete s;
+        return ctx->FailHip(e, "uploading resample tables");
+    }
+    char *base             = (char *)s->tables;
+    s->dev.in_w            = in_w;
+    s->dev.in_h            = in_h;
+    s->dev.out_w           = out_w;
+    s->dev.out_h           = out_h;
+    s->dev.swap_rb         = in_fmt == TIMG_HIP_FMT_BGRA;
+    s->dev.vertical_first  = p.vertical_first;
+    s->dev.h_sequential    = p.h_sequential;
+    s->dev.h_width         = p.h_width;
+    s->dev.h_taps          = (const int2 *)(base + o_ht);
+    s->dev.h_coeff         = (const float *)(base + o_hc);
+    s->dev.v_runs          = (const int2 *)(base + o_vr);
+    s->dev.v_rows          = (const int *)(base + o_vi);
+    s->dev.v_coeff         = (const float *)(base + o_vc);
+    std::string why;
+    s->streaming_ok = timg_amd::PrepareStreamSchedule(s, &why);
+    *out            = s;
+    return TIMG_HIP_OK;
+}
+
+void timg_hip_scaler_destroy(timg_hip_scaler *s) {
+    if (!s) return;
+    timg_amd::ReleaseStreamSchedule(s);
+    if (s->tables) (void)hipFree(s->tables);
+    delete s;
+}
+
+int timg_hip_scaler_set_kernel(timg_hip_scaler *s, int which) {
+    if (!s || which < 0 || which > 2) return TIMG_HIP_ERR_ARG;
+    if (which == 2 && !s->streaming_ok)
+        return s->ctx->Fail(TIMG_HIP_ERR_UNSUPP, "streaming kernel does not cover this plan");
+    s->forced_kernel = which;
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_scaler_info(const timg_hip_scaler *s, int info[8]) {
+    if (!s || !info) return TIMG_HIP_ERR_ARG;
+    info[0] = s->plan.vertical_first;
+    info[1] = s->plan.h_width;
+    info[2] = s->plan.v_is_gather;
+    info[3] = s->plan.v_widest;
+    info[4] = s->plan.h_filter;
+    info[5] = s->plan.v_filter;
+    info[6] = s->streaming_ok;
+    info[7] = s->plan.max_active_rows;
+    return TIMG_HIP_OK;
+}
+
+size_t timg_hip_scaler_algorithmic_bytes(const timg_hip_scaler *s) {
+    if (!s) return 0;
+    return (size_t)4 * s->plan.in_w * s->plan.in_h + (size_t)4 * s->plan.out_w * s->plan.out_h;
+}
+
+int timg_hip_scale_blend(timg_hip_ctx *ctx, timg_hip_scaler *s, const uint8_t *src,
+                         int src_stride, size_t src_frame_stride, int src_on_device,
+                         uint8_t *dst, int dst_stride, size_t dst_frame_stride,
+                         int dst_on_device, int n_frames, const timg_hip_blend *blend,
+                         int *any_transparent, void *stream) {
+    if (!ctx || !s || !src || !dst || n_frames <= 0) return TIMG_HIP_ERR_ARG;
+    if (s->ctx != ctx) return ctx->Fail(TIMG_HIP_ERR_ARG, "scaler belongs to another context");
+    const timg_amd::ResamplePlan &p = s->plan;
+    if (src_stride == 0) src_stride = p.in_w * 4;
+    if (dst_stride == 0) dst_stride = p.out_w * 4;
+    if (src_stride < p.in_w * 4 || dst_stride < p.out_w * 4 || (src_stride & 3) ||
+        (dst_stride & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride");
+    if (src_frame_stride == 0) src_frame_stride = (size_t)src_stride * p.in_h;
+    if (dst_frame_stride == 0) dst_frame_stride = (size_t)dst_stride * p.out_h;
+    if (((uintptr_t)src & 3) || ((uintptr_t)dst & 3) || (src_frame_stride & 3) ||
+        (dst_frame_stride & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "buffers must be 4-byte aligned");
+
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->Stream(stream);
+    std::unique_lock<std::mutex> lock(ctx->mu, std::defer_lock);
+    const bool uses_scratch = !src_on_device || !dst_on_device || any_transparent;
+    if (uses_scratch) lock.lock();
+
+    FrameBatch batch;
+    batch.n_frames          = n_frames;
+    batch.src_stride        = (size_t)src_stride;
+    batch.src_frame_stride  = src_frame_stride;
+    batch.dst_stride        = (size_t)dst_stride;
+    batch.dst_frame_stride  = dst_frame_stride;
+    batch.transparent_flags = nullptr;
+
+    const size_t src_bytes = src_frame_stride * (size_t)(n_frames - 1) + (size_t)src_stride * p.in_h;
+    const size_t dst_bytes = dst_frame_stride * (size_t)(n_frames - 1) + (size_t)dst_stride * p.out_h;
+    if (src_on_device) {
+        batch.src = src;
+    } else {
+        TIMG_HIP_TRY(ctx, ctx->dev[0].Reserve(src_bytes));
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].ptr, src, src_bytes, hipMemcpyHostToDevice, st));
+        batch.src = (const uint8_t *)ctx->dev[0].ptr;
+    }
+    if (dst_on_device) {
+        batch.dst = dst;
+    } else {
+        TIMG_HIP_TRY(ctx, ctx->dev[1].Reserve(dst_bytes));
+        batch.dst = (uint8_t *)ctx->dev[1].ptr;
+    }
+    if (any_transparent) {
+        TIMG_HIP_TRY(ctx, ctx->dev[2].Reserve(sizeof(int) * n_frames));
+        TIMG_HIP_TRY(ctx, hipMemsetAsync(ctx->dev[2].ptr, 0, sizeof(int) * n_frames, st));
+        batch.transparent_flags = (int *)ctx->dev[2].ptr;
+    }
+
+    const DevBlend db = MakeDevBlend(blend);
+    hipError_t e;
+    if (p.identity) {
+        e = timg_amd::LaunchCopyBlend(s->dev, db, batch, st);
+    } else {
+        const bool want_stream =
+            s->forced_kernel == 2 || (s->forced_kernel == 0 && s->streaming_ok);
+        e = want_stream ? timg_amd::LaunchScaleStream(s, db, batch, st)
+                        : timg_amd::LaunchScaleGeneric(s->dev, db, batch, st);
+    }
+    if (e != hipSuccess) return ctx->FailHip(e, "scale kernel launch");
+
+    if (!dst_on_device)
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(dst, batch.dst, dst_bytes, hipMemcpyDeviceToHost, st));
+    if (any_transparent)
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(any_transparent, batch.transparent_flags,
+                                         sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
+    if (uses_scratch) TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_alpha_compose(timg_hip_ctx *ctx, uint8_t *fb, int w, int h, int stride,
+                           size_t frame_stride, int on_device, int n_frames,
+                           const timg_hip_blend *blend, int *any_transparent, void *stream) {
+    if (!ctx || !fb || w <= 0 || h <= 0 || n_frames <= 0 || !blend) return TIMG_HIP_ERR_ARG;
+    if (stride == 0) stride = w * 4;
+    if (stride < w * 4 || (stride & 3) || ((uintptr_t)fb & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride/alignment");
+    if (frame_stride == 0) frame_stride = (size_t)stride * h;
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->Stream(stream);
+    std::unique_lock<std::mutex> lock(ctx->mu, std::defer_lock);
+    const bool uses_scratch = !on_device || any_transparent;
+    if (uses_scratch) lock.lock();
+    const size_t bytes = frame_stride * (size_t)(n_frames - 1) + (size_t)stride * h;
+    uint8_t *dfb       = fb;
+    if (!on_device) {
+        TIMG_HIP_TRY(ctx, ctx->dev[0].Reserve(bytes));
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].ptr, fb, bytes, hipMemcpyHostToDevice, st));
+        dfb = (uint8_t *)ctx->dev[0].ptr;
+    }
+    int *flags = nullptr;
+    if (any_transparent) {
+        TIMG_HIP_TRY(ctx, ctx->dev[2].Reserve(sizeof(int) * n_frames));
+        TIMG_HIP_TRY(ctx, hipMemsetAsync(ctx->dev[2].ptr, 0, sizeof(int) * n_frames, st));
+        flags = (int *)ctx->dev[2].ptr;
+    }
+    const DevBlend db = MakeDevBlend(blend);
+    hipError_t e = timg_amd::LaunchAlphaCompose(dfb, w, h, (size_t)stride, frame_stride, n_frames,
+                                                db, flags, st);
+    if (e != hipSuccess) return ctx->FailHip(e, "alpha compose launch");
+    if (!on_device)
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(fb, dfb, bytes, hipMemcpyDeviceToHost, st));
+    if (any_transparent)
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(any_transparent, flags, sizeof(int) * n_frames,
+                                         hipMemcpyDeviceToHost, st));
+    if (uses_scratch) TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return TIMG_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// timg_amd/csrc/context.h -- internal definitions behind the opaque handles of
+// include/timg_hip.h.
+#ifndef TIMG_AMD_CONTEXT_H
+#define TIMG_AMD_CONTEXT_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/timg_hip.h"
+#include "device_plan.h"
+#include "resample_plan.h"
+
+// Growable device / pinned-host scratch area.
+struct TimgBuffer {
+    void *ptr     = nullptr;
+    size_t bytes  = 0;
+    bool pinned   = false;
+    hipError_t Reserve(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (ptr) {
+            if (pinned)
+                (void)hipHostFree(ptr);
+            else
+                (void)hipFree(ptr);
+            ptr   = nullptr;
+            bytes = 0;
+        }
+        // grow geometrically so repeated calls settle quickly
+        size_t cap = want + want / 4 + 256;
+        hipError_t e = pinned ? hipHostMalloc(&ptr, cap, hipHostMallocDefault)
+                              : hipMalloc(&ptr, cap);
+        if (e == hipSuccess) bytes = cap;
+        return e;
+    }
+    void Release() {
+        if (ptr) {
+            if (pinned)
+                (void)hipHostFree(ptr);
+            else
+                (void)hipFree(ptr);
+        }
+        ptr   = nullptr;
+        bytes = 0;
+    }
+};
+
+struct timg_hip_ctx {
+    int device          = 0;
+    hipStream_t stream  = nullptr;  // used when the caller passes stream == NULL
+    std::mutex mu;                  // serialises scratch use per context
+    std::string last_error;
+    int cu_count = 0;
+
+    // scratch: [0] staged source, [1] staged destination, [2] flags/lengths,
+    // [3..] canvas intermediates
+    TimgBuffer dev[8];
+    TimgBuffer pin[4];
+
+    timg_hip_ctx() {
+        for (auto &p : pin) p.pinned = true;
+    }
+    int Fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        last_error = buf;
+        return code;
+    }
+    int FailHip(hipError_t e, const char *what) {
+        return Fail(TIMG_HIP_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+    }
+    hipStream_t Stream(void *s) { return s ? (hipStream_t)s : stream; }
+};
+
+struct timg_hip_scaler {
+    timg_hip_ctx *ctx = nullptr;
+    timg_amd::ResamplePlan plan;
+    timg_amd::DevPlan dev{};
+    void *tables      = nullptr;  // one allocation holding every table
+    int forced_kernel = 0;
+    bool streaming_ok = false;
+    // streaming-kernel schedule (see scale_stream.hip)
+    void *stream_tables = nullptr;
+    int stream_cfg[8]   = {0};
+};
+
+// Shared by the canvas entry points.
+timg_amd::DevBlend MakeDevBlend(const timg_hip_blend *b);
+
+#define TIMG_HIP_TRY(ctx, expr)                                  \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) return (ctx)->FailHip(_e, #expr); \
+    } while (0)
+
+#endif

@@ -1,0 +1,91 @@
+// timg_amd/csrc/pixel_math.h -- device-side per-pixel arithmetic shared by the
+// scale, blend and canvas kernels.  Everything here must round exactly like
+// the reference's CPU code, so this translation unit is built with
+// -ffp-contract=off (no FMA contraction) and relies on hipcc's default
+// correctly-rounded fp32 divide and sqrt.
+#ifndef TIMG_AMD_PIXEL_MATH_H
+#define TIMG_AMD_PIXEL_MATH_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace timg_amd {
+
+// 2^-120: stb's "small float" (stb_image_resize2.h:1104)
+#define TIMG_TINY_F32 0x1p-120f
+
+// A decoded, alpha-weighted source pixel as stb keeps it internally:
+// R G B A R*A G*A B*A, each channel u8/255 (stb_image_resize2.h:8300-8321,
+// 4081-4175).
+struct Px7 {
+    float c[7];
+};
+
+__device__ __forceinline__ Px7 DecodePx(uint32_t px, int swap_rb) {
+    const float k = 1.0f / 255.0f;
+    float r       = (float)(px & 0xffu) * k;
+    const float g = (float)((px >> 8) & 0xffu) * k;
+    float b       = (float)((px >> 16) & 0xffu) * k;
+    const float a = (float)(px >> 24) * k;
+    if (swap_rb) {
+        const float t = r;
+        r             = b;
+        b             = t;
+    }
+    Px7 o;
+    o.c[0] = r;
+    o.c[1] = g;
+    o.c[2] = b;
+    o.c[3] = a;
+    o.c[4] = r * a;
+    o.c[5] = g * a;
+    o.c[6] = b * a;
+    return o;
+}
+
+__device__ __forceinline__ uint32_t ToByte(float v) {
+    // stb_image_resize2.h:8415-8432 / 1391-1403: v*255 + 0.5, clamp, truncate
+    float f = v * 255.0f + 0.5f;
+    f       = f < 0.0f ? 0.0f : f;
+    f       = f > 255.0f ? 255.0f : f;
+    return (uint32_t)f;
+}
+
+// Undo the alpha weighting (stb_image_resize2.h:4247-4292) and quantise.
+__device__ __forceinline__ uint32_t EncodePx(const Px7 &p) {
+    const float alpha = p.c[3];
+    float r, g, b;
+    if (alpha < TIMG_TINY_F32) {
+        r = p.c[0];
+        g = p.c[1];
+        b = p.c[2];
+    } else {
+        const float inv = 1.0f / alpha;
+        r               = p.c[4] * inv;
+        g               = p.c[5] * inv;
+        b               = p.c[6] * inv;
+    }
+    return ToByte(r) | (ToByte(g) << 8) | (ToByte(b) << 16) | (ToByte(alpha) << 24);
+}
+
+// timg::LinearColor (src/framebuffer.h:138-174): c^2 as "linear", sqrt back.
+__device__ __forceinline__ uint32_t GammaByte(float v) {
+    const float s = sqrtf(v);
+    return s > 255.0f ? 255u : (uint32_t)s;
+}
+
+// LinearColor(px).AlphaBlend(bg).repack() for a pixel whose alpha != 255
+// (src/framebuffer.h:155-161, src/framebuffer.cc:126-131).
+__device__ __forceinline__ uint32_t BlendOver(uint32_t px, const float bg[3]) {
+    const uint32_t r8 = px & 0xffu, g8 = (px >> 8) & 0xffu, b8 = (px >> 16) & 0xffu;
+    const float a  = (float)(px >> 24);
+    const float na = 255.0f - a;
+    const float r  = ((float)(r8 * r8) * a + bg[0] * na) / 255.0f;
+    const float g  = ((float)(g8 * g8) * a + bg[1] * na) / 255.0f;
+    const float b  = ((float)(b8 * b8) * a + bg[2] * na) / 255.0f;
+    return GammaByte(r) | (GammaByte(g) << 8) | (GammaByte(b) << 16) | 0xff000000u;
+}
+
+}  // namespace timg_amd
+#endif

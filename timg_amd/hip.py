@@ -1,0 +1,263 @@
+"""ctypes binding of include/timg_hip.h (tests / bench plumbing).
+
+No torch types cross the boundary: callers hand over raw pointers (ints) for
+device memory -- e.g. ``tensor.data_ptr()`` -- or numpy arrays for host memory.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, byref, c_char_p, c_int, c_size_t, c_uint32,
+                    c_uint8, c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libtimg_hip.so")
+
+
+class TimgHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"timg_hip error {code}: {msg}")
+        self.code = code
+
+
+class Blend(ctypes.Structure):
+    """timg_hip_blend"""
+    _fields_ = [("enabled", c_int), ("bg", c_uint32), ("pattern", c_uint32),
+                ("pattern_w", c_int), ("pattern_h", c_int), ("start_row", c_int)]
+
+    @staticmethod
+    def make(bg, pattern=(0, 0, 0, 0), pw=0, ph=0, start_row=0, enabled=True):
+        def pack(c):
+            return int(c[0]) | int(c[1]) << 8 | int(c[2]) << 16 | int(c[3]) << 24
+        return Blend(1 if enabled else 0, pack(bg), pack(pattern), pw, ph, start_row)
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libtimg_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (make -C timg_amd/csrc). There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    vp = c_void_p
+    L.timg_hip_init.argtypes = [c_int, POINTER(vp)]
+    L.timg_hip_destroy.argtypes = [vp]
+    L.timg_hip_destroy.restype = None
+    L.timg_hip_last_error.argtypes = [vp]
+    L.timg_hip_last_error.restype = c_char_p
+    L.timg_hip_malloc.argtypes = [vp, c_size_t, POINTER(vp)]
+    L.timg_hip_free.argtypes = [vp, vp]
+    L.timg_hip_memcpy_h2d.argtypes = [vp, vp, vp, c_size_t, vp]
+    L.timg_hip_memcpy_d2h.argtypes = [vp, vp, vp, c_size_t, vp]
+    L.timg_hip_sync.argtypes = [vp, vp]
+    L.timg_hip_scaler_create.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(vp)]
+    L.timg_hip_scaler_destroy.argtypes = [vp]
+    L.timg_hip_scaler_destroy.restype = None
+    L.timg_hip_scaler_set_kernel.argtypes = [vp, c_int]
+    L.timg_hip_scaler_info.argtypes = [vp, POINTER(c_int)]
+    L.timg_hip_scaler_algorithmic_bytes.argtypes = [vp]
+    L.timg_hip_scaler_algorithmic_bytes.restype = c_size_t
+    L.timg_hip_scale_blend.argtypes = [vp, vp, vp, c_int, c_size_t, c_int, vp, c_int, c_size_t,
+                                       c_int, c_int, POINTER(Blend), POINTER(c_int), vp]
+    L.timg_hip_alpha_compose.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
+                                         POINTER(Blend), POINTER(c_int), vp]
+    L.timg_hip_autocrop_bbox.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
+                                         c_int, POINTER(c_int), vp]
+    L.timg_hip_block_max_bytes.argtypes = [c_int, c_int]
+    L.timg_hip_block_max_bytes.restype = c_size_t
+    L.timg_hip_block_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
+                                        c_int, c_int, vp, c_size_t, c_int, POINTER(c_size_t), vp]
+    L.timg_hip_sixel_max_bytes.argtypes = [c_int, c_int]
+    L.timg_hip_sixel_max_bytes.restype = c_size_t
+    L.timg_hip_sixel_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
+                                        c_int, POINTER(Blend), vp, c_size_t, c_int,
+                                        POINTER(c_size_t), vp]
+    _lib = L
+    return L
+
+
+def _ptr(x):
+    """numpy array -> (pointer, False); int device pointer -> (pointer, True)."""
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return c_void_p(x.ctypes.data), False
+    return c_void_p(int(x)), True
+
+
+class Scaler:
+    def __init__(self, owner: "TimgHip", handle, in_w, in_h, out_w, out_h):
+        self.owner, self.handle = owner, handle
+        self.in_w, self.in_h, self.out_w, self.out_h = in_w, in_h, out_w, out_h
+
+    def info(self):
+        a = (c_int * 8)()
+        self.owner._check(self.owner.L.timg_hip_scaler_info(self.handle, a))
+        keys = ["vertical_first", "h_widest", "v_is_gather", "v_widest", "h_filter",
+                "v_filter", "streaming_ok", "max_active_rows"]
+        return dict(zip(keys, list(a)))
+
+    def set_kernel(self, which: int):
+        self.owner._check(self.owner.L.timg_hip_scaler_set_kernel(self.handle, which))
+
+    def algorithmic_bytes(self) -> int:
+        return int(self.owner.L.timg_hip_scaler_algorithmic_bytes(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.owner.L.timg_hip_scaler_destroy(self.handle)
+            self.handle = None
+
+
+class TimgHip:
+    """One timg_hip_ctx."""
+
+    QUARTER, UPPER, COLOR256 = 1, 2, 4
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = c_void_p()
+        rc = self.L.timg_hip_init(device, byref(h))
+        if rc != 0:
+            raise TimgHipError(rc, (self.L.timg_hip_last_error(None) or b"").decode())
+        self.ctx = h
+
+    def close(self):
+        if self.ctx:
+            self.L.timg_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TimgHipError(rc, (self.L.timg_hip_last_error(self.ctx) or b"").decode())
+
+    # -- memory helpers ------------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = c_void_p()
+        self._check(self.L.timg_hip_malloc(self.ctx, nbytes, byref(p)))
+        return p.value
+
+    def free(self, ptr: int):
+        self._check(self.L.timg_hip_free(self.ctx, c_void_p(ptr)))
+
+    def upload(self, arr: np.ndarray, dptr: int | None = None) -> int:
+        arr = np.ascontiguousarray(arr)
+        if dptr is None:
+            dptr = self.malloc(arr.nbytes)
+        self._check(self.L.timg_hip_memcpy_h2d(self.ctx, c_void_p(dptr), c_void_p(arr.ctypes.data),
+                                               arr.nbytes, None))
+        return dptr
+
+    def download(self, dptr: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, np.uint8)
+        self._check(self.L.timg_hip_memcpy_d2h(self.ctx, c_void_p(out.ctypes.data), c_void_p(dptr),
+                                               nbytes, None))
+        return out
+
+    def sync(self, stream=None):
+        self._check(self.L.timg_hip_sync(self.ctx, c_void_p(stream) if stream else None))
+
+    # -- scaler --------------------------------------------------------------
+    def scaler(self, in_w, in_h, out_w, out_h, in_fmt=0, filter=0) -> Scaler:
+        h = c_void_p()
+        self._check(self.L.timg_hip_scaler_create(self.ctx, in_w, in_h, in_fmt, out_w, out_h,
+                                                  filter, byref(h)))
+        return Scaler(self, h, in_w, in_h, out_w, out_h)
+
+    def scale_blend(self, scaler: Scaler, src, dst, n_frames=1, blend: Blend | None = None,
+                    want_transparent=False, stream=None, src_stride=0, dst_stride=0,
+                    src_frame_stride=0, dst_frame_stride=0):
+        sp, s_dev = _ptr(src)
+        dp, d_dev = _ptr(dst)
+        flags = (c_int * n_frames)() if want_transparent else None
+        self._check(self.L.timg_hip_scale_blend(
+            self.ctx, scaler.handle, sp, src_stride, src_frame_stride, int(s_dev), dp, dst_stride,
+            dst_frame_stride, int(d_dev), n_frames, byref(blend) if blend is not None else None,
+            flags, c_void_p(stream) if stream else None))
+        return list(flags) if want_transparent else None
+
+    def scale(self, src: np.ndarray, out_w, out_h, in_fmt=0, filter=0, blend=None,
+              kernel=0) -> np.ndarray:
+        """Host convenience: (H,W,4) uint8 -> (out_h,out_w,4) uint8."""
+        sh, sw = src.shape[:2]
+        sc = self.scaler(sw, sh, out_w, out_h, in_fmt, filter)
+        try:
+            if kernel:
+                sc.set_kernel(kernel)
+            dst = np.empty((out_h, out_w, 4), np.uint8)
+            self.scale_blend(sc, np.ascontiguousarray(src), dst, 1, blend)
+            return dst
+        finally:
+            sc.close()
+
+    def alpha_compose(self, fb, w, h, blend: Blend, n_frames=1, want_transparent=False,
+                      stride=0, frame_stride=0, stream=None):
+        p, dev = _ptr(fb)
+        flags = (c_int * n_frames)() if want_transparent else None
+        self._check(self.L.timg_hip_alpha_compose(self.ctx, p, w, h, stride, frame_stride,
+                                                  int(dev), n_frames, byref(blend), flags,
+                                                  c_void_p(stream) if stream else None))
+        return list(flags) if want_transparent else None
+
+    def autocrop_bbox(self, src, w, h, n_frames=1, crop_border=0, stride=0, frame_stride=0):
+        p, dev = _ptr(src)
+        out = (c_int * (4 * n_frames))()
+        self._check(self.L.timg_hip_autocrop_bbox(self.ctx, p, w, h, stride, frame_stride,
+                                                  int(dev), n_frames, crop_border, out, None))
+        return np.array(out[:]).reshape(n_frames, 4)
+
+    # -- canvases --------------------------------------------------------------
+    def block_max_bytes(self, w, h) -> int:
+        return int(self.L.timg_hip_block_max_bytes(w, h))
+
+    def block_encode(self, fb, w, h, flags=0, x_indent=0, n_frames=1, out=None, out_cap=None,
+                     stride=0, frame_stride=0, stream=None):
+        """Returns list[bytes] (host out) or the lengths (device out)."""
+        p, dev = _ptr(fb)
+        if out_cap is None:
+            out_cap = self.block_max_bytes(w, h)
+        host_out = out is None
+        if host_out:
+            out = np.empty(out_cap * n_frames, np.uint8)
+        op, o_dev = _ptr(out)
+        lens = (c_size_t * n_frames)()
+        self._check(self.L.timg_hip_block_encode(self.ctx, p, w, h, stride, frame_stride, int(dev),
+                                                 n_frames, flags, x_indent, op, out_cap,
+                                                 int(o_dev), lens,
+                                                 c_void_p(stream) if stream else None))
+        if host_out:
+            return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
+        return list(lens)
+
+    def sixel_max_bytes(self, w, h) -> int:
+        return int(self.L.timg_hip_sixel_max_bytes(w, h))
+
+    def sixel_encode(self, fb, w, h, flags=0, pad_blend: Blend | None = None, n_frames=1,
+                     out=None, out_cap=None, stride=0, frame_stride=0, stream=None):
+        p, dev = _ptr(fb)
+        if out_cap is None:
+            out_cap = self.sixel_max_bytes(w, h)
+        host_out = out is None
+        if host_out:
+            out = np.empty(out_cap * n_frames, np.uint8)
+        op, o_dev = _ptr(out)
+        lens = (c_size_t * n_frames)()
+        self._check(self.L.timg_hip_sixel_encode(self.ctx, p, w, h, stride, frame_stride, int(dev),
+                                                 n_frames, flags,
+                                                 byref(pad_blend) if pad_blend is not None else None,
+                                                 op, out_cap, int(o_dev), lens,
+                                                 c_void_p(stream) if stream else None))
+        if host_out:
+            return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
+        return list(lens)

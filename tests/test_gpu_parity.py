@@ -145,3 +145,49 @@ def test_autocrop_bbox(hip):
     assert hip.autocrop_bbox(fb, 160, 90, crop_border=40).tolist() == [[0, 0, 0, 0]]
     blank = np.zeros((20, 30, 4), np.uint8)
     assert hip.autocrop_bbox(blank, 30, 20).tolist() == [[0, 0, 0, 0]]
+
+
+# ---- sixel: the HIP path implements oracle lookup_mode 1 byte for byte -------
+SIXEL_CASES = [("photo", 800, 450), ("alpha", 320, 203), ("noise", 200, 100), ("photo", 64, 7),
+               ("photo", 100, 56), ("noise", 33, 6), ("photo", 2, 13), ("alpha", 1, 1)]
+
+
+@pytest.mark.parametrize("kind,w,h", SIXEL_CASES)
+def test_sixel_bytes_match_oracle(hip, oracle, kind, w, h):
+    fb = synth.make(kind, w, h, seed=5)
+    got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 4),
+                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 4, 4, lookup_mode=1)
+    if got != want:
+        n = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
+        raise AssertionError(f"len {len(got)} vs {len(want)}, first diff at {n}: "
+                             f"{got[max(0, n - 20):n + 20]!r} vs {want[max(0, n - 20):n + 20]!r}")
+
+
+def test_sixel_few_colours_and_no_background(hip, oracle):
+    fb = np.zeros((36, 120, 4), np.uint8)
+    fb[..., 3] = 255
+    for i in range(20):
+        fb[:, 6 * i:6 * i + 6, :3] = (8 * i % 256, 16 * (i % 16), 248 - 8 * (i % 32))
+    assert hip.sixel_encode(fb, 120, 36)[0] == oracle.sixel_encode(fb, has_getter=False)
+    fb2 = synth.photo(60, 20, 2)
+    got = hip.sixel_encode(fb2, 60, 20, flags=1, pad_blend=timg_amd.Blend.make(BG, (200, 10, 10, 255), 9, 9))[0]
+    assert got == oracle.sixel_encode(fb2, BG, (200, 10, 10, 255), 9, 9, broken_cursor=True)
+
+
+def test_sixel_batch_device_resident(hip, oracle):
+    n, w, h = 4, 200, 112
+    frames = np.stack([synth.photo(w, h, 40 + i) for i in range(n)])
+    d = hip.upload(frames)
+    outs = hip.sixel_encode(d, w, h, pad_blend=timg_amd.Blend.make(BG), n_frames=n)
+    # device input, host output
+    for i in range(n):
+        assert outs[i] == oracle.sixel_encode(frames[i], BG), i
+    hip.free(d)
+
+
+def test_sixel_too_wide_is_refused(hip):
+    fb = np.zeros((6, 1400, 4), np.uint8)
+    with pytest.raises(timg_amd.TimgHipError) as e:
+        hip.sixel_encode(fb, 1400, 6)
+    assert e.value.code == -5

@@ -1,5 +1,913 @@
-// timg_amd/csrc/sixel_canvas.hip -- placeholder until the sixel kernels land.
+// timg_amd/csrc/sixel_canvas.hip -- device twin of the pixel work behind
+// timg::SixelCanvas::Send (src/sixel-canvas.cc:100-155), i.e. of the two
+// libsixel calls it makes: sixel_dither_initialize (adaptive 256-colour
+// palette) and sixel_encode (nearest colour + Floyd-Steinberg + band RLE).
+//
+// libsixel is not part of the reference tree (parity unpinned); the
+// kernels below implement the algorithm written down in oracle/sixel.c
+// (lookup_mode 1) bit for bit: all arithmetic is integer.
+//
+//   K1 HistSample / MarkFirst   sparse-sampled 15-bit histogram, first-seen order
+//   K2 MedianCut                one wave per frame: median cut -> palette
+//   K3 BuildLut                 15-bit cell -> nearest palette entry (+ its rgb)
+//   K4 Dither                   one wave per frame, rows skewed by 4 columns:
+//                               lookup + Floyd-Steinberg, errors passed between
+//                               rows through DPP shuffles (no memory traffic)
+//   K5 EncodeBand               one workgroup per 6-row band: colour runs ->
+//                               nodes -> libsixel's greedy packing -> RLE bytes
+//   K6 AssembleFrame / CopyBands  header, palette, band offsets, compaction
+#include <cstring>
+
 #include "context.h"
+#include "pixel_math.h"
+
+namespace timg_amd {
+namespace {
+
+constexpr int kMaxColors     = 256;
+constexpr int kMaxEntries    = 8192;  // 6 * width entries per band -> width <= 1365
+constexpr int kMaxSixelWidth = kMaxEntries / 6;
+
+struct SixelGeom {
+    int w, h, h6;        // frame, padded height
+    int bands;
+    size_t stride, frame_stride;
+    uint32_t pad[2];     // RGBA of the pad rows: background / pattern colour
+    int pad_checker, pad_pw, pad_ph;
+    int broken_cursor;
+    uint32_t sample_stride_px, n_samples;
+    size_t band_cap;     // scratch bytes per band
+};
+
+// per-frame device scratch
+struct SixelFrameScratch {
+    uint32_t *hist_cnt;    // [32768]
+    uint32_t *hist_first;  // [32768]
+    uint32_t *entries;     // [n_samples]  cnt<<15 | hash for first-seen samples, else 0
+    uint32_t *tab_a;       // [32768]
+    uint32_t *tab_b;       // [32768]
+    uint32_t *lut;         // [32768] idx | r<<8 | g<<16 | b<<24
+    uint8_t *palette;      // [768]
+    int *meta;             // [0]=ncolors [1]=dither
+    uint8_t *index;        // [h6 * w]
+    char *band_bytes;      // [bands * band_cap]
+    int *band_meta;        // [bands * 4]: len, first colour, last colour, first tag len
+    uint32_t *band_off;    // [bands * 2]: output offset, elided bytes
+};
+
+struct SixelBatch {
+    const uint8_t *fb;
+    uint32_t *hist_cnt, *hist_first, *entries, *tab_a, *tab_b, *lut;
+    uint8_t *palette;
+    int *meta;
+    uint8_t *index;
+    char *band_bytes;
+    int *band_meta;
+    uint32_t *band_off;
+    char *out;
+    size_t out_cap;
+    unsigned long long *out_len;
+};
+
+__device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, const SixelGeom &g,
+                                                          int f) {
+    SixelFrameScratch s;
+    s.hist_cnt   = b.hist_cnt + (size_t)f * 32768;
+    s.hist_first = b.hist_first + (size_t)f * 32768;
+    s.entries    = b.entries + (size_t)f * g.n_samples;
+    s.tab_a      = b.tab_a + (size_t)f * 32768;
+    s.tab_b      = b.tab_b + (size_t)f * 32768;
+    s.lut        = b.lut + (size_t)f * 32768;
+    s.palette    = b.palette + (size_t)f * 768;
+    s.meta       = b.meta + (size_t)f * 4;
+    s.index      = b.index + (size_t)f * g.h6 * g.w;
+    s.band_bytes = b.band_bytes + (size_t)f * g.bands * g.band_cap;
+    s.band_meta  = b.band_meta + (size_t)f * g.bands * 4;
+    s.band_off   = b.band_off + (size_t)f * g.bands * 2;
+    return s;
+}
+
+// Pixel of the padded frame SixelCanvas::Send builds (src/sixel-canvas.cc:111-120):
+// the original rows, then rows of background (or checkerboard) colour.
+__device__ __forceinline__ uint32_t PaddedPixel(const uint8_t *frame, const SixelGeom &g, int x,
+                                                int y) {
+    if (y < g.h) return *reinterpret_cast<const uint32_t *>(frame + (size_t)y * g.stride + (size_t)x * 4);
+    const int alt = g.pad_checker && (((x / g.pad_pw) + (y / g.pad_ph)) & 1);
+    return g.pad[alt];
+}
+
+__device__ __forceinline__ uint32_t Hash555(uint32_t px) {  // r,g,b in the low 3 bytes
+    return ((px & 0xf8u) << 7) | (((px >> 8) & 0xf8u) << 2) | ((px >> 19) & 0x1fu);
+}
+
+// ---- K1 ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) HistSampleKernel(SixelGeom g, SixelBatch b) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f      = blockIdx.y;
+    if (k >= g.n_samples) return;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const uint32_t p          = k * g.sample_stride_px;
+    const uint32_t px = PaddedPixel(b.fb + (size_t)f * g.frame_stride, g, p % g.w, p / g.w);
+    const uint32_t h  = Hash555(px);
+    atomicAdd(&s.hist_cnt[h], 1u);
+    atomicMin(&s.hist_first[h], k);
+}
+
+__global__ void __launch_bounds__(256) MarkFirstKernel(SixelGeom g, SixelBatch b) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f      = blockIdx.y;
+    if (k >= g.n_samples) return;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const uint32_t p          = k * g.sample_stride_px;
+    const uint32_t px = PaddedPixel(b.fb + (size_t)f * g.frame_stride, g, p % g.w, p / g.w);
+    const uint32_t h  = Hash555(px);
+    uint32_t e        = 0;
+    if (s.hist_first[h] == k) {
+        uint32_t c = s.hist_cnt[h];
+        if (c > 65535u) c = 65535u;  // libsixel's histogram is unsigned short, saturating
+        e = (c << 15) | h;
+    }
+    s.entries[k] = e;
+}
+
+// ---- K2: median cut, one wave per frame -------------------------------------------
+__device__ __forceinline__ uint32_t PlaneKey(uint32_t entry, int plane) {
+    return (entry >> (10 - 5 * plane)) & 0x1fu;  // plane 0=r 1=g 2=b
+}
+
+struct CutBox {
+    uint32_t ind, colors, sum, buf;  // buf: 0 = tab_a, 1 = tab_b
+};
+
+__global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b) {
+    const int f    = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    __shared__ CutBox boxes[kMaxColors];
+    __shared__ CutBox boxes_tmp[kMaxColors];
+    __shared__ uint32_t color_hist[3][32];  // colours per key, all three planes
+    __shared__ uint32_t pixel_hist[32];     // pixel counts per key of the chosen plane
+    __shared__ uint32_t key_base[32];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // compact first-seen entries (stable) into tab_a
+    uint32_t n = 0, total = 0;
+    for (uint32_t k0 = 0; k0 < g.n_samples; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
+        const unsigned long long m = __ballot(e != 0);
+        if (e) s.tab_a[n + __popcll(m & lt_mask)] = e;
+        n += __popcll(m);
+        uint32_t c = e >> 15;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        total += c;
+    }
+    __threadfence_block();
+
+    uint32_t nboxes = 0;
+    if (n <= (uint32_t)kMaxColors) {
+        // few enough colours: palette = the histogram colours, no diffusion
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t e     = s.tab_a[i];
+            s.palette[i * 3 + 0] = (uint8_t)(((e >> 10) & 0x1f) << 3);
+            s.palette[i * 3 + 1] = (uint8_t)(((e >> 5) & 0x1f) << 3);
+            s.palette[i * 3 + 2] = (uint8_t)((e & 0x1f) << 3);
+        }
+        if (lane == 0) {
+            s.meta[0] = (int)n;
+            s.meta[1] = 0;
+        }
+        return;
+    }
+    if (lane == 0) boxes[0] = CutBox{0, n, total, 0};
+    nboxes = 1;
+    __syncthreads();
+
+    while (nboxes < (uint32_t)kMaxColors) {
+        // first box (in sum-descending order) that still holds >= 2 colours
+        uint32_t bi = 0xffffffffu;
+        for (uint32_t i0 = 0; i0 < nboxes && bi == 0xffffffffu; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool ok    = i < nboxes && boxes[i].colors >= 2;
+            const unsigned long long m = __ballot(ok);
+            if (m) bi = i0 + (uint32_t)__ffsll((long long)m) - 1;
+        }
+        if (bi == 0xffffffffu) break;
+        const CutBox box     = boxes[bi];
+        const uint32_t *src  = box.buf ? s.tab_b : s.tab_a;
+        uint32_t *dst        = box.buf ? s.tab_a : s.tab_b;
+
+        // pass 1: per-plane key histograms (colours), min/max fall out of them
+        for (int i = lane; i < 96; i += 64) (&color_hist[0][0])[i] = 0;
+        if (lane < 32) pixel_hist[lane] = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < box.colors; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            if (i < box.colors) {
+                const uint32_t e = src[box.ind + i];
+                atomicAdd(&color_hist[0][PlaneKey(e, 0)], 1u);
+                atomicAdd(&color_hist[1][PlaneKey(e, 1)], 1u);
+                atomicAdd(&color_hist[2][PlaneKey(e, 2)], 1u);
+            }
+        }
+        __syncthreads();
+        // SIXEL_LARGE_LUM: plane with the largest luminosity-weighted spread
+        int plane = 0;
+        {
+            const double lum[3] = {0.2989, 0.5866, 0.1145};
+            double best         = 0.0;
+            for (int p = 0; p < 3; ++p) {
+                int lo = 31, hi = 0;
+                for (int k = 0; k < 32; ++k)
+                    if (color_hist[p][k]) {
+                        lo = k < lo ? k : lo;
+                        hi = k > hi ? k : hi;
+                    }
+                const double spread = lum[p] * (double)((hi - lo) << 3);
+                if (spread > best) {
+                    plane = p;
+                    best  = spread;
+                }
+            }
+        }
+        // exclusive bases of the stable counting sort
+        if (lane == 0) {
+            uint32_t acc = 0;
+            for (int k = 0; k < 32; ++k) {
+                key_base[k] = acc;
+                acc += color_hist[plane][k];
+            }
+        }
+        __syncthreads();
+        // pass 2: stable scatter by key, chunk after chunk in order
+        for (uint32_t i0 = 0; i0 < box.colors; i0 += 64) {
+            const uint32_t i   = i0 + lane;
+            const bool live    = i < box.colors;
+            const uint32_t e   = live ? src[box.ind + i] : 0u;
+            const uint32_t key = live ? PlaneKey(e, plane) : 0xffu;
+            uint32_t rank      = 0;
+            unsigned long long todo = __ballot(live);
+            while (todo) {  // one round per distinct key in this chunk (uniform)
+                const int leader              = __ffsll((long long)todo) - 1;
+                const uint32_t k0             = __shfl(key, leader);
+                const unsigned long long same = __ballot(live && key == k0);
+                if (live && key == k0) rank = key_base[k0] + (uint32_t)__popcll(same & lt_mask);
+                __syncthreads();
+                if (lane == leader) key_base[k0] += (uint32_t)__popcll(same);
+                __syncthreads();
+                todo &= ~same;
+            }
+            if (live) {
+                dst[box.ind + rank] = e;
+                atomicAdd(&pixel_hist[key], e >> 15);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // median by pixel count (libsixel splitBox): with P(i) = sum of the first i
+        // counts, the smallest i in [1, colors-1] with P(i) >= sum/2, else colors-1.
+        // Locate the key bin through the per-key pixel totals, then walk inside it.
+        const uint32_t half = box.sum / 2;
+        uint32_t median, lowersum;
+        {
+            uint32_t before_px = 0, before_n = 0;
+            int kb = 0;
+            for (; kb < 31; ++kb) {
+                if (color_hist[plane][kb] && before_px + pixel_hist[kb] >= half) break;
+                before_px += pixel_hist[kb];
+                before_n += color_hist[plane][kb];
+            }
+            const uint32_t cnt = color_hist[plane][kb];
+            uint32_t run       = before_px;
+            uint32_t found = 0xffffffffu, found_sum = 0;
+            for (uint32_t j0 = 0; j0 < cnt && found == 0xffffffffu; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const uint32_t c = j < cnt ? (dst[box.ind + before_n + j] >> 15) : 0u;
+                uint32_t incl    = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                const uint32_t idx = before_n + j;
+                const uint32_t pre = run + incl - c;  // P(idx)
+                const bool hit     = j < cnt && idx >= 1 && pre >= half;
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    found       = __shfl(idx, l);
+                    found_sum   = __shfl(pre, l);
+                }
+                run += __shfl(incl, 63);
+            }
+            if (found == 0xffffffffu) {  // first entry of the next bin
+                found     = before_n + cnt;
+                found_sum = before_px + pixel_hist[kb];
+            }
+            median   = found;
+            lowersum = found_sum;
+            if (median >= box.colors - 1) {
+                median   = box.colors - 1;
+                lowersum = box.sum - (dst[box.ind + box.colors - 1] >> 15);
+            }
+        }
+        // split, then stable re-sort of the boxes by sum, descending
+        __syncthreads();
+        if (lane == 0) {
+            boxes[bi]     = CutBox{box.ind, median, lowersum, box.buf ^ 1u};
+            boxes[nboxes] = CutBox{box.ind + median, box.colors - median, box.sum - lowersum,
+                                   box.buf ^ 1u};
+        }
+        ++nboxes;
+        __syncthreads();
+        for (uint32_t i = lane; i < nboxes; i += 64) {
+            const uint32_t mine = boxes[i].sum;
+            uint32_t rank       = 0;
+            for (uint32_t j = 0; j < nboxes; ++j) {
+                const uint32_t o = boxes[j].sum;
+                rank += (o > mine || (o == mine && j < i)) ? 1u : 0u;
+            }
+            boxes_tmp[rank] = boxes[i];
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < nboxes; i += 64) boxes[i] = boxes_tmp[i];
+        __syncthreads();
+    }
+    // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
+    for (uint32_t bi = lane; bi < nboxes; bi += 64) {
+        const CutBox box    = boxes[bi];
+        const uint32_t *src = box.buf ? s.tab_b : s.tab_a;
+        uint32_t sum[3]     = {0, 0, 0};
+        for (uint32_t i = 0; i < box.colors; ++i) {
+            const uint32_t e = src[box.ind + i];
+            sum[0] += ((e >> 10) & 0x1f) << 3;
+            sum[1] += ((e >> 5) & 0x1f) << 3;
+            sum[2] += (e & 0x1f) << 3;
+        }
+        s.palette[bi * 3 + 0] = (uint8_t)(sum[0] / box.colors);
+        s.palette[bi * 3 + 1] = (uint8_t)(sum[1] / box.colors);
+        s.palette[bi * 3 + 2] = (uint8_t)(sum[2] / box.colors);
+    }
+    if (lane == 0) {
+        s.meta[0] = (int)nboxes;
+        s.meta[1] = 1;  // more colours than palette entries: diffuse
+    }
+}
+
+// ---- K3: 15-bit cell -> nearest palette entry ----------------------------------------
+__global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b) {
+    const int f               = blockIdx.y;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    __shared__ uint8_t pal[768];
+    const int ncolors = s.meta[0];
+    for (int i = threadIdx.x; i < ncolors * 3; i += 256) pal[i] = s.palette[i];
+    __syncthreads();
+    const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(((cell >> 10) & 0x1f) << 3 | 4), gg = (int)(((cell >> 5) & 0x1f) << 3 | 4),
+              bl = (int)((cell & 0x1f) << 3 | 4);
+    int best = 0, diff = 0x7fffffff;
+    for (int i = 0; i < ncolors; ++i) {
+        const int dr = r - pal[i * 3], dg = gg - pal[i * 3 + 1], db = bl - pal[i * 3 + 2];
+        const int d  = dr * dr + dg * dg + db * db;
+        if (d < diff) {
+            diff = d;
+            best = i;
+        }
+    }
+    s.lut[cell] = (uint32_t)best | ((uint32_t)pal[best * 3] << 8) |
+                  ((uint32_t)pal[best * 3 + 1] << 16) | ((uint32_t)pal[best * 3 + 2] << 24);
+}
+
+// ---- K4: lookup + Floyd-Steinberg -----------------------------------------------------
+// Errors travel packed: three signed 9-bit values biased by 256 in 10-bit fields.
+__device__ __forceinline__ uint32_t PackErr(int r, int g, int b) {
+    return (uint32_t)(r + 256) | ((uint32_t)(g + 256) << 10) | ((uint32_t)(b + 256) << 20);
+}
+constexpr uint32_t kZeroErr = 256u | (256u << 10) | (256u << 20);
+
+__device__ __forceinline__ int ClampAdd(int v, int err, int num) {
+    const int c = v + err * num / 16;  // C division: truncates toward zero
+    return c < 0 ? 0 : (c > 255 ? 255 : c);
+}
+
+__device__ __forceinline__ void ApplyErr(int v[3], uint32_t packed, int num) {
+    v[0] = ClampAdd(v[0], (int)(packed & 0x3ffu) - 256, num);
+    v[1] = ClampAdd(v[1], (int)((packed >> 10) & 0x3ffu) - 256, num);
+    v[2] = ClampAdd(v[2], (int)((packed >> 20) & 0x3ffu) - 256, num);
+}
+
+__global__ void __launch_bounds__(64) DitherKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *lut      = lds;            // 32768 entries
+    uint32_t *boundary = lds + 32768;    // w packed errors of the row above the block
+    const int f               = blockIdx.x;
+    const int lane            = threadIdx.x;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
+    for (int i = lane; i < 32768; i += 64) lut[i] = s.lut[i];
+    for (int i = lane; i < g.w; i += 64) boundary[i] = kZeroErr;
+    const bool dither = s.meta[1] != 0;
+    __syncthreads();
+
+    const int W = g.w, H = g.h6;
+    for (int row0 = 0; row0 < H; row0 += 64) {
+        const int row      = row0 + lane;
+        const bool has_row = row < H;
+        // history of this lane's own (diffusable) errors, newest first
+        uint32_t h1 = kZeroErr, h2 = kZeroErr, h3 = kZeroErr, h4 = kZeroErr, h5 = kZeroErr;
+        uint32_t first_err = kZeroErr;  // e(0,row) for the x == W-1 quirk
+        uint32_t packed_idx = 0;
+        const int steps = W + 4 * 63;
+        // source pixels are fetched four steps ahead of their use
+        uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+        for (int t = -4; t < steps; ++t) {
+            // the lane above is 4 columns ahead: its h3/h4/h5 are e(x+1), e(x), e(x-1)
+            uint32_t up_r = __shfl_up(h3, 1), up_c = __shfl_up(h4, 1), up_l = __shfl_up(h5, 1);
+            const int x = t - 4 * lane;
+            if (lane == 0) {
+                up_l = (x - 1 >= 0 && x - 1 < W) ? boundary[x - 1] : kZeroErr;
+                up_c = (x >= 0 && x < W) ? boundary[x] : kZeroErr;
+                up_r = (x + 1 >= 0 && x + 1 < W) ? boundary[x + 1] : kZeroErr;
+            }
+            const uint32_t px = pf0;
+            pf0               = pf1;
+            pf1               = pf2;
+            pf2               = pf3;
+            pf3 = (has_row && x + 4 >= 0 && x + 4 < W) ? PaddedPixel(frame, g, x + 4, row) : 0u;
+            uint32_t mine = kZeroErr;
+            if (has_row && x >= 0 && x < W) {
+                int v[3] = {(int)(px & 0xffu), (int)((px >> 8) & 0xffu), (int)((px >> 16) & 0xffu)};
+                // arrival order of the contributions in raster order:
+                // (x-1,y-1) 1/16, (x,y-1) 5/16, (x+1,y-1) 3/16, [(0,y) 3/16], (x-1,y) 7/16
+                ApplyErr(v, up_l, 1);
+                ApplyErr(v, up_c, 5);
+                ApplyErr(v, up_r, 3);
+                if (x == W - 1 && W > 2) ApplyErr(v, first_err, 3);
+                ApplyErr(v, h1, 7);
+                if (x == W - 1 && W == 2) ApplyErr(v, first_err, 3);  // same source pixel: 7/16 first
+                const uint32_t cell = ((uint32_t)(v[0] >> 3) << 10) | ((uint32_t)(v[1] >> 3) << 5) |
+                                      (uint32_t)(v[2] >> 3);
+                const uint32_t e = lut[cell];
+                if (dither && x < W - 1 && row < H - 1)
+                    mine = PackErr(v[0] - (int)((e >> 8) & 0xffu), v[1] - (int)((e >> 16) & 0xffu),
+                                   v[2] - (int)(e >> 24));
+                if (x == 0) first_err = mine;
+                // four indices per 32-bit store
+                packed_idx |= (e & 0xffu) << (8 * (x & 3));
+                if ((x & 3) == 3 || x == W - 1) {
+                    uint8_t *dst = s.index + (size_t)row * W + (x & ~3);
+                    const int nb = (x & 3) + 1;
+                    if (nb == 4 && ((W & 3) == 0))
+                        *reinterpret_cast<uint32_t *>(dst) = packed_idx;
+                    else
+                        for (int k = 0; k < nb; ++k) dst[k] = (uint8_t)(packed_idx >> (8 * k));
+                    packed_idx = 0;
+                }
+                if (lane == 63) boundary[x] = mine;  // row above the next block
+            }
+            h5 = h4;
+            h4 = h3;
+            h3 = h2;
+            h2 = h1;
+            h1 = mine;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- K5: one workgroup per band ---------------------------------------------------------
+// Bitonic sort of n (power of two) 32-bit keys in LDS with an optional 16-bit payload.
+__device__ void BitonicSort(uint32_t *keys, uint16_t *vals, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up    = (i & k) == 0;
+                    const uint32_t a = keys[i], c = keys[ixj];
+                    if ((a > c) == up) {
+                        keys[i]   = c;
+                        keys[ixj] = a;
+                        if (vals) {
+                            const uint16_t t = vals[i];
+                            vals[i]          = vals[ixj];
+                            vals[ixj]        = t;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int NumLen(uint32_t v) {
+    return v >= 10000 ? 5 : v >= 1000 ? 4 : v >= 100 ? 3 : v >= 10 ? 2 : 1;
+}
+
+__device__ __forceinline__ char *PutUInt(char *p, uint32_t v) {
+    char t[10];
+    int n = 0;
+    do {
+        t[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
+
+// libsixel's sixel_put_flash for a run of `count` identical characters.
+template <bool kWrite>
+__device__ __forceinline__ int FlushRun(char *&p, int ch, int count) {
+    int n = 0;
+    while (count > 255) {  // has_gri_arg_limit
+        if (kWrite) {
+            *p++ = '!'; *p++ = '2'; *p++ = '5'; *p++ = '5'; *p++ = (char)ch;
+        }
+        n += 5;
+        count -= 255;
+    }
+    if (count > 3) {
+        if (kWrite) {
+            *p++ = '!';
+            p    = PutUInt(p, (uint32_t)count);
+            *p++ = (char)ch;
+        }
+        n += 2 + NumLen((uint32_t)count);
+    } else {
+        if (kWrite)
+            for (int i = 0; i < count; ++i) *p++ = (char)ch;
+        n += count;
+    }
+    return n;
+}
+
+// Bytes of one node (libsixel sixel_put_node): optional "#c", the gap of empty
+// columns from the pen position, then the node's columns sx..mx-1 read from the
+// band's (colour, x)-sorted entries.  Returns the byte count.
+template <bool kWrite>
+__device__ int EmitNode(char *p, const uint32_t *entries, int first_entry, int color, int sx,
+                        int mx, int x_start, bool tag) {
+    int n = 0;
+    if (tag) {
+        if (kWrite) {
+            *p++ = '#';
+            p    = PutUInt(p, (uint32_t)color);
+        }
+        n += 1 + NumLen((uint32_t)color);
+    }
+    int run_ch = 0, run_n = 0;
+    auto push = [&](int bits, int count) {
+        const int ch = bits + '?';
+        if (ch == run_ch) {
+            run_n += count;
+        } else {
+            if (run_n) n += FlushRun<kWrite>(p, run_ch, run_n);
+            run_ch = ch;
+            run_n  = count;
+        }
+    };
+    if (sx > x_start) push(0, sx - x_start);
+    int x = sx, e = first_entry;
+    while (x < mx) {
+        const uint32_t ent = entries[e];
+        const int ex       = (int)((ent >> 6) & 0xffffu);
+        if (ex > x) push(0, ex - x);
+        push((int)(ent & 0x3fu), 1);
+        x = ex + 1;
+        ++e;
+    }
+    if (run_n) n += FlushRun<kWrite>(p, run_ch, run_n);
+    return n;
+}
+
+// LDS carve-up of EncodeBandKernel (bytes): 3 x 32 KiB + 3 x 16 KiB + 1 KiB
+constexpr size_t kBandLdsBytes =
+    (size_t)kMaxEntries * (3 * sizeof(uint32_t) + 3 * sizeof(uint16_t)) + kMaxEntries / 8;
+
+__global__ void __launch_bounds__(256) EncodeBandKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *ent      = lds;                    // colour<<22 | x<<6 | mask, sorted
+    uint32_t *node_key = lds + kMaxEntries;      // sx<<20 | (4095-mx)<<8 | colour, sorted
+    uint32_t *node_off = lds + 2 * kMaxEntries;  // per output slot: byte size, then offset
+    uint16_t *node_ent = reinterpret_cast<uint16_t *>(lds + 3 * kMaxEntries);  // first entry
+    uint16_t *order    = node_ent + kMaxEntries;  // output slot -> node | new_pass << 15
+    uint16_t *x_start  = order + kMaxEntries;     // pen position when the node is put
+    uint32_t *alive    = reinterpret_cast<uint32_t *>(x_start + kMaxEntries);
+    __shared__ int s_count[2];
+    __shared__ uint32_t s_scan[5];
+    __shared__ int s_overflow;
+
+    const int band            = blockIdx.x;
+    const int f               = blockIdx.y;
+    const int tid             = threadIdx.x;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const int W               = g.w;
+    const uint8_t *rows       = s.index + (size_t)band * 6 * W;
+
+    if (tid < 2) s_count[tid] = 0;
+    if (tid == 0) s_overflow = 0;
+    for (int i = tid; i < kMaxEntries; i += 256) ent[i] = 0xffffffffu;
+    __syncthreads();
+    // (colour, x, mask) entries: one per distinct colour of every column
+    for (int x = tid; x < W; x += 256) {
+        uint32_t c[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) c[r] = rows[(size_t)r * W + x];
+        uint32_t done = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (done & (1u << r)) continue;
+            uint32_t mask = 0;
+#pragma unroll
+            for (int q = r; q < 6; ++q)
+                if (c[q] == c[r]) mask |= 1u << q;
+            done |= mask;
+            const int at = atomicAdd(&s_count[0], 1);
+            ent[at]      = (c[r] << 22) | ((uint32_t)x << 6) | mask;
+        }
+    }
+    __syncthreads();
+    const int n_ent = s_count[0];
+    int n_pow       = 64;
+    while (n_pow < n_ent) n_pow <<= 1;
+    BitonicSort(ent, nullptr, n_pow);
+
+    // A node starts at a new colour or after a gap of >= 10 empty columns
+    // (libsixel merges shorter gaps into the node).
+    for (int i = tid; i < kMaxEntries; i += 256) {
+        node_key[i] = 0xffffffffu;
+        node_ent[i] = 0;
+    }
+    __syncthreads();
+    auto breaks = [&](int i) {  // is there a node boundary between entries i-1 and i?
+        const uint32_t p = ent[i - 1], e = ent[i];
+        return (p >> 22) != (e >> 22) ||
+               (int)((e >> 6) & 0xffffu) - (int)((p >> 6) & 0xffffu) - 1 >= 10;
+    };
+    for (int i = tid; i < n_ent; i += 256) {
+        if (i != 0 && !breaks(i)) continue;
+        int j = i;
+        while (j + 1 < n_ent && !breaks(j + 1)) ++j;
+        const uint32_t e  = ent[i];
+        const uint32_t sx = (e >> 6) & 0xffffu, mx = ((ent[j] >> 6) & 0xffffu) + 1;
+        const int at      = atomicAdd(&s_count[1], 1);
+        node_key[at]      = (sx << 20) | ((4095u - mx) << 8) | (e >> 22);
+        node_ent[at]      = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n_nodes = s_count[1];
+    n_pow             = 64;
+    while (n_pow < n_nodes) n_pow <<= 1;
+    BitonicSort(node_key, node_ent, n_pow);  // by sx asc, mx desc, colour asc
+
+    // libsixel's greedy packing: sweep the sorted list, taking every node that
+    // starts at or after the pen position; repeat until none is left.  One wave.
+    const int n_words = (n_nodes + 31) / 32;
+    for (int i = tid; i < kMaxEntries / 32; i += 256) {
+        const int base = i * 32;
+        uint32_t m     = 0;
+        if (base + 32 <= n_nodes)
+            m = 0xffffffffu;
+        else if (base < n_nodes)
+            m = (1u << (n_nodes - base)) - 1u;
+        alive[i] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid;
+        int emitted = 0, head_word = 0, x = 0, search_from = 0;
+        bool new_pass = true, first_pass = true;
+        while (emitted < n_nodes) {
+            int start;
+            if (new_pass) {
+                while (head_word < n_words && alive[head_word] == 0) ++head_word;
+                start = head_word * 32;
+            } else {
+                // lower bound of sx >= x in [search_from, n_nodes), 64-way per round
+                int lo = search_from, hi = n_nodes;
+                while (hi > lo) {
+                    const int step = (hi - lo + 63) / 64;
+                    const int idx  = lo + lane * step;
+                    const bool lt  = idx < hi && (int)(node_key[idx] >> 20) < x;
+                    const int cnt  = __popcll(__ballot(lt));  // sorted: lt lanes are a prefix
+                    if (cnt == 0) {
+                        hi = lo;
+                    } else {
+                        const int last_lt = lo + (cnt - 1) * step;
+                        const int nhi     = last_lt + step;
+                        lo                = last_lt + 1;
+                        hi                = nhi < hi ? nhi : hi;
+                    }
+                }
+                start = lo;
+            }
+            int found = -1;
+            for (int w0 = start >> 5; w0 < n_words && found < 0; w0 += 64) {
+                const int w = w0 + lane;
+                uint32_t m  = w < n_words ? alive[w] : 0u;
+                if (w == (start >> 5)) m &= ~((1u << (start & 31)) - 1u);
+                const unsigned long long any = __ballot(m != 0);
+                if (any) {
+                    const int l       = __ffsll((long long)any) - 1;
+                    const uint32_t mm = __shfl(m, l);
+                    found             = (w0 + l) * 32 + (__ffs((int)mm) - 1);
+                }
+            }
+            if (found < 0) {  // sweep exhausted: carriage return, next pass
+                new_pass = true;
+                continue;
+            }
+            if (lane == 0) {
+                order[emitted]   = (uint16_t)((uint32_t)found | ((new_pass && !first_pass) ? 0x8000u : 0u));
+                x_start[emitted] = (uint16_t)(new_pass ? 0 : x);
+                alive[found >> 5] &= ~(1u << (found & 31));
+            }
+            x = 4095 - (int)((node_key[found] >> 8) & 0xfffu);  // pen moves to the node's mx
+            ++emitted;
+            new_pass    = false;
+            first_pass  = false;
+            search_from = found + 1;
+        }
+    }
+    __syncthreads();
+
+    auto describe = [&](int k, int *node_first, int *color, int *sx, int *mx, bool *tag, bool *cr) {
+        const uint32_t o   = order[k];
+        const int node     = (int)(o & 0x7fffu);
+        const uint32_t key = node_key[node];
+        *node_first        = node_ent[node];
+        *color             = (int)(key & 0xffu);
+        *sx                = (int)(key >> 20);
+        *mx                = 4095 - (int)((key >> 8) & 0xfffu);
+        *cr                = (o & 0x8000u) != 0;
+        // "#c" only when the active colour changes (first node: always, fixed up later)
+        *tag = k == 0 || (int)(node_key[order[k - 1] & 0x7fffu] & 0xffu) != *color;
+    };
+    // phase 1: byte size of every output slot
+    for (int k = tid; k < n_nodes; k += 256) {
+        int first_e, color, sx, mx;
+        bool tag, cr;
+        describe(k, &first_e, &color, &sx, &mx, &tag, &cr);
+        char *none = nullptr;
+        node_off[k] = (uint32_t)EmitNode<false>(none, ent, first_e, color, sx, mx, x_start[k], tag) +
+                      (cr ? 1u : 0u);
+    }
+    __syncthreads();
+    // exclusive scan (256 contiguous chunks)
+    const int lead = band > 0 ? 1 : 0;  // '-' (DECGNL) in front of every band but the first
+    {
+        const int per   = (n_nodes + 255) / 256;
+        const int begin = min(tid * per, n_nodes), end = min(begin + per, n_nodes);
+        uint32_t sum    = 0;
+        for (int k = begin; k < end; ++k) sum += node_off[k];
+        uint32_t incl  = sum;
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_scan[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int q = 0; q < wv; ++q) before += s_scan[q];
+        uint32_t run = before + incl - sum + (uint32_t)lead;
+        for (int k = begin; k < end; ++k) {
+            const uint32_t sz = node_off[k];
+            node_off[k]       = run;
+            run += sz;
+        }
+        if (tid == 255) s_scan[4] = before + incl + (uint32_t)lead;
+        __syncthreads();
+    }
+    const uint32_t band_len = s_scan[4];
+    // phase 2: bytes into the band's scratch slot
+    char *out_band = s.band_bytes + (size_t)band * g.band_cap;
+    if (band_len > g.band_cap) {
+        if (tid == 0) s_overflow = 1;
+    } else {
+        if (tid == 0 && lead) out_band[0] = '-';
+        for (int k = tid; k < n_nodes; k += 256) {
+            int first_e, color, sx, mx;
+            bool tag, cr;
+            describe(k, &first_e, &color, &sx, &mx, &tag, &cr);
+            char *p = out_band + node_off[k];
+            if (cr) *p++ = '$';
+            EmitNode<true>(p, ent, first_e, color, sx, mx, x_start[k], tag);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int first_color = n_nodes ? (int)(node_key[order[0] & 0x7fffu] & 0xffu) : -1;
+        const int last_color  = n_nodes ? (int)(node_key[order[n_nodes - 1] & 0x7fffu] & 0xffu) : -1;
+        // an overflowing band reports a length no caller buffer can hold
+        s.band_meta[band * 4 + 0] = s_overflow ? 0x3fffffff : (int)band_len;
+        s.band_meta[band * 4 + 1] = first_color;
+        s.band_meta[band * 4 + 2] = last_color;
+        s.band_meta[band * 4 + 3] = first_color >= 0 ? 1 + NumLen((uint32_t)first_color) : 0;
+    }
+}
+
+// ---- K6 -------------------------------------------------------------------------------
+__device__ __forceinline__ int PaletteEntryLen(int n, const uint8_t *rgb) {
+    return 1 + NumLen((uint32_t)n) + 3 + NumLen((rgb[0] * 100u + 127u) / 255u) + 1 +
+           NumLen((rgb[1] * 100u + 127u) / 255u) + 1 + NumLen((rgb[2] * 100u + 127u) / 255u);
+}
+
+__global__ void __launch_bounds__(256) AssembleFrameKernel(SixelGeom g, SixelBatch b) {
+    const int f               = blockIdx.x;
+    const int tid             = threadIdx.x;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    char *out                 = b.out + (size_t)f * b.out_cap;
+    __shared__ uint32_t pal_off[kMaxColors + 1];
+    const int ncolors = s.meta[0];
+    // cursor mode string + DCS + raster attributes, by one thread
+    if (tid == 0) {
+        char tmp[96];
+        char *p            = tmp;
+        const char *cursor = g.broken_cursor ? "\033[80l\033[?7730l\033[?8452h"
+                                             : "\033[80h\033[?7730h\033[?8452l";
+        for (const char *c = cursor; *c; ++c) *p++ = *c;
+        *p++ = '\033'; *p++ = 'P'; *p++ = 'q';
+        *p++ = '"'; *p++ = '1'; *p++ = ';'; *p++ = '1'; *p++ = ';';
+        p    = PutUInt(p, (uint32_t)g.w);
+        *p++ = ';';
+        p    = PutUInt(p, (uint32_t)g.h6);
+        const uint32_t n = (uint32_t)(p - tmp);
+        for (uint32_t i = 0; i < n; ++i)
+            if (i < b.out_cap) out[i] = tmp[i];
+        uint32_t acc = n;
+        for (int c = 0; c < ncolors; ++c) {
+            pal_off[c] = acc;
+            acc += (uint32_t)PaletteEntryLen(c, s.palette + c * 3);
+        }
+        pal_off[ncolors] = acc;
+        // band offsets with the '#c' elision across band boundaries
+        uint32_t at = acc;
+        for (int band = 0; band < g.bands; ++band) {
+            const int *m   = s.band_meta + band * 4;
+            uint32_t elide = 0;
+            if (band > 0 && m[1] >= 0 && m[1] == s.band_meta[(band - 1) * 4 + 2]) elide = (uint32_t)m[3];
+            s.band_off[band * 2 + 0] = at;
+            s.band_off[band * 2 + 1] = elide;
+            at += (uint32_t)m[0] - elide;
+        }
+        // ST + cursor suffix
+        const char tail[3] = {'\033', '\\', g.broken_cursor ? '\n' : '\r'};
+        for (int i = 0; i < 3; ++i)
+            if (at + i < b.out_cap) out[at + i] = tail[i];
+        b.out_len[f] = (unsigned long long)at + 3ull;
+    }
+    __syncthreads();
+    if (tid < ncolors) {
+        char tmp[24];
+        char *p            = tmp;
+        const uint8_t *rgb = s.palette + tid * 3;
+        *p++ = '#';
+        p    = PutUInt(p, (uint32_t)tid);
+        *p++ = ';'; *p++ = '2'; *p++ = ';';
+        p    = PutUInt(p, (rgb[0] * 100u + 127u) / 255u);
+        *p++ = ';';
+        p    = PutUInt(p, (rgb[1] * 100u + 127u) / 255u);
+        *p++ = ';';
+        p    = PutUInt(p, (rgb[2] * 100u + 127u) / 255u);
+        const uint32_t n = (uint32_t)(p - tmp), at = pal_off[tid];
+        for (uint32_t i = 0; i < n; ++i)
+            if (at + i < b.out_cap) out[at + i] = tmp[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) CopyBandsKernel(SixelGeom g, SixelBatch b) {
+    const int band            = blockIdx.x;
+    const int f               = blockIdx.y;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const char *src           = s.band_bytes + (size_t)band * g.band_cap;
+    char *out                 = b.out + (size_t)f * b.out_cap;
+    const uint32_t len        = (uint32_t)s.band_meta[band * 4 + 0];
+    const uint32_t at         = s.band_off[band * 2 + 0];
+    const uint32_t elide      = s.band_off[band * 2 + 1];
+    const uint32_t lead       = band > 0 ? 1u : 0u;  // the elided tag sits right after '-'
+    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+        if (i >= lead && i < lead + elide) continue;
+        const uint32_t o = i < lead ? i : i - elide;
+        if ((size_t)at + o < b.out_cap) out[at + o] = src[i];
+    }
+}
+
+__global__ void InitHistKernel(uint32_t *cnt, uint32_t *first, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        cnt[i]   = 0u;
+        first[i] = 0xffffffffu;
+    }
+}
+
+}  // namespace
+}  // namespace timg_amd
+
+using namespace timg_amd;
 
 static size_t Round6(int h) { return (size_t)((h + 5) - (h + 5) % 6); }
 
@@ -7,9 +915,152 @@ extern "C" size_t timg_hip_sixel_max_bytes(int w, int h) {
     return 1024 + (size_t)w * Round6(h) * 5;  // src/sixel-canvas.cc:123
 }
 
-extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *, int, int, int, size_t,
-                                     int, int, int, const timg_hip_blend *, char *, size_t, int,
-                                     size_t *, void *) {
-    if (!ctx) return TIMG_HIP_ERR_ARG;
-    return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "sixel encode not built yet");
+extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
+                                     int stride, size_t frame_stride, int fb_on_device,
+                                     int n_frames, int flags, const timg_hip_blend *pad_blend,
+                                     char *out, size_t out_cap, int out_on_device,
+                                     size_t *out_len, void *stream) {
+    if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0)
+        return TIMG_HIP_ERR_ARG;
+    if (w > kMaxSixelWidth)
+        return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "sixel width %d > %d", w, kMaxSixelWidth);
+    if (stride == 0) stride = w * 4;
+    if (stride < w * 4 || (stride & 3) || ((uintptr_t)fb & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride/alignment");
+    if (frame_stride == 0) frame_stride = (size_t)stride * h;
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->Stream(stream);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+
+    SixelGeom g;
+    memset(&g, 0, sizeof(g));
+    g.w            = w;
+    g.h            = h;
+    g.h6           = (int)Round6(h);
+    g.bands        = g.h6 / 6;
+    g.stride       = (size_t)stride;
+    g.frame_stride = frame_stride;
+    g.broken_cursor = (flags & TIMG_HIP_SIXEL_BROKEN_CURSOR) != 0;
+    // Pad rows: a transparent-black pixel blended over the background is the
+    // background colour itself (sqrt(c*c) == c), opaque; without a usable
+    // background it stays 0,0,0,0 (src/sixel-canvas.cc:111-118).
+    g.pad[0] = g.pad[1] = 0u;
+    g.pad_pw = g.pad_ph = 1;
+    if (pad_blend && pad_blend->enabled && (pad_blend->bg >> 24) != 0) {
+        g.pad[0] = (pad_blend->bg & 0x00ffffffu) | 0xff000000u;
+        g.pad[1] = g.pad[0];
+        const uint32_t pat = pad_blend->pattern;
+        if (!((pat >> 24) == 0 || pat == pad_blend->bg || pad_blend->pattern_w <= 0 ||
+              pad_blend->pattern_h <= 0)) {
+            g.pad_checker = 1;
+            g.pad[1]      = (pat & 0x00ffffffu) | 0xff000000u;
+            g.pad_pw      = pad_blend->pattern_w;
+            g.pad_ph      = pad_blend->pattern_h;
+        }
+    }
+    // libsixel's sparse sampling (quality "low": 18383 samples budget)
+    const uint32_t npix = (uint32_t)w * (uint32_t)g.h6;
+    uint32_t sp         = npix / 18383u;
+    if (npix < 18383u) sp = 6;
+    if (sp == 0) sp = 1;
+    g.sample_stride_px = sp;
+    g.n_samples        = (npix + sp - 1) / sp;
+    g.band_cap         = (size_t)w * 6 * 16 + 1024;  // >= 16 bytes per (column, colour) entry
+
+    const size_t fb_bytes = frame_stride * (size_t)(n_frames - 1) + (size_t)stride * h;
+    const uint8_t *dfb    = fb;
+    if (!fb_on_device) {
+        TIMG_HIP_TRY(ctx, ctx->dev[0].Reserve(fb_bytes));
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].ptr, fb, fb_bytes, hipMemcpyHostToDevice, st));
+        dfb = (const uint8_t *)ctx->dev[0].ptr;
+    }
+    char *dout = out;
+    if (!out_on_device) {
+        TIMG_HIP_TRY(ctx, ctx->dev[1].Reserve(out_cap * (size_t)n_frames));
+        dout = (char *)ctx->dev[1].ptr;
+    }
+    // one scratch allocation, carved up
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nf = (size_t)n_frames;
+    size_t off      = 0;
+    auto carve      = [&](size_t bytes) {
+        const size_t at = off;
+        off             = align(off + bytes);
+        return at;
+    };
+    const size_t o_cnt   = carve(nf * 32768 * 4);
+    const size_t o_first = carve(nf * 32768 * 4);
+    const size_t o_ent   = carve(nf * g.n_samples * 4);
+    const size_t o_ta    = carve(nf * 32768 * 4);
+    const size_t o_tb    = carve(nf * 32768 * 4);
+    const size_t o_lut   = carve(nf * 32768 * 4);
+    const size_t o_pal   = carve(nf * 768);
+    const size_t o_meta  = carve(nf * 4 * sizeof(int));
+    const size_t o_idx   = carve(nf * (size_t)g.h6 * w);
+    const size_t o_bb    = carve(nf * g.bands * g.band_cap);
+    const size_t o_bm    = carve(nf * g.bands * 4 * sizeof(int));
+    const size_t o_bo    = carve(nf * g.bands * 2 * sizeof(uint32_t));
+    const size_t o_len   = carve(nf * sizeof(unsigned long long));
+    TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
+    char *base = (char *)ctx->dev[5].ptr;
+    SixelBatch b;
+    b.fb         = dfb;
+    b.hist_cnt   = (uint32_t *)(base + o_cnt);
+    b.hist_first = (uint32_t *)(base + o_first);
+    b.entries    = (uint32_t *)(base + o_ent);
+    b.tab_a      = (uint32_t *)(base + o_ta);
+    b.tab_b      = (uint32_t *)(base + o_tb);
+    b.lut        = (uint32_t *)(base + o_lut);
+    b.palette    = (uint8_t *)(base + o_pal);
+    b.meta       = (int *)(base + o_meta);
+    b.index      = (uint8_t *)(base + o_idx);
+    b.band_bytes = base + o_bb;
+    b.band_meta  = (int *)(base + o_bm);
+    b.band_off   = (uint32_t *)(base + o_bo);
+    b.out        = dout;
+    b.out_cap    = out_cap;
+    b.out_len    = (unsigned long long *)(base + o_len);
+
+    const size_t nbins = nf * 32768;
+    hipLaunchKernelGGL(InitHistKernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, st,
+                       b.hist_cnt, b.hist_first, nbins);
+    const dim3 sgrid((g.n_samples + 255) / 256, n_frames);
+    hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(64), 0, st, g, b);
+    hipLaunchKernelGGL(BuildLutKernel, dim3(128, n_frames), dim3(256), 0, st, g, b);
+    const size_t dither_lds = (32768 + (size_t)w) * sizeof(uint32_t);
+    const size_t band_lds   = kBandLdsBytes;
+    // both kernels need more than the default 64 KiB of dynamic LDS
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)dither_lds));
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)EncodeBandKernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)band_lds));
+    hipLaunchKernelGGL(DitherKernel, dim3(n_frames), dim3(64), dither_lds, st, g, b);
+    hipLaunchKernelGGL(EncodeBandKernel, dim3(g.bands, n_frames), dim3(256), band_lds, st, g, b);
+    hipLaunchKernelGGL(AssembleFrameKernel, dim3(n_frames), dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(CopyBandsKernel, dim3(g.bands, n_frames), dim3(256), 0, st, g, b);
+    TIMG_HIP_TRY(ctx, hipGetLastError());
+
+    TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * nf));
+    unsigned long long *len_h = (unsigned long long *)ctx->pin[0].ptr;
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * nf,
+                                     hipMemcpyDeviceToHost, st));
+    TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    size_t worst = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        out_len[i] = (size_t)len_h[i];
+        if (out_len[i] > worst) worst = out_len[i];
+    }
+    if (worst > out_cap)
+        return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %zu bytes, out_cap is %zu", worst, out_cap);
+    if (!out_on_device) {
+        for (int i = 0; i < n_frames; ++i)
+            TIMG_HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * out_cap, dout + (size_t)i * out_cap,
+                                             out_len[i], hipMemcpyDeviceToHost, st));
+        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    return TIMG_HIP_OK;
 }

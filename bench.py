@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of hzeller/timg on MI355X, BASELINE.json's metric:
+
+    Mpixels/s scale+sixel-encode, 4K -> 800 px, grid = 8x8
+    (+ achieved HBM GB/s of the scale+blend kernel)
+
+One "step" = one pass of the hot path over one batch of 64 synthetic 3840x2160
+RGBA frames that are already resident in HBM: scale(+alpha-compose) each to
+800x450, sixel-encode each, lengths back on the host; with N>1 ranks every
+rank runs its own 64-frame batch (weak scaling, frames are independent) and
+the variable-length outputs are gathered to rank 0 over RCCL for ordered
+emission -- the only exchange step the path has.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 64] [--kind photo]
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte
+accounting behind `roofline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(in_w, in_h, out_w, out_h, bg, n_sample_frames, frames):
+    """The reference's CPU path on the host cores, on a bounded sample of the
+    same workload: the REAL reference (oracle/_ref, hzeller/timg sources) for
+    scale + alpha-compose where it was built, the oracle's restatement for the
+    sixel encode (libsixel is not in the reference tree).  Checker code used as
+    a yardstick only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    ref = oracle_lib.Ref.try_load()
+    cores = max(1, min(os.cpu_count() or 1, n_sample_frames))
+    distinct = [np.ascontiguousarray(f) for f in frames]  # a few of the GPU's own input frames
+    scaler = ref if ref is not None else orc
+
+    def work(idx_list):
+        for i in idx_list:
+            fb = scaler.scale(distinct[i % len(distinct)], out_w, out_h)
+            fb, _ = scaler.alpha_compose(fb, bg)
+            orc.sixel_encode(fb, bg=bg, lookup_mode=0)
+
+    work([0])  # warm-up
+    shards = [list(range(t, n_sample_frames, cores)) for t in range(cores)]
+    threads = [threading.Thread(target=work, args=(s,)) for s in shards]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    mpx = n_sample_frames * in_w * in_h / 1e6 / dt
+    return {
+        "value": round(mpx, 2), "unit": "Mpixels/s", "cores": cores,
+        "kind": "reference" if ref is not None else "port",
+        "sample": (f"{n_sample_frames} frames {in_w}x{in_h}->{out_w}x{out_h} on {cores} threads: "
+                   f"scale+blend = {'hzeller/timg sources (oracle/_ref)' if ref is not None else 'oracle port'}, "
+                   "sixel = oracle restatement of libsixel (parity unpinned)"),
+        "seconds": round(dt, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64, help="frames per rank per step (grid 8x8)")
+    ap.add_argument("--kind", default="photo", choices=["photo", "noise", "alpha"])
+    ap.add_argument("--mode", default="sixel", choices=["sixel", "quarter", "half"])
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 streaming")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import timg_amd
+    from timg_amd.gather import gather_frames_to_root
+    from timg_amd.pipeline import GridPipeline, synth_frames_on_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    in_w, in_h, out_w, out_h = 3840, 2160, 800, 450
+    if args.mode != "sixel":
+        out_w, out_h = 200, 56  # BASELINE config 3: grid cell of an 800-cell canvas
+    bg = (0x1E, 0x1E, 0x2E, 0xFF)
+    hip = timg_amd.TimgHip(local_rank)
+    blend = timg_amd.Blend.make(bg)
+    pipe = GridPipeline(hip, args.frames, in_w, in_h, out_w, out_h, args.mode, blend)
+    if args.kernel:
+        pipe.scaler.set_kernel(args.kernel)
+    src = synth_frames_on_device(args.frames, in_w, in_h, args.kind, seed=rank)
+    torch.cuda.synchronize()
+
+    pipe.stream.wait_stream(torch.cuda.current_stream())
+
+    def one_step(timed_events=None):
+        # HIP events on the stream the kernels are launched on (pipe.stream)
+        if timed_events is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(pipe.stream)
+        pipe.scale(src)
+        if timed_events is not None:
+            e1.record(pipe.stream)
+        pipe.encode()
+        if timed_events is not None:
+            e2.record(pipe.stream)
+            timed_events.append((e0, e1, e2))
+        if world > 1:
+            payload, lens = pipe.packed_output()
+            gather_frames_to_root(payload, lens)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(events)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    scale_ms = [a.elapsed_time(b) for a, b, _ in events]
+    encode_ms = [b.elapsed_time(c) for _, b, c in events]
+    scale_avg_ms = sum(scale_ms) / len(scale_ms)
+    alg_bytes = pipe.scaler.algorithmic_bytes() * args.frames  # per launch (one batch)
+    achieved = alg_bytes / (scale_avg_ms * 1e-3) / 1e9
+    total_px = world * args.frames * in_w * in_h * args.steps
+    value = total_px / 1e6 / elapsed
+    info = pipe.scaler.info()
+    out_bytes = sum(pipe.lengths)
+
+    result = {
+        "metric": "Mpixels/s scale+sixel-encode, 4K->800px grid=8x8" if args.mode == "sixel"
+                  else f"Mpixels/s scale+{args.mode}-block-encode, 4K->200x56 grid=8x8",
+        "value": round(value, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"{args.frames}x {in_w}x{in_h} RGBA8 S-{args.kind} frames per GPU, resident in HBM "
+                         f"-> scale+alpha-compose to {out_w}x{out_h} -> {args.mode} encode "
+                         "(BASELINE metric config: 4K->800px grid=8x8)"),
+            "frames_per_gpu": args.frames,
+            "parallelism": f"frames sharded {world} way(s), RCCL gather of output bytes to rank 0"
+                           if world > 1 else "single GPU, batched launches",
+            "scale_kernel": "streaming" if (info["streaming_ok"] and args.kernel != 1) else "generic",
+            "pass_order": "vertical-first" if info["vertical_first"] else "horizontal-first",
+        },
+        "roofline": {
+            "kernel": "scale+alpha-compose (reads every source byte once)",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": round(scale_avg_ms, 4),
+        },
+        "stages_ms": {"scale_blend": round(scale_avg_ms, 3),
+                      "encode": round(sum(encode_ms) / len(encode_ms), 3)},
+        "output_bytes_per_step": out_bytes,
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            t = json.load(open(traffic_file))
+            if t.get("workload_frames") == args.frames and t.get("kernel") == result["config"]["scale_kernel"]:
+                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    if rank == 0 and not args.no_cpu_baseline:
+        n_cpu = args.cpu_frames or 2 * max(1, min(os.cpu_count() or 1, 32))
+        host_frames = src[:min(4, args.frames)].cpu().numpy()
+        result["cpu_baseline"] = cpu_baseline(in_w, in_h, out_w, out_h, bg, n_cpu, host_frames) \
+            if args.mode == "sixel" else None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    hip.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,7 +105,8 @@ int timg_hip_scale_blend(timg_hip_ctx *ctx, timg_hip_scaler *s,
 
 /* Force a kernel family for A/B measurements and parity tests:
  * 0 = auto, 1 = generic gather kernel, 2 = streaming kernel (fails with
- * TIMG_HIP_ERR_UNSUPP when the plan is outside its coverage). */
+ * TIMG_HIP_ERR_UNSUPP when the plan is outside its coverage), 3 / 4 = streaming
+ * kernel that skips its opaque / opaque+premultiplied fast passes. */
 int timg_hip_scaler_set_kernel(timg_hip_scaler *s, int which);
 /* Introspection: info[0]=vertical_first [1]=h_widest [2]=v_is_gather
  * [3]=v_widest [4]=h_filter [5]=v_filter [6]=streaming kernel applicable

@@ -203,10 +203,11 @@ void timg_hip_scaler_destroy(timg_hip_scaler *s) {
 }
 
 int timg_hip_scaler_set_kernel(timg_hip_scaler *s, int which) {
-    if (!s || which < 0 || which > 2) return TIMG_HIP_ERR_ARG;
-    if (which == 2 && !s->streaming_ok)
+    if (!s || which < 0 || which > 4) return TIMG_HIP_ERR_ARG;
+    if (which >= 2 && !s->streaming_ok)
         return s->ctx->Fail(TIMG_HIP_ERR_UNSUPP, "streaming kernel does not cover this plan");
-    s->forced_kernel = which;
+    s->forced_kernel = which > 2 ? 2 : which;
+    s->stream_cfg[3] = which > 2 ? which - 2 : 0;  // first channel set the streaming kernel tries
     return TIMG_HIP_OK;
 }
 

@@ -45,6 +45,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own libamdhip64.so.7; the process can only hold
+    # one HIP runtime (same SONAME), and torch refuses to run on a foreign one.
+    # Let torch bring its runtime in first -- libtimg_hip.so is happy with either.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional plumbing
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise FileNotFoundError(

@@ -1,0 +1,112 @@
+"""Hot-path pipelines on device-resident frames (bench / test plumbing).
+
+torch is used for device memory, streams and torch.distributed only; every
+pixel goes through libtimg_hip.so (C-ABI calls on the current torch stream).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .hip import Blend, TimgHip
+
+
+class GridPipeline:
+    """scale(+blend) -> canvas encode for a batch of equally sized frames."""
+
+    def __init__(self, hip: TimgHip, n_frames: int, in_w: int, in_h: int, out_w: int, out_h: int,
+                 mode: str = "sixel", blend: Blend | None = None, device: str = "cuda"):
+        self.hip, self.n = hip, n_frames
+        self.in_w, self.in_h, self.out_w, self.out_h = in_w, in_h, out_w, out_h
+        self.mode = mode
+        self.blend = blend
+        self.scaler = hip.scaler(in_w, in_h, out_w, out_h)
+        self.scaled = torch.empty((n_frames, out_h, out_w, 4), dtype=torch.uint8, device=device)
+        if mode == "sixel":
+            self.cap = hip.sixel_max_bytes(out_w, out_h)
+        else:
+            self.cap = hip.block_max_bytes(out_w, out_h)
+        self.out = torch.empty((n_frames, self.cap), dtype=torch.uint8, device=device)
+        self.lengths = None
+        # A dedicated (non-null) HIP stream: the C-ABI reads a NULL stream as
+        # "the context's own stream", and torch's default stream is NULL.
+        self.stream = torch.cuda.Stream(device=device)
+
+    def stream_ptr(self):
+        return self.stream.cuda_stream
+
+    def scale(self, src: torch.Tensor):
+        self.hip.scale_blend(self.scaler, src.data_ptr(), self.scaled.data_ptr(), self.n, self.blend,
+                             stream=self.stream_ptr())
+
+    def encode(self):
+        st = self.stream_ptr()
+        if self.mode == "sixel":
+            lens = self.hip.sixel_encode(self.scaled.data_ptr(), self.out_w, self.out_h,
+                                         pad_blend=self.blend, n_frames=self.n,
+                                         out=self.out.data_ptr(), out_cap=self.cap, stream=st)
+        else:
+            flags = {"half": 0, "quarter": TimgHip.QUARTER}[self.mode]
+            lens = self.hip.block_encode(self.scaled.data_ptr(), self.out_w, self.out_h, flags=flags,
+                                         n_frames=self.n, out=self.out.data_ptr(), out_cap=self.cap,
+                                         stream=st)
+        self.lengths = lens
+        return lens
+
+    def step(self, src: torch.Tensor):
+        self.scale(src)
+        return self.encode()
+
+    def packed_output(self):
+        """(payload uint8 tensor, lengths int64 tensor): frames back to back."""
+        lens = torch.tensor(self.lengths, dtype=torch.int64)
+        parts = [self.out[i, :n] for i, n in enumerate(self.lengths)]
+        return torch.cat(parts), lens.to(self.out.device)
+
+    def frame_bytes(self, i: int) -> bytes:
+        return self.out[i, :self.lengths[i]].cpu().numpy().tobytes()
+
+    def close(self):
+        self.scaler.close()
+
+
+def synth_frames_on_device(n: int, w: int, h: int, kind: str = "photo", seed: int = 0,
+                           device: str = "cuda") -> torch.Tensor:
+    """Seeded synthetic RGBA8 frames generated on the device (nothing crosses
+    PCIe): the S-photo / S-noise / S-alpha families of SURVEY.md 8d, torch RNG."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0x71170000 + seed)
+    out = torch.empty((n, h, w, 4), dtype=torch.uint8, device=device)
+    if kind == "noise":
+        out.copy_(torch.randint(0, 256, (n, h, w, 4), generator=g, device=device, dtype=torch.uint8))
+        return out
+    yy = torch.arange(h, device=device, dtype=torch.float32)[:, None] / h
+    xx = torch.arange(w, device=device, dtype=torch.float32)[None, :] / w
+    for i in range(n):
+        for c in range(3):
+            acc = torch.zeros((h, w), device=device)
+            for _ in range(3):
+                fx, fy, ph = (torch.rand(3, generator=g, device=device) * torch.tensor(
+                    [5.5, 5.5, 6.2832], device=device) + torch.tensor([0.5, 0.5, 0.0], device=device)).tolist()
+                acc += torch.sin(6.2832 * (fx * xx + fy * yy) + ph)
+            v = (acc / 6.0 + 0.5) * 255.0
+            v += torch.randn((h, w), generator=g, device=device) * (0.04 * 255.0)
+            out[i, :, :, c] = v.clamp_(0, 255).to(torch.uint8)
+        if kind == "alpha":
+            ry = (torch.arange(h, device=device, dtype=torch.float32)[:, None] - h / 2) / (h / 2)
+            rx = (torch.arange(w, device=device, dtype=torch.float32)[None, :] - w / 2) / (w / 2)
+            a = ((1.0 - torch.sqrt(rx * rx + ry * ry) / 1.2).clamp_(0, 1) * 255.0).to(torch.uint8)
+            b = max(1, min(64, min(w, h) // 8))
+            a[:b] = 0
+            a[-b:] = 0
+            a[:, :b] = 0
+            a[:, -b:] = 0
+            pick = torch.rand((h, w), generator=g, device=device) < 0.10
+            special = torch.tensor([0, 0x5F, 0x60, 0xFF], dtype=torch.uint8, device=device)[
+                torch.randint(0, 4, (h, w), generator=g, device=device)]
+            out[i, :, :, 3] = torch.where(pick, special, a)
+        else:
+            out[i, :, :, 3] = 255
+    return out

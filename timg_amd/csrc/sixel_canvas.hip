@@ -131,26 +131,35 @@ __global__ void __launch_bounds__(256) MarkFirstKernel(SixelGeom g, SixelBatch b
 }
 
 // ---- K2: median cut, one wave per frame -------------------------------------------
+// The split order of libsixel's median cut is inherently serial (always the
+// largest remaining box), so a frame gets one wave; a batch of frames fills the
+// chip.  The colour table lives in LDS (ping-pong halves, global-memory
+// fallback for > kCutLdsEntries colours) and a split costs a few hundred
+// instructions: boxes of <= 64 colours are sorted in registers with ballots,
+// larger ones by a stable per-lane-segment counting sort on the 5-bit key.
+constexpr int kCutLdsEntries = 16384;
+constexpr size_t kCutLdsBytes =
+    (size_t)2 * kCutLdsEntries * sizeof(uint32_t) + (size_t)64 * 33 * sizeof(uint32_t);
+
 __device__ __forceinline__ uint32_t PlaneKey(uint32_t entry, int plane) {
     return (entry >> (10 - 5 * plane)) & 0x1fu;  // plane 0=r 1=g 2=b
 }
 
 struct CutBox {
-    uint32_t ind, colors, sum, buf;  // buf: 0 = tab_a, 1 = tab_b
+    uint32_t ind, colors, sum, buf;  // buf: which half of the ping-pong table holds it
 };
 
 __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t cut_lds[];
+    uint32_t *lane_cnt = cut_lds + 2 * kCutLdsEntries;  // [64][33]
+    __shared__ CutBox box_a[kMaxColors], box_b[kMaxColors];
+    __shared__ uint32_t s_min[3], s_max[3], s_key_total[32], s_key_base[32];
     const int f    = blockIdx.x;
     const int lane = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    __shared__ CutBox boxes[kMaxColors];
-    __shared__ CutBox boxes_tmp[kMaxColors];
-    __shared__ uint32_t color_hist[3][32];  // colours per key, all three planes
-    __shared__ uint32_t pixel_hist[32];     // pixel counts per key of the chosen plane
-    __shared__ uint32_t key_base[32];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // compact first-seen entries (stable) into tab_a
+    // compact the first-seen entries (stable) into tab_a
     uint32_t n = 0, total = 0;
     for (uint32_t k0 = 0; k0 < g.n_samples; k0 += 64) {
         const uint32_t k = k0 + lane;
@@ -164,8 +173,8 @@ __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b)
         total += c;
     }
     __threadfence_block();
+    __syncthreads();
 
-    uint32_t nboxes = 0;
     if (n <= (uint32_t)kMaxColors) {
         // few enough colours: palette = the histogram colours, no diffusion
         for (uint32_t i = lane; i < n; i += 64) {
@@ -180,8 +189,18 @@ __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b)
         }
         return;
     }
+    uint32_t *tab[2];
+    if (n <= (uint32_t)kCutLdsEntries) {
+        tab[0] = cut_lds;
+        tab[1] = cut_lds + kCutLdsEntries;
+        for (uint32_t i = lane; i < n; i += 64) tab[0][i] = s.tab_a[i];
+    } else {
+        tab[0] = s.tab_a;
+        tab[1] = s.tab_b;
+    }
+    CutBox *boxes = box_a, *boxes_next = box_b;
     if (lane == 0) boxes[0] = CutBox{0, n, total, 0};
-    nboxes = 1;
+    uint32_t nboxes = 1;
     __syncthreads();
 
     while (nboxes < (uint32_t)kMaxColors) {
@@ -189,26 +208,37 @@ __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b)
         uint32_t bi = 0xffffffffu;
         for (uint32_t i0 = 0; i0 < nboxes && bi == 0xffffffffu; i0 += 64) {
             const uint32_t i = i0 + lane;
-            const bool ok    = i < nboxes && boxes[i].colors >= 2;
-            const unsigned long long m = __ballot(ok);
+            const unsigned long long m = __ballot(i < nboxes && boxes[i].colors >= 2);
             if (m) bi = i0 + (uint32_t)__ffsll((long long)m) - 1;
         }
         if (bi == 0xffffffffu) break;
-        const CutBox box     = boxes[bi];
-        const uint32_t *src  = box.buf ? s.tab_b : s.tab_a;
-        uint32_t *dst        = box.buf ? s.tab_a : s.tab_b;
+        const CutBox box    = boxes[bi];
+        const uint32_t *src = tab[box.buf] + box.ind;
+        uint32_t *dst       = tab[box.buf ^ 1u] + box.ind;
+        const uint32_t half = box.sum / 2;
+        uint32_t median, lowersum;
 
-        // pass 1: per-plane key histograms (colours), min/max fall out of them
-        for (int i = lane; i < 96; i += 64) (&color_hist[0][0])[i] = 0;
-        if (lane < 32) pixel_hist[lane] = 0;
+        // per-plane extent of the box (5-bit keys)
+        if (lane < 3) {
+            s_min[lane] = 31;
+            s_max[lane] = 0;
+        }
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < box.colors; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            if (i < box.colors) {
-                const uint32_t e = src[box.ind + i];
-                atomicAdd(&color_hist[0][PlaneKey(e, 0)], 1u);
-                atomicAdd(&color_hist[1][PlaneKey(e, 1)], 1u);
-                atomicAdd(&color_hist[2][PlaneKey(e, 2)], 1u);
+        {
+            uint32_t mn[3] = {31, 31, 31}, mx[3] = {0, 0, 0};
+            for (uint32_t i = lane; i < box.colors; i += 64) {
+                const uint32_t e = src[i];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const uint32_t k = PlaneKey(e, p);
+                    mn[p] = k < mn[p] ? k : mn[p];
+                    mx[p] = k > mx[p] ? k : mx[p];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                atomicMin(&s_min[p], mn[p]);
+                atomicMax(&s_max[p], mx[p]);
             }
         }
         __syncthreads();
@@ -217,130 +247,159 @@ __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b)
         {
             const double lum[3] = {0.2989, 0.5866, 0.1145};
             double best         = 0.0;
+#pragma unroll
             for (int p = 0; p < 3; ++p) {
-                int lo = 31, hi = 0;
-                for (int k = 0; k < 32; ++k)
-                    if (color_hist[p][k]) {
-                        lo = k < lo ? k : lo;
-                        hi = k > hi ? k : hi;
-                    }
-                const double spread = lum[p] * (double)((hi - lo) << 3);
+                const double spread = lum[p] * (double)((s_max[p] - s_min[p]) << 3);
                 if (spread > best) {
                     plane = p;
                     best  = spread;
                 }
             }
         }
-        // exclusive bases of the stable counting sort
-        if (lane == 0) {
-            uint32_t acc = 0;
-            for (int k = 0; k < 32; ++k) {
-                key_base[k] = acc;
-                acc += color_hist[plane][k];
-            }
-        }
-        __syncthreads();
-        // pass 2: stable scatter by key, chunk after chunk in order
-        for (uint32_t i0 = 0; i0 < box.colors; i0 += 64) {
-            const uint32_t i   = i0 + lane;
-            const bool live    = i < box.colors;
-            const uint32_t e   = live ? src[box.ind + i] : 0u;
-            const uint32_t key = live ? PlaneKey(e, plane) : 0xffu;
-            uint32_t rank      = 0;
-            unsigned long long todo = __ballot(live);
-            while (todo) {  // one round per distinct key in this chunk (uniform)
-                const int leader              = __ffsll((long long)todo) - 1;
-                const uint32_t k0             = __shfl(key, leader);
-                const unsigned long long same = __ballot(live && key == k0);
-                if (live && key == k0) rank = key_base[k0] + (uint32_t)__popcll(same & lt_mask);
-                __syncthreads();
-                if (lane == leader) key_base[k0] += (uint32_t)__popcll(same);
-                __syncthreads();
-                todo &= ~same;
-            }
-            if (live) {
-                dst[box.ind + rank] = e;
-                atomicAdd(&pixel_hist[key], e >> 15);
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        // median by pixel count (libsixel splitBox): with P(i) = sum of the first i
-        // counts, the smallest i in [1, colors-1] with P(i) >= sum/2, else colors-1.
-        // Locate the key bin through the per-key pixel totals, then walk inside it.
-        const uint32_t half = box.sum / 2;
-        uint32_t median, lowersum;
-        {
-            uint32_t before_px = 0, before_n = 0;
-            int kb = 0;
-            for (; kb < 31; ++kb) {
-                if (color_hist[plane][kb] && before_px + pixel_hist[kb] >= half) break;
-                before_px += pixel_hist[kb];
-                before_n += color_hist[plane][kb];
-            }
-            const uint32_t cnt = color_hist[plane][kb];
-            uint32_t run       = before_px;
-            uint32_t found = 0xffffffffu, found_sum = 0;
-            for (uint32_t j0 = 0; j0 < cnt && found == 0xffffffffu; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const uint32_t c = j < cnt ? (dst[box.ind + before_n + j] >> 15) : 0u;
-                uint32_t incl    = c;
+
+        if (box.colors <= 64) {
+            // ---- small box: stable LSD radix sort on the key, in registers -----
+            const bool live = (uint32_t)lane < box.colors;
+            uint32_t e      = live ? src[lane] : 0xffffffffu;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
+            for (int bit = 0; bit < 6; ++bit) {
+                // dead lanes carry key 32 so that they sort behind everything
+                const uint32_t key = e == 0xffffffffu ? 32u : PlaneKey(e, plane);
+                const bool one     = (key >> bit) & 1u;
+                const unsigned long long ones = __ballot(one);
+                const int n_zero   = 64 - __popcll(ones);
+                const int dest     = one ? n_zero + __popcll(ones & lt_mask) : __popcll(~ones & lt_mask);
+                // forward permutation through LDS (the lane-count scratch is free here)
+                lane_cnt[dest] = e;
+                __syncthreads();
+                e = lane_cnt[lane];
+                __syncthreads();
+            }
+            if (live) dst[lane] = e;
+            const uint32_t c = live ? (e >> 15) : 0u;
+            uint32_t incl    = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t pre = incl - c;  // P(lane): pixels in front of entry `lane`
+            const unsigned long long hit = __ballot(live && lane >= 1 && pre >= half);
+            median = hit ? (uint32_t)__ffsll((long long)hit) - 1 : box.colors - 1;
+            if (median > box.colors - 1) median = box.colors - 1;
+            lowersum = __shfl(pre, (int)median);
+        } else {
+            // ---- large box: stable counting sort, one contiguous segment per lane -
+            // (odd segment length keeps the lanes on different LDS banks)
+            const uint32_t seg = (((box.colors + 63) / 64) | 1u);
+            const uint32_t a   = min(box.colors, (uint32_t)lane * seg);
+            const uint32_t z   = min(box.colors, a + seg);
+            uint32_t *mine     = lane_cnt + lane * 33;
+            for (int k = 0; k < 32; ++k) mine[k] = 0;
+            for (uint32_t i = a; i < z; ++i) mine[PlaneKey(src[i], plane)] += 1;
+            __syncthreads();
+            if (lane < 32) {  // exclusive prefix over the lanes, per key
+                uint32_t run = 0;
+                for (int l = 0; l < 64; ++l) {
+                    const uint32_t t       = lane_cnt[l * 33 + lane];
+                    lane_cnt[l * 33 + lane] = run;
+                    run += t;
+                }
+                s_key_total[lane] = run;
+            }
+            __syncthreads();
+            if (lane < 32) {
+                uint32_t incl = s_key_total[lane];
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
                     const uint32_t o = __shfl_up(incl, d);
                     if (lane >= d) incl += o;
                 }
-                const uint32_t idx = before_n + j;
-                const uint32_t pre = run + incl - c;  // P(idx)
-                const bool hit     = j < cnt && idx >= 1 && pre >= half;
-                const unsigned long long m = __ballot(hit);
-                if (m) {
-                    const int l = __ffsll((long long)m) - 1;
-                    found       = __shfl(idx, l);
-                    found_sum   = __shfl(pre, l);
+                s_key_base[lane] = incl - s_key_total[lane];
+            }
+            __syncthreads();
+            for (uint32_t i = a; i < z; ++i) {
+                const uint32_t e   = src[i];
+                const uint32_t k   = PlaneKey(e, plane);
+                const uint32_t off = mine[k];
+                mine[k]            = off + 1;
+                dst[s_key_base[k] + off] = e;
+            }
+            __threadfence_block();
+            __syncthreads();
+            // median: the lane whose segment of the sorted box holds the crossing walks it
+            uint32_t seg_sum = 0;
+            for (uint32_t i = a; i < z; ++i) seg_sum += dst[i] >> 15;
+            uint32_t incl = seg_sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            uint32_t run  = incl - seg_sum;  // P(a)
+            uint32_t cand = 0xffffffffu, cand_sum = 0;
+            for (uint32_t i = a; i < z; ++i) {
+                if (i >= 1 && run >= half) {
+                    cand     = i;
+                    cand_sum = run;
+                    break;
                 }
-                run += __shfl(incl, 63);
+                run += dst[i] >> 15;
             }
-            if (found == 0xffffffffu) {  // first entry of the next bin
-                found     = before_n + cnt;
-                found_sum = before_px + pixel_hist[kb];
+            const unsigned long long hit = __ballot(cand != 0xffffffffu);
+            if (hit) {
+                const int l = __ffsll((long long)hit) - 1;  // lowest lane = lowest index
+                median      = __shfl(cand, l);
+                lowersum    = __shfl(cand_sum, l);
+            } else {
+                median   = box.colors - 1;
+                lowersum = 0;
             }
-            median   = found;
-            lowersum = found_sum;
             if (median >= box.colors - 1) {
                 median   = box.colors - 1;
-                lowersum = box.sum - (dst[box.ind + box.colors - 1] >> 15);
+                lowersum = box.sum - (dst[box.colors - 1] >> 15);
             }
         }
-        // split, then stable re-sort of the boxes by sum, descending
-        __syncthreads();
+
+        // replace the box by its halves and restore the stable sum-descending order:
+        // the low half keeps the parent's place in the pre-sort sequence, the high
+        // half is appended (libsixel qsorts the whole vector; pinned as stable).
+        const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u};
+        const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u};
+        uint32_t cnt_gt_lo = 0, cnt_ge_hi = 0;
+        for (uint32_t i0 = 0; i0 < nboxes; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool other = i < nboxes && i != bi;
+            const uint32_t sm = other ? boxes[i].sum : 0u;
+            cnt_gt_lo += (uint32_t)__popcll(__ballot(other && sm > lo.sum));
+            cnt_ge_hi += (uint32_t)__popcll(__ballot(other && sm >= hi.sum));
+        }
+        for (uint32_t i0 = 0; i0 < nboxes; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            if (i < nboxes && i != bi) {
+                const CutBox o = boxes[i];
+                const uint32_t pos = (i < bi ? i : i - 1) + (o.sum > lo.sum ? 0u : 1u) +
+                                     (o.sum >= hi.sum ? 0u : 1u);
+                boxes_next[pos] = o;
+            }
+        }
         if (lane == 0) {
-            boxes[bi]     = CutBox{box.ind, median, lowersum, box.buf ^ 1u};
-            boxes[nboxes] = CutBox{box.ind + median, box.colors - median, box.sum - lowersum,
-                                   box.buf ^ 1u};
+            boxes_next[cnt_gt_lo + (lo.sum < hi.sum ? 1u : 0u)]  = lo;
+            boxes_next[cnt_ge_hi + (lo.sum >= hi.sum ? 1u : 0u)] = hi;
         }
         ++nboxes;
-        __syncthreads();
-        for (uint32_t i = lane; i < nboxes; i += 64) {
-            const uint32_t mine = boxes[i].sum;
-            uint32_t rank       = 0;
-            for (uint32_t j = 0; j < nboxes; ++j) {
-                const uint32_t o = boxes[j].sum;
-                rank += (o > mine || (o == mine && j < i)) ? 1u : 0u;
-            }
-            boxes_tmp[rank] = boxes[i];
-        }
-        __syncthreads();
-        for (uint32_t i = lane; i < nboxes; i += 64) boxes[i] = boxes_tmp[i];
+        CutBox *t  = boxes;
+        boxes      = boxes_next;
+        boxes_next = t;
         __syncthreads();
     }
     // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
     for (uint32_t bi = lane; bi < nboxes; bi += 64) {
         const CutBox box    = boxes[bi];
-        const uint32_t *src = box.buf ? s.tab_b : s.tab_a;
+        const uint32_t *src = tab[box.buf] + box.ind;
         uint32_t sum[3]     = {0, 0, 0};
         for (uint32_t i = 0; i < box.colors; ++i) {
-            const uint32_t e = src[box.ind + i];
+            const uint32_t e = src[i];
             sum[0] += ((e >> 10) & 0x1f) << 3;
             sum[1] += ((e >> 5) & 0x1f) << 3;
             sum[2] += (e & 0x1f) << 3;
@@ -1021,14 +1080,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.out_cap    = out_cap;
     b.out_len    = (unsigned long long *)(base + o_len);
 
-    const size_t nbins = nf * 32768;
-    hipLaunchKernelGGL(InitHistKernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, st,
-                       b.hist_cnt, b.hist_first, nbins);
-    const dim3 sgrid((g.n_samples + 255) / 256, n_frames);
-    hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(64), 0, st, g, b);
-    hipLaunchKernelGGL(BuildLutKernel, dim3(128, n_frames), dim3(256), 0, st, g, b);
     const size_t dither_lds = (32768 + (size_t)w) * sizeof(uint32_t);
     const size_t band_lds   = kBandLdsBytes;
     // both kernels need more than the default 64 KiB of dynamic LDS
@@ -1038,6 +1089,17 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)EncodeBandKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)band_lds));
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kCutLdsBytes));
+    const size_t nbins = nf * 32768;
+    hipLaunchKernelGGL(InitHistKernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, st,
+                       b.hist_cnt, b.hist_first, nbins);
+    const dim3 sgrid((g.n_samples + 255) / 256, n_frames);
+    hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(64), kCutLdsBytes, st, g, b);
+    hipLaunchKernelGGL(BuildLutKernel, dim3(128, n_frames), dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(DitherKernel, dim3(n_frames), dim3(64), dither_lds, st, g, b);
     hipLaunchKernelGGL(EncodeBandKernel, dim3(g.bands, n_frames), dim3(256), band_lds, st, g, b);
     hipLaunchKernelGGL(AssembleFrameKernel, dim3(n_frames), dim3(256), 0, st, g, b);

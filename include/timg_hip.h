@@ -161,6 +161,23 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
                           size_t out_cap, int out_on_device, size_t *out_len,
                           void *stream);
 
+/* Stateful canvas = one UnicodeBlockCanvas object: keeps what the reference
+ * keeps between Sends (last height / indent and the backing store of the
+ * previous frame, src/unicode-block-canvas.h:66-79) on the device, so that
+ * animations get the frame-difference encoding of Send (:343-346: cells equal
+ * to the previous frame are skipped, :244-247, and turn into cursor moves,
+ * :249-263, :313-315, :397-399).  `flags` as above. */
+typedef struct timg_hip_block_canvas timg_hip_block_canvas;
+int timg_hip_block_canvas_create(timg_hip_ctx *ctx, int flags, timg_hip_block_canvas **out);
+void timg_hip_block_canvas_destroy(timg_hip_block_canvas *c);
+/* One Send(x, dy, fb): writes the bytes Send appends after its cursor prefix
+ * into the host buffer out (capacity out_cap >= timg_hip_block_max_bytes) and
+ * their count into *out_len (0 = the reference hands an empty buffer to the
+ * sequencer, :390-395).  fb may be host or device memory.  Synchronises. */
+int timg_hip_block_canvas_send(timg_hip_block_canvas *c, int x, int dy, const uint8_t *fb,
+                               int w, int h, int stride, int fb_on_device, char *out,
+                               size_t out_cap, size_t *out_len, void *stream);
+
 /* ---- sixel canvas: timg::SixelCanvas -------------------------------------
  * Replaces the two libsixel calls of SixelCanvas::Send
  * (src/sixel-canvas.cc:137-145: sixel_dither_initialize + sixel_encode) and

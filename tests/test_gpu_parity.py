@@ -130,6 +130,50 @@ def test_block_indent_and_batch(hip, oracle):
             assert outs[i] == oracle.block_encode(frames[i], quarter=bool(flags & 1), x=x), i
 
 
+def _cursor_up_prefix(dy, rows_of):
+    # TerminalCanvas::MoveCursorDY as consumed by Send (src/terminal-canvas.cc:66-73)
+    return b"" if dy >= 0 else b"\x1b[%dA" % rows_of(-dy)
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 5])
+def test_block_frame_diff_sequences(hip, oracle, flags):
+    """Animation frames through one stateful canvas: the frame-difference
+    encoding (skipped cells -> cursor moves) byte for byte against the oracle's
+    canvas, which test_oracle_vs_ref pins to the real UnicodeBlockCanvas."""
+    rng = np.random.default_rng(100 + flags)
+    for trial in range(12):
+        w, h, x = int(rng.integers(2, 90)), int(rng.integers(2, 60)), int(rng.integers(0, 7))
+        if trial == 0:
+            w, h, x = 200, 56, 0
+        q, up, c256 = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+        oc = oracle.block_canvas(q, up, c256)
+        hc = hip.block_canvas(flags)
+        fb = synth.photo(w, h, seed=trial)
+        for f in range(7):
+            dy = 0 if f == 0 else -h
+            if f == 4:
+                dy = -h - 2  # breaks the emit_difference condition (:344-346)
+            k = int(rng.integers(0, 6))
+            fb = fb.copy()
+            if k == 1:
+                fb[rng.integers(0, h), rng.integers(0, w)] = [1, 2, 3, 255]
+            elif k == 2:
+                fb[rng.integers(0, h):] = rng.integers(0, 256, 3).tolist() + [255]
+            elif k == 3:
+                fb = synth.noise(w, h, seed=trial * 10 + f, opaque=True)
+            elif k == 4:  # a few scattered rows change, the rest is skipped
+                for r in rng.integers(0, h, 3):
+                    fb[r, rng.integers(0, w):] = rng.integers(0, 256, 4).tolist()
+            # k == 0 / 5: identical frame -> the reference emits an empty buffer
+            want = oc.send(x, dy, fb)
+            body = hc.send(x, dy, fb, w, h)
+            # the reference drops the cursor prefix too when nothing was emitted (:390-395)
+            got = _cursor_up_prefix(dy, lambda px: (px + 1) // 2) + body if body else b""
+            assert got == want, (trial, f, k, len(got), len(want), got[:60], want[:60])
+        oc.close()
+        hc.close()
+
+
 def test_block_output_too_small_is_reported(hip):
     fb = synth.noise(64, 64, 1)
     with pytest.raises(timg_amd.TimgHipError) as e:

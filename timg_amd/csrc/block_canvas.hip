@@ -9,7 +9,12 @@
 //                  byte length per cell, exclusive prefix inside the row
 //   K3 ScanFrames  one workgroup per frame: row offsets, frame length
 //   K4 EmitCells   one thread per cell: write its bytes at its offset
-// Byte-exact with the reference for a first Send (no frame-diff).
+// Frame-diff mode (emit_difference, :244-247, :343-346): a cell whose pixels
+// equal the previous frame's is skipped; skipped cells turn into cursor-right
+// moves in front of the next emitted cell (:260-263), rows without any emitted
+// cell into newlines / a cursor-down move in front of the next emitting row
+// (:249-258, :313-315) or after the last one (:397-399).  The previous frame
+// stays on the device (it is exactly what the reference's backing store holds).
 #include <cstring>
 
 #include "context.h"
@@ -37,7 +42,7 @@ struct BlockGeom {
     int rows;            // text rows: (h + 1) / 2
     int row_offset;      // -1 when an odd height shifts everything down (:356-358)
     int indent;          // Send's x in character cells
-    int indent_len;      // strlen("\033[<indent>C") or 0
+    int emit_diff;       // compare against the previous frame
     size_t stride, frame_stride;
 };
 
@@ -126,7 +131,7 @@ __device__ __forceinline__ uint32_t FetchPx(const uint8_t *frame, const BlockGeo
 }
 
 __global__ void __launch_bounds__(256)
-PickCellsKernel(const uint8_t *fb, BlockGeom g, CellRec *cells) {
+PickCellsKernel(const uint8_t *fb, const uint8_t *prev_fb, BlockGeom g, CellRec *cells) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     const int trow = blockIdx.y;
     const int f    = blockIdx.z;
@@ -220,6 +225,21 @@ PickCellsKernel(const uint8_t *fb, BlockGeom g, CellRec *cells) {
             rec.meta = best_block;
         }
     }
+    if (g.emit_diff) {  // EqualToBacking, :129-136
+        const uint8_t *prev = prev_fb + (size_t)f * g.frame_stride;
+        bool same;
+        if (!g.quarter) {
+            same = FetchPx(frame, g, top_row, cell) == FetchPx(prev, g, top_row, cell) &&
+                   FetchPx(frame, g, top_row + 1, cell) == FetchPx(prev, g, top_row + 1, cell);
+        } else {
+            const int x = cell * 2;
+            same = FetchPx(frame, g, top_row, x) == FetchPx(prev, g, top_row, x) &&
+                   FetchPx(frame, g, top_row, x + 1) == FetchPx(prev, g, top_row, x + 1) &&
+                   FetchPx(frame, g, top_row + 1, x) == FetchPx(prev, g, top_row + 1, x) &&
+                   FetchPx(frame, g, top_row + 1, x + 1) == FetchPx(prev, g, top_row + 1, x + 1);
+        }
+        if (same) rec.meta |= 0x400u;
+    }
     cells[((size_t)f * g.rows + trow) * g.cells + cell] = rec;
 }
 
@@ -246,6 +266,13 @@ __device__ __forceinline__ uint32_t ColorLen(uint32_t px, int color256) {
     return DigitsLen(px & 0xffu) + DigitsLen((px >> 8) & 0xffu) + DigitsLen((px >> 16) & 0xffu);
 }
 
+__device__ __forceinline__ uint32_t DecLen(uint32_t v) {
+    return v >= 10000 ? 5u : v >= 1000 ? 4u : v >= 100 ? 3u : v >= 10 ? 2u : 1u;
+}
+
+// meta bits of a CellRec after ScanRows:
+//   0-7 block, 8 emit fg, 9 emit bg, 10 skipped (equal to previous frame),
+//   11 first emitted cell of its row, 12 last emitted cell, 16-31 cursor-right count
 // One wave (64 lanes) per text row.
 __global__ void __launch_bounds__(64)
 ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
@@ -254,46 +281,51 @@ ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
     const int f    = blockIdx.y;
     CellRec *row   = cells + ((size_t)f * g.rows + trow) * g.cells;
 
-    // carried across 64-cell chunks
-    bool have_fg      = false;  // a non-background cell was seen: last_fg valid
-    uint32_t last_fg  = 0;
-    bool have_bg      = false;
-    uint32_t prev_bg  = 0;
-    uint32_t base_off = (uint32_t)g.indent_len;
+    // state carried across 64-cell chunks (the reference's per-row locals, :235-240)
+    int last_present   = -1;  // index of the last emitted cell
+    uint32_t prev_bg   = 0;   // its background (pick.bg of `last`)
+    bool have_fg       = false;
+    uint32_t last_fg   = 0;   // last_foreground
+    uint32_t base_off  = 0;
 
     for (int c0 = 0; c0 < g.cells; c0 += 64) {
-        const int i      = c0 + lane;
-        const bool live  = i < g.cells;
-        CellRec rec      = live ? row[i] : CellRec{0, 0, 0, 0};
-        const bool nonbg = live && (rec.meta & 0xffu) != kBackground;
+        const int i        = c0 + lane;
+        const bool live    = i < g.cells;
+        CellRec rec        = live ? row[i] : CellRec{0, 0, 0, 0};
+        const bool present = live && !(rec.meta & 0x400u);
+        const bool nonbg   = present && (rec.meta & 0xffu) != kBackground;
 
-        // fg of the nearest earlier non-background cell (the reference's
-        // last_foreground: it only changes when a non-background cell emits,
-        // and then equals that cell's fg, :270-279).
-        int src = nonbg ? lane : -1;
+        int sp = present ? lane : -1, sn = nonbg ? lane : -1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(src, d);
-            if (lane >= d) src = src > o ? src : o;
+            const int op = __shfl_up(sp, d), on = __shfl_up(sn, d);
+            if (lane >= d) {
+                sp = sp > op ? sp : op;
+                sn = sn > on ? sn : on;
+            }
         }
-        int prev_src = __shfl_up(src, 1);
-        if (lane == 0) prev_src = -1;
-        const uint32_t fg_from_lane = __shfl(rec.fg, prev_src < 0 ? 0 : prev_src);
-        const bool prev_known       = prev_src >= 0 || have_fg;
-        const uint32_t prev_fg      = prev_src >= 0 ? fg_from_lane : last_fg;
-        const bool emit_fg          = nonbg && (!prev_known || rec.fg != prev_fg);
+        int prev_p = __shfl_up(sp, 1), prev_n = __shfl_up(sn, 1);
+        if (lane == 0) prev_p = prev_n = -1;
 
-        uint32_t left_bg = __shfl_up(rec.bg, 1);
-        bool left_known  = true;
-        if (lane == 0) {
-            left_bg    = prev_bg;
-            left_known = have_bg;
-        }
-        const bool emit_bg = live && (!left_known || rec.bg != left_bg);
+        // cursor-right in front of an emitted cell: cells skipped since the last
+        // emitted one; the row starts with x_skip = indent (:240)
+        const int prev_present = prev_p >= 0 ? c0 + prev_p : last_present;
+        const uint32_t skip    = present ? (uint32_t)(i - prev_present - 1 + (prev_present < 0 ? g.indent : 0)) : 0u;
+
+        const uint32_t bg_from_lane = __shfl(rec.bg, prev_p < 0 ? 0 : prev_p);
+        const bool left_known       = prev_p >= 0 || last_present >= 0;
+        const uint32_t left_bg      = prev_p >= 0 ? bg_from_lane : prev_bg;
+        const bool emit_bg          = present && (!left_known || rec.bg != left_bg);
+
+        const uint32_t fg_from_lane = __shfl(rec.fg, prev_n < 0 ? 0 : prev_n);
+        const bool fg_known         = prev_n >= 0 || have_fg;
+        const uint32_t prev_fg      = prev_n >= 0 ? fg_from_lane : last_fg;
+        const bool emit_fg          = nonbg && (!fg_known || rec.fg != prev_fg);
 
         uint32_t len = 0;
-        if (live) {
-            if (emit_fg || emit_bg) len += 2;  // ESC [
+        if (present) {
+            if (skip) len += 3 + DecLen(skip);  // ESC [ n C
+            if (emit_fg || emit_bg) len += 2;   // ESC [
             if (emit_fg) len += 5 + ColorLen(rec.fg, g.color256);
             if (emit_bg) len += Transparent(rec.bg) ? 3u : 5u + ColorLen(rec.bg, g.color256);
             len += (rec.meta & 0xffu) == kBackground ? 1u : 3u;
@@ -306,40 +338,77 @@ ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
         }
         if (live) {
             rec.off  = base_off + incl - len;
-            rec.meta = (rec.meta & 0xffu) | (emit_fg ? 0x100u : 0u) | (emit_bg ? 0x200u : 0u);
-            row[i]   = rec;
+            rec.meta = (rec.meta & 0x4ffu) | (emit_fg ? 0x100u : 0u) | (emit_bg ? 0x200u : 0u) |
+                       ((present && prev_present < 0) ? 0x800u : 0u) | ((skip & 0xffffu) << 16);
+            row[i] = rec;
         }
         // carry
-        const int last_lane   = (g.cells - c0) >= 64 ? 63 : (g.cells - c0 - 1);
-        base_off += __shfl(incl, last_lane);
-        const int chunk_src   = __shfl(src, last_lane);
-        const uint32_t cfg    = __shfl(rec.fg, chunk_src < 0 ? 0 : chunk_src);
-        if (chunk_src >= 0) {
+        base_off += __shfl(incl, 63);
+        const int chunk_p = __shfl(sp, 63), chunk_n = __shfl(sn, 63);
+        const uint32_t cbg = __shfl(rec.bg, chunk_p < 0 ? 0 : chunk_p);
+        const uint32_t cfg = __shfl(rec.fg, chunk_n < 0 ? 0 : chunk_n);
+        if (chunk_p >= 0) {
+            last_present = c0 + chunk_p;
+            prev_bg      = cbg;
+        }
+        if (chunk_n >= 0) {
             have_fg = true;
             last_fg = cfg;
         }
-        prev_bg = __shfl(rec.bg, last_lane);
-        have_bg = true;
     }
-    if (lane == 0) row_len[(size_t)f * g.rows + trow] = base_off + 5;  // + "\033[0m\n"
+    if (lane == 0) {
+        if (last_present >= 0) row[last_present].meta |= 0x1000u;  // writes "\033[0m\n" (:313-318)
+        row_len[(size_t)f * g.rows + trow] = last_present >= 0 ? base_off + 5 : 0u;
+    }
 }
 
-// One workgroup per frame: exclusive scan of the row lengths (in place ->
-// row offsets) and the frame total.
+// One workgroup per frame: vertical skips, row offsets and the frame length.
+// row_len (in/out): byte length of each text row -> its byte offset;
+// row_yskip (out): empty rows immediately above each emitting row.
+__device__ __forceinline__ char *PutDec(char *p, uint32_t v) {
+    char t[10];
+    int n = 0;
+    do {
+        t[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
+
 __global__ void __launch_bounds__(256)
-ScanFramesKernel(BlockGeom g, uint32_t *row_len, unsigned long long *frame_len) {
+ScanFramesKernel(BlockGeom g, uint32_t *row_len, uint32_t *row_yskip,
+                 unsigned long long *frame_len, char *out, size_t out_cap) {
     __shared__ uint32_t wave_tot[4];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t carry, trailing;
     const int f    = blockIdx.x;
     const int tid  = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     uint32_t *rl   = row_len + (size_t)f * g.rows;
-    if (tid == 0) carry = 0;
+    uint32_t *ys   = row_yskip + (size_t)f * g.rows;
+    if (tid == 0) {
+        carry      = 0;
+        uint32_t k = 0;
+        for (int q = g.rows - 1; q >= 0 && rl[q] == 0; --q) ++k;
+        trailing = k;  // rows left empty at the bottom
+    }
+    // y_skip of a row = number of consecutive empty rows right above it
+    for (int r = tid; r < g.rows; r += 256) {
+        uint32_t k = 0;
+        if (rl[r] != 0)
+            for (int q = r - 1; q >= 0 && rl[q] == 0; --q) ++k;
+        ys[r] = k;
+    }
     __syncthreads();
     for (int r0 = 0; r0 < g.rows; r0 += 256) {
-        const int r      = r0 + tid;
-        const uint32_t v = r < g.rows ? rl[r] : 0u;
-        uint32_t incl    = v;
+        const int r = r0 + tid;
+        uint32_t v  = 0;
+        if (r < g.rows && rl[r] != 0) {
+            const uint32_t k = ys[r];
+            // up to four '\n', else ESC [ k B (:249-258)
+            v = rl[r] + (k == 0 ? 0u : (k <= 4 ? k : 3u + DecLen(k)));
+        }
+        uint32_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(incl, d);
@@ -354,7 +423,24 @@ ScanFramesKernel(BlockGeom g, uint32_t *row_len, unsigned long long *frame_len) 
         if (tid == 255) carry = before + incl;
         __syncthreads();
     }
-    if (tid == 0) frame_len[f] = carry;
+    if (tid == 0) {
+        uint32_t total = carry;
+        // nothing emitted at all: zero-size buffer (:390-395); otherwise one
+        // cursor-down move over the empty rows at the bottom (:397-399)
+        if (total != 0 && trailing != 0) {
+            char tmp[16];
+            char *p = tmp;
+            *p++    = '\033';
+            *p++    = '[';
+            p       = PutDec(p, trailing);
+            *p++    = 'B';
+            char *frame_out = out + (size_t)f * out_cap;
+            for (int i = 0; i < (int)(p - tmp); ++i)
+                if ((size_t)total + i < out_cap) frame_out[total + i] = tmp[i];
+            total += (uint32_t)(p - tmp);
+        }
+        frame_len[f] = total;
+    }
 }
 
 __device__ __forceinline__ char *PutNum(char *p, uint32_t v) {  // "ddd;"
@@ -387,19 +473,39 @@ __constant__ unsigned char kGlyphBytes[9][3] = {
 };
 
 __global__ void __launch_bounds__(256)
-EmitCellsKernel(BlockGeom g, const CellRec *cells, const uint32_t *row_off, char *out,
-                size_t out_cap) {
+EmitCellsKernel(BlockGeom g, const CellRec *cells, const uint32_t *row_off,
+                const uint32_t *row_yskip, char *out, size_t out_cap) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     const int trow = blockIdx.y;
     const int f    = blockIdx.z;
     if (cell >= g.cells) return;
     const size_t row_index = (size_t)f * g.rows + trow;
     const CellRec rec      = cells[row_index * g.cells + cell];
-    const size_t row_base  = row_off[row_index];
+    if (rec.meta & 0x400u) return;  // unchanged since the previous frame
+    const uint32_t yskip   = (rec.meta & 0x800u) ? row_yskip[row_index] : 0u;
+    // the vertical skip sits in front of the row's first emitted cell
+    const size_t y_len     = yskip == 0 ? 0 : (yskip <= 4 ? yskip : 3 + DecLen(yskip));
     char *frame_out        = out + (size_t)f * out_cap;
 
-    char buf[48];
-    char *p              = buf;
+    char buf[80];
+    char *p = buf;
+    if (yskip) {
+        if (yskip <= 4) {
+            for (uint32_t i = 0; i < yskip; ++i) *p++ = '\n';
+        } else {
+            *p++ = '\033';
+            *p++ = '[';
+            p    = PutDec(p, yskip);
+            *p++ = 'B';
+        }
+    }
+    const uint32_t skip = rec.meta >> 16;
+    if (skip) {  // "\033[<n>C", :260-263
+        *p++ = '\033';
+        *p++ = '[';
+        p    = PutDec(p, skip);
+        *p++ = 'C';
+    }
     const uint32_t block = rec.meta & 0xffu;
     const bool emit_fg = rec.meta & 0x100u, emit_bg = rec.meta & 0x200u;
     if (emit_fg || emit_bg) {
@@ -426,40 +532,88 @@ EmitCellsKernel(BlockGeom g, const CellRec *cells, const uint32_t *row_off, char
         *p++ = (char)kGlyphBytes[block][1];
         *p++ = (char)kGlyphBytes[block][2];
     }
-    const size_t at = row_base + rec.off;
+    if (rec.meta & 0x1000u) {  // last emitted cell of the row: "\033[0m\n", :313-318
+        *p++ = '\033'; *p++ = '['; *p++ = '0'; *p++ = 'm'; *p++ = '\n';
+    }
+    // row offsets already include every earlier row's vertical skip; this row's
+    // own skip shifts all of its cells but the first one
+    const size_t at = (size_t)row_off[row_index] + rec.off + ((rec.meta & 0x800u) ? 0 : 0);
     const int n     = (int)(p - buf);
+    (void)y_len;
     for (int i = 0; i < n; ++i)
         if (at + i < out_cap) frame_out[at + i] = buf[i];
+}
 
-    if (cell == 0 && g.indent_len > 0) {  // "\033[<indent>C", :260-263
-        char ib[16];
-        int k        = 0;
-        ib[k++]      = '\033';
-        ib[k++]      = '[';
-        char digits[12];
-        int nd       = 0;
-        uint32_t v   = (uint32_t)g.indent;
-        do {
-            digits[nd++] = (char)('0' + v % 10);
-            v /= 10;
-        } while (v);
-        while (nd) ib[k++] = digits[--nd];
-        ib[k++] = 'C';
-        for (int i = 0; i < k; ++i)
-            if (row_base + i < out_cap) frame_out[row_base + i] = ib[i];
-    }
-    if (cell == g.cells - 1) {  // "\033[0m\n", :313-318
-        const char tail[5] = {'\033', '[', '0', 'm', '\n'};
-        const size_t e     = at + n;
-        for (int i = 0; i < 5; ++i)
-            if (e + i < out_cap) frame_out[e + i] = tail[i];
-    }
+// Adds a row's own vertical-skip length to the offsets of all of its cells but
+// the first emitted one (which carries the skip bytes itself).
+__global__ void __launch_bounds__(256)
+ShiftRowsKernel(BlockGeom g, CellRec *cells, const uint32_t *row_yskip) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int trow = blockIdx.y;
+    const int f    = blockIdx.z;
+    if (cell >= g.cells) return;
+    const size_t row_index = (size_t)f * g.rows + trow;
+    const uint32_t k       = row_yskip[row_index];
+    if (k == 0) return;
+    CellRec *rec = &cells[row_index * g.cells + cell];
+    if (rec->meta & 0xc00u) return;  // skipped cell, or the first emitted one
+    rec->off += k <= 4 ? k : 3u + DecLen(k);
+}
+
+struct BlockScratch {
+    CellRec *cells;
+    uint32_t *row_len, *row_yskip;
+    unsigned long long *frame_len;
+};
+
+hipError_t RunBlockEncode(const uint8_t *fb, const uint8_t *prev, const BlockGeom &g, int n_frames,
+                          const BlockScratch &sc, char *out, size_t out_cap, hipStream_t st) {
+    const dim3 cell_grid((g.cells + 255) / 256, g.rows, n_frames);
+    hipLaunchKernelGGL(PickCellsKernel, cell_grid, dim3(256), 0, st, fb, prev, g, sc.cells);
+    hipLaunchKernelGGL(ScanRowsKernel, dim3(g.rows, n_frames), dim3(64), 0, st, g, sc.cells,
+                       sc.row_len);
+    hipLaunchKernelGGL(ScanFramesKernel, dim3(n_frames), dim3(256), 0, st, g, sc.row_len,
+                       sc.row_yskip, sc.frame_len, out, out_cap);
+    if (g.emit_diff)
+        hipLaunchKernelGGL(ShiftRowsKernel, cell_grid, dim3(256), 0, st, g, sc.cells, sc.row_yskip);
+    hipLaunchKernelGGL(EmitCellsKernel, cell_grid, dim3(256), 0, st, g, sc.cells, sc.row_len,
+                       sc.row_yskip, out, out_cap);
+    return hipGetLastError();
+}
+
+BlockGeom MakeGeom(int w, int h, int stride, size_t frame_stride, int flags, int x_indent) {
+    BlockGeom g;
+    g.w            = w;
+    g.h            = h;
+    g.quarter      = (flags & TIMG_HIP_BLOCK_QUARTER) != 0;
+    g.upper        = (flags & TIMG_HIP_BLOCK_UPPER) != 0;
+    g.color256     = (flags & TIMG_HIP_BLOCK_COLOR256) != 0;
+    g.cells        = g.quarter ? (w + 1) / 2 : w;
+    g.rows         = (h + 1) / 2;
+    g.row_offset   = ((h & 1) && !g.upper) ? -1 : 0;
+    g.indent       = g.quarter ? x_indent / 2 : x_indent;
+    g.emit_diff    = 0;
+    g.stride       = (size_t)stride;
+    g.frame_stride = frame_stride;
+    return g;
 }
 
 }  // namespace
 }  // namespace timg_amd
 
 using namespace timg_amd;
+
+// Stateful canvas: what UnicodeBlockCanvas keeps between Sends (:66-79 of the
+// header): last height / indent and the previous frame (its backing store).
+struct timg_hip_block_canvas {
+    timg_hip_ctx *ctx = nullptr;
+    int flags         = 0;
+    int last_height = 0, last_x_indent = 0, last_width = 0;
+    TimgBuffer prev;     // previous frame, device
+    TimgBuffer cur;      // staging for host frames
+    TimgBuffer scratch;  // cells + rows
+    TimgBuffer dout;     // device output when the caller's buffer is on the host
+};
 
 extern "C" {
 
@@ -485,24 +639,7 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, in
     hipStream_t st = ctx->Stream(stream);
     std::lock_guard<std::mutex> lock(ctx->mu);
 
-    BlockGeom g;
-    g.w            = w;
-    g.h            = h;
-    g.quarter      = (flags & TIMG_HIP_BLOCK_QUARTER) != 0;
-    g.upper        = (flags & TIMG_HIP_BLOCK_UPPER) != 0;
-    g.color256     = (flags & TIMG_HIP_BLOCK_COLOR256) != 0;
-    g.cells        = g.quarter ? (w + 1) / 2 : w;
-    g.rows         = (h + 1) / 2;
-    g.row_offset   = ((h & 1) && !g.upper) ? -1 : 0;
-    g.indent       = g.quarter ? x_indent / 2 : x_indent;
-    g.indent_len   = 0;
-    if (g.indent > 0) {
-        char tmp[32];
-        g.indent_len = snprintf(tmp, sizeof(tmp), "\033[%dC", g.indent);
-    }
-    g.stride       = (size_t)stride;
-    g.frame_stride = frame_stride;
-
+    const BlockGeom g = MakeGeom(w, h, stride, frame_stride, flags, x_indent);
     const size_t fb_bytes = frame_stride * (size_t)(n_frames - 1) + (size_t)stride * h;
     const uint8_t *dfb    = fb;
     if (!fb_on_device) {
@@ -518,22 +655,18 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, in
     const size_t n_rows  = (size_t)g.rows * n_frames;
     const size_t n_cells = n_rows * g.cells;
     TIMG_HIP_TRY(ctx, ctx->dev[3].Reserve(n_cells * sizeof(CellRec)));
-    TIMG_HIP_TRY(ctx, ctx->dev[4].Reserve(n_rows * sizeof(uint32_t)));
+    TIMG_HIP_TRY(ctx, ctx->dev[4].Reserve(2 * n_rows * sizeof(uint32_t)));
     TIMG_HIP_TRY(ctx, ctx->dev[2].Reserve(sizeof(unsigned long long) * n_frames));
     TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * n_frames));
-    CellRec *cells              = (CellRec *)ctx->dev[3].ptr;
-    uint32_t *row_len           = (uint32_t *)ctx->dev[4].ptr;
-    unsigned long long *flen    = (unsigned long long *)ctx->dev[2].ptr;
-    unsigned long long *flen_h  = (unsigned long long *)ctx->pin[0].ptr;
+    BlockScratch sc;
+    sc.cells      = (CellRec *)ctx->dev[3].ptr;
+    sc.row_len    = (uint32_t *)ctx->dev[4].ptr;
+    sc.row_yskip  = sc.row_len + n_rows;
+    sc.frame_len  = (unsigned long long *)ctx->dev[2].ptr;
+    unsigned long long *flen_h = (unsigned long long *)ctx->pin[0].ptr;
 
-    const dim3 cell_grid((g.cells + 255) / 256, g.rows, n_frames);
-    hipLaunchKernelGGL(PickCellsKernel, cell_grid, dim3(256), 0, st, dfb, g, cells);
-    hipLaunchKernelGGL(ScanRowsKernel, dim3(g.rows, n_frames), dim3(64), 0, st, g, cells, row_len);
-    hipLaunchKernelGGL(ScanFramesKernel, dim3(n_frames), dim3(256), 0, st, g, row_len, flen);
-    hipLaunchKernelGGL(EmitCellsKernel, cell_grid, dim3(256), 0, st, g, cells, row_len, dout,
-                       out_cap);
-    TIMG_HIP_TRY(ctx, hipGetLastError());
-    TIMG_HIP_TRY(ctx, hipMemcpyAsync(flen_h, flen, sizeof(unsigned long long) * n_frames,
+    TIMG_HIP_TRY(ctx, RunBlockEncode(dfb, nullptr, g, n_frames, sc, dout, out_cap, st));
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(flen_h, sc.frame_len, sizeof(unsigned long long) * n_frames,
                                      hipMemcpyDeviceToHost, st));
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     size_t worst = 0;
@@ -549,6 +682,75 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, in
                                              out_len[i], hipMemcpyDeviceToHost, st));
         TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
+    return TIMG_HIP_OK;
+}
+
+int timg_hip_block_canvas_create(timg_hip_ctx *ctx, int flags, timg_hip_block_canvas **out) {
+    if (!ctx || !out) return TIMG_HIP_ERR_ARG;
+    timg_hip_block_canvas *c = new (std::nothrow) timg_hip_block_canvas();
+    if (!c) return TIMG_HIP_ERR_NOMEM;
+    c->ctx   = ctx;
+    c->flags = flags;
+    *out     = c;
+    return TIMG_HIP_OK;
+}
+
+void timg_hip_block_canvas_destroy(timg_hip_block_canvas *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    c->prev.Release();
+    c->cur.Release();
+    c->scratch.Release();
+    c->dout.Release();
+    delete c;
+}
+
+int timg_hip_block_canvas_send(timg_hip_block_canvas *c, int x, int dy, const uint8_t *fb, int w,
+                               int h, int stride, int fb_on_device, char *out, size_t out_cap,
+                               size_t *out_len, void *stream) {
+    if (!c || !fb || !out || !out_len || w <= 0 || h <= 0 || x < 0) return TIMG_HIP_ERR_ARG;
+    timg_hip_ctx *ctx = c->ctx;
+    if (stride == 0) stride = w * 4;
+    if (stride < w * 4 || (stride & 3) || ((uintptr_t)fb & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride/alignment");
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->Stream(stream);
+    BlockGeom g    = MakeGeom(w, h, w * 4, (size_t)w * 4 * h, c->flags, x);
+    // :344-346 (plus: the backing store must describe a frame of this width)
+    g.emit_diff = (g.indent == c->last_x_indent) && (c->last_height > 0) &&
+                  (dy < 0 ? -dy : dy) == c->last_height && c->last_width == w && c->last_height == h;
+    const size_t bytes = (size_t)w * 4 * h;
+    TIMG_HIP_TRY(ctx, c->cur.Reserve(bytes));
+    TIMG_HIP_TRY(ctx, c->prev.Reserve(bytes));
+    // tightly packed device copy of the frame (it becomes the next backing store)
+    TIMG_HIP_TRY(ctx, hipMemcpy2DAsync(c->cur.ptr, (size_t)w * 4, fb, (size_t)stride, (size_t)w * 4,
+                                       (size_t)h, fb_on_device ? hipMemcpyDeviceToDevice
+                                                               : hipMemcpyHostToDevice, st));
+    const size_t n_rows = (size_t)g.rows, n_cells = n_rows * g.cells;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_rows = align(n_cells * sizeof(CellRec));
+    const size_t o_len  = align(o_rows + 2 * n_rows * sizeof(uint32_t));
+    TIMG_HIP_TRY(ctx, c->scratch.Reserve(o_len + 64));
+    TIMG_HIP_TRY(ctx, c->dout.Reserve(out_cap));
+    BlockScratch sc;
+    sc.cells     = (CellRec *)c->scratch.ptr;
+    sc.row_len   = (uint32_t *)((char *)c->scratch.ptr + o_rows);
+    sc.row_yskip = sc.row_len + n_rows;
+    sc.frame_len = (unsigned long long *)((char *)c->scratch.ptr + o_len);
+    TIMG_HIP_TRY(ctx, RunBlockEncode((const uint8_t *)c->cur.ptr, (const uint8_t *)c->prev.ptr, g, 1,
+                                     sc, (char *)c->dout.ptr, out_cap, st));
+    unsigned long long len = 0;
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(&len, sc.frame_len, sizeof(len), hipMemcpyDeviceToHost, st));
+    TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    // the frame just shown is the new backing store
+    std::swap(c->cur, c->prev);
+    c->last_height   = h;
+    c->last_width    = w;
+    c->last_x_indent = g.indent;
+    *out_len         = (size_t)len;
+    if (len > out_cap)
+        return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %llu bytes, out_cap is %zu", len, out_cap);
+    if (len) TIMG_HIP_TRY(ctx, hipMemcpy(out, c->dout.ptr, (size_t)len, hipMemcpyDeviceToHost));
     return TIMG_HIP_OK;
 }
 

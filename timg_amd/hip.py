@@ -86,6 +86,11 @@ def load_library():
     L.timg_hip_block_max_bytes.restype = c_size_t
     L.timg_hip_block_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
                                         c_int, c_int, vp, c_size_t, c_int, POINTER(c_size_t), vp]
+    L.timg_hip_block_canvas_create.argtypes = [vp, c_int, POINTER(vp)]
+    L.timg_hip_block_canvas_destroy.argtypes = [vp]
+    L.timg_hip_block_canvas_destroy.restype = None
+    L.timg_hip_block_canvas_send.argtypes = [vp, c_int, c_int, vp, c_int, c_int, c_int, c_int, vp,
+                                             c_size_t, POINTER(c_size_t), vp]
     L.timg_hip_sixel_max_bytes.argtypes = [c_int, c_int]
     L.timg_hip_sixel_max_bytes.restype = c_size_t
     L.timg_hip_sixel_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
@@ -124,6 +129,32 @@ class Scaler:
     def close(self):
         if self.handle:
             self.owner.L.timg_hip_scaler_destroy(self.handle)
+            self.handle = None
+
+
+class BlockCanvas:
+    """timg_hip_block_canvas: one UnicodeBlockCanvas' worth of state (frame-diff)."""
+
+    def __init__(self, owner: "TimgHip", flags: int):
+        self.owner = owner
+        h = c_void_p()
+        owner._check(owner.L.timg_hip_block_canvas_create(owner.ctx, flags, byref(h)))
+        self.handle = h
+
+    def send(self, x: int, dy: int, fb, w: int, h: int, stride: int = 0) -> bytes:
+        """Bytes Send(x, dy, fb) appends after its cursor prefix."""
+        p, dev = _ptr(fb)
+        cap = self.owner.block_max_bytes(w, h)
+        out = np.empty(cap, np.uint8)
+        n = c_size_t()
+        self.owner._check(self.owner.L.timg_hip_block_canvas_send(
+            self.handle, x, dy, p, w, h, stride, int(dev), c_void_p(out.ctypes.data), cap,
+            byref(n), None))
+        return out[:n.value].tobytes()
+
+    def close(self):
+        if self.handle:
+            self.owner.L.timg_hip_block_canvas_destroy(self.handle)
             self.handle = None
 
 
@@ -246,6 +277,9 @@ class TimgHip:
         if host_out:
             return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
         return list(lens)
+
+    def block_canvas(self, flags=0) -> BlockCanvas:
+        return BlockCanvas(self, flags)
 
     def sixel_max_bytes(self, w, h) -> int:
         return int(self.L.timg_hip_sixel_max_bytes(w, h))

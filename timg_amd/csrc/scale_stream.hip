@@ -3,22 +3,27 @@
 // 4K -> 200x56, see resample_plan.cc VerticalFirst).
 //
 // Data flow per workgroup = one (column strip, output-row band, frame):
-//   * every lane owns kPix adjacent source columns and walks the band's source
-//     rows top to bottom ONCE (coalesced 8-byte loads, next row prefetched);
+//   * every lane owns kPix = 4 adjacent source columns (one 16-byte load per
+//     source row, kPrefetch rows in flight) and walks the band's source rows
+//     top to bottom ONCE;
 //   * a source row feeds the <= kSlots output rows whose vertical filter
-//     covers it; their running sums live in registers (7 channels each) and
-//     are updated in source-row order -- exactly stb's vertical chain;
-//   * when an output row has seen its last source row its column sums go to
-//     LDS and the strip's output pixels are produced by the horizontal
+//     covers it; their running sums live in registers and are updated in
+//     source-row order -- exactly stb's vertical chain;
+//   * when an output row has seen its last source row, its column sums go to
+//     one of two LDS staging rows (double buffered: one barrier per completed
+//     row) and the strip's output pixels are produced by the horizontal
 //     even/odd-chain gather, un-weighted, blended and stored as RGBA8.
 // Which slot an output row uses, and the per-row weights, come from a small
-// host-built schedule, so the kernel has no data-dependent control flow beyond
-// wave-uniform branches.
+// host-built schedule that arrives through the scalar cache, so the kernel has
+// no data-dependent control flow beyond wave-uniform branches.
 //
 // HBM traffic: each source byte is read once per band that needs it (band
-// height trades halo re-reads against grid size); same-strip bands land on
-// the same XCD (block id mod 8), so the halo rows are L2 hits.
+// height trades halo re-reads against grid size).  The kernel is VALU-bound,
+// not HBM-bound: separately rounded multiplies and adds (no FMA: the
+// reference's arithmetic is unfused) cost ~31 lane-ops per source pixel in the
+// vertical chain alone -- see DESIGN.md "scale kernel roofline".
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,12 +35,13 @@ namespace timg_amd {
 
 namespace {
 
-constexpr int kPix       = 2;    // source columns per lane
+constexpr int kPix       = 4;    // source columns per lane (16-byte loads)
 constexpr int kSlots     = 5;    // output rows in flight per lane
 constexpr int kThreads   = 256;
 constexpr int kStripCols = kPix * kThreads;
-constexpr int kStage     = 2;    // output rows that may complete on one source row
-constexpr int kLdsCoeffs = 32;   // horizontal weights kept in LDS up to this tap count
+constexpr int kStage     = 2;    // staging rows (and: rows that may complete on one source row)
+constexpr int kPrefetch  = 4;    // source rows in flight per lane
+constexpr int kLdsCoeffFloats = 12 * 1024;  // horizontal weights kept in LDS up to this many
 
 struct StripInfo {
     int ox0, ox1;  // output columns [ox0, ox1)
@@ -58,7 +64,7 @@ struct RowSched {
     float weight[kSlots];
     int flags[kSlots];
     float alpha_sum[kSlots];
-    int pad;
+    int any_last;  // some slot completes on this row
 };
 static_assert(sizeof(RowSched) == 64, "RowSched must stay one cache line");
 
@@ -68,6 +74,23 @@ struct StreamTables {
     const RowSched *sched;
     int n_strips, n_bands;
 };
+
+// The schedule tables are written by the host before the launch and never by a
+// kernel: reading them through the constant address space lets the compiler use
+// scalar loads (s_load_dwordx16 for a RowSched), which neither occupy the vector
+// memory queue nor force the pixel prefetches to drain (vmcnt is in-order).
+#define TIMG_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ T LoadConstant(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "word-sized tables only");
+    const TIMG_CONST_AS uint32_t *w = (const TIMG_CONST_AS uint32_t *)(uintptr_t)p;
+    uint32_t tmp[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) tmp[i] = w[i];
+    T out;
+    __builtin_memcpy(&out, tmp, sizeof(T));
+    return out;
+}
 
 // Channel sets.  stb filters 7 floats per pixel (R G B A RA GA BA); which of
 // them a tile really needs depends on its data:
@@ -86,16 +109,13 @@ template <> struct ModeTraits<kPremult> { static constexpr int kCh = 4, kStride 
 template <> struct ModeTraits<kFull>    { static constexpr int kCh = 7, kStride = 8; };
 
 template <int M>
-__device__ __forceinline__ void DecodeMode(uint32_t px, int swap_rb, float out[ModeTraits<M>::kCh]) {
+__device__ __forceinline__ void DecodeMode(uint32_t px, float out[ModeTraits<M>::kCh]) {
+    // (a b,g,r,a source is filtered as if it were r,g,b,a -- the three colour
+    // channels go through identical arithmetic -- and swapped back on output)
     const float k = 1.0f / 255.0f;
-    float r       = (float)(px & 0xffu) * k;
+    const float r = (float)(px & 0xffu) * k;
     const float g = (float)((px >> 8) & 0xffu) * k;
-    float b       = (float)((px >> 16) & 0xffu) * k;
-    if (swap_rb) {
-        const float t = r;
-        r             = b;
-        b             = t;
-    }
+    const float b = (float)((px >> 16) & 0xffu) * k;
     if (M == kOpaque) {
         out[0] = r;
         out[1] = g;
@@ -119,14 +139,17 @@ __device__ __forceinline__ void DecodeMode(uint32_t px, int swap_rb, float out[M
     }
 }
 
-__device__ __forceinline__ uint32_t FinishStreamPixel(const Px7 &acc, int x, int y,
+__device__ __forceinline__ uint32_t FinishStreamPixel(const Px7 &acc, int x, int y, int swap_rb,
                                                       const DevBlend &blend, int *flag) {
     uint32_t out = EncodePx(acc);
+    if (swap_rb) out = (out & 0xff00ff00u) | ((out & 0xffu) << 16) | ((out >> 16) & 0xffu);
     if ((out >> 24) != 0xffu && y >= blend.start_row) {
         if (flag) *flag = 1;
         if (blend.enabled) {
             const bool alt = blend.checker && (((x / blend.pw) + (y / blend.ph)) & 1);
-            out            = BlendOver(out, alt ? blend.pat : blend.bg);
+            const float bg[3] = {alt ? blend.pat[0] : blend.bg[0], alt ? blend.pat[1] : blend.bg[1],
+                                 alt ? blend.pat[2] : blend.bg[2]};
+            out = BlendOver(out, bg);
         }
     }
     return out;
@@ -140,12 +163,102 @@ struct TileCtx {
     BandInfo bi;
     const RowSched *sched;
     int f;
-    float *stage;    // kStage * kStripCols * 8 floats
-    float *hcoef;    // h_width * hrow floats (k-major), valid if lds_coeffs
+    float *stage;    // kStage * kStripCols * kStride floats
+    float *hcoef;    // h_width * hrow floats (k-major)
+    int2 *htaps;     // hrow entries {first tap - cx0, tap count}
     int hrow;        // outputs per strip rounded up (row length of hcoef)
     int *fail;       // LDS flag
-    bool lds_coeffs;
 };
+
+// Horizontal pass of one completed output row y over the strip's outputs:
+// stb's gather with an even and an odd accumulation chain (or one chain for
+// <= 3 taps), stb_image_resize2.h:5801-6009.  The staged row holds kHc floats
+// per source column: kOpaque R G B + the (column-independent) vertical alpha
+// sum, kPremult A RA GA BA, kFull all seven.
+template <int M>
+__device__ __forceinline__ void HorizontalRow(const TileCtx &c, const float *stage_row, int y,
+                                              int *flag, bool *ok) {
+    constexpr int kStride = ModeTraits<M>::kStride;
+    constexpr int kHc     = M == kFull ? 7 : 4;
+    const DevPlan &plan     = *c.plan;
+    const FrameBatch &batch = *c.batch;
+    const int n_out         = c.si.ox1 - c.si.ox0;
+    uint8_t *dst_row = batch.dst + (size_t)c.f * batch.dst_frame_stride + (size_t)y * batch.dst_stride;
+    for (int o = threadIdx.x; o < n_out; o += kThreads) {
+        const int ox      = c.si.ox0 + o;
+        const int2 ht     = c.htaps[o];
+        const float *base = stage_row + (size_t)ht.x * kStride;
+        const float *hw   = c.hcoef + o;  // weights of this column, hrow floats apart
+        float even[kHc], odd[kHc];
+#pragma unroll
+        for (int ch = 0; ch < kHc; ++ch) even[ch] = odd[ch] = 0.0f;
+        auto tap = [&](int k, float v[kHc]) {
+            const float4 t0 = *reinterpret_cast<const float4 *>(base + k * kStride);
+            v[0] = t0.x;
+            v[1] = t0.y;
+            v[2] = t0.z;
+            v[3] = t0.w;
+            if (kHc > 4) {
+                const float4 t1 = *reinterpret_cast<const float4 *>(base + k * kStride + 4);
+                v[kHc > 4 ? 4 : 0] = t1.x;
+                v[kHc > 5 ? 5 : 0] = t1.y;
+                v[kHc > 6 ? 6 : 0] = t1.z;
+            }
+        };
+        float v[kHc], v1[kHc];
+        if (plan.h_sequential) {
+            for (int k = 0; k < ht.y; ++k) {
+                const float w = hw[k * c.hrow];
+                tap(k, v);
+#pragma unroll
+                for (int ch = 0; ch < kHc; ++ch) even[ch] = even[ch] + v[ch] * w;  // 0 + x == x
+            }
+        } else {
+            int k = 0;
+            for (; k + 1 < ht.y; k += 2) {
+                const float w0 = hw[k * c.hrow], w1 = hw[(k + 1) * c.hrow];
+                tap(k, v);
+                tap(k + 1, v1);
+#pragma unroll
+                for (int ch = 0; ch < kHc; ++ch) {
+                    even[ch] = even[ch] + v[ch] * w0;
+                    odd[ch]  = odd[ch] + v1[ch] * w1;
+                }
+            }
+            if (k < ht.y) {
+                const float w = hw[k * c.hrow];
+                tap(k, v);
+#pragma unroll
+                for (int ch = 0; ch < kHc; ++ch) even[ch] = even[ch] + v[ch] * w;
+            }
+#pragma unroll
+            for (int ch = 0; ch < kHc; ++ch) even[ch] = even[ch] + odd[ch];
+        }
+        Px7 px;
+        if (M == kOpaque) {
+            // with alpha == 1 the straight and the weighted sums coincide
+            px.c[0] = even[0];
+            px.c[1] = even[1];
+            px.c[2] = even[2];
+            px.c[3] = even[3];
+            px.c[4] = even[0];
+            px.c[5] = even[1];
+            px.c[6] = even[2];
+        } else if (M == kPremult) {
+            px.c[0] = px.c[1] = px.c[2] = 0.0f;
+            px.c[3] = even[0];
+            px.c[4] = even[1];
+            px.c[5] = even[2];
+            px.c[6] = even[3];
+            if (px.c[3] < TIMG_TINY_F32) *ok = false;  // needs the straight RGB sums
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 7; ++ch) px.c[ch] = even[ch < kHc ? ch : 0];
+        }
+        const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, *c.blend, flag);
+        *reinterpret_cast<uint32_t *>(dst_row + (size_t)ox * 4) = out;
+    }
+}
 
 // Runs one tile with channel set M.  Returns false (uniformly) when M's
 // assumption did not hold; the caller then retries with the next set.
@@ -156,29 +269,17 @@ __device__ bool RunTile(const TileCtx &c) {
     const FrameBatch &batch = *c.batch;
     const int tid           = threadIdx.x;
     const int col0          = c.si.cx0 + tid * kPix;
-    const bool in0 = col0 < plan.in_w, in1 = col0 + 1 < plan.in_w;
-    const uint8_t *src = batch.src + (size_t)c.f * batch.src_frame_stride + (size_t)col0 * 4;
-    int *flag          = batch.transparent_flags ? batch.transparent_flags + c.f : nullptr;
+    // in_w is a multiple of kPix (PrepareStreamSchedule): a lane is either fully
+    // inside the row or fully past its end; the latter re-read the last pixels
+    // (never consumed: no tap reaches past in_w) so that loads need no predicate
+    const uint32_t lane_off = (uint32_t)min(col0, plan.in_w - kPix) * 4u;
+    const uint8_t *frame    = batch.src + (size_t)c.f * batch.src_frame_stride;
+    int *flag               = batch.transparent_flags ? batch.transparent_flags + c.f : nullptr;
+    const int r1            = c.bi.r1;
 
-    const int ox      = c.si.ox0 + tid;
-    const bool has_ox = ox < c.si.ox1;
-    int2 ht           = make_int2(c.si.cx0, 1);
-    const float *hc   = plan.h_coeff;
-    if (has_ox) {
-        ht = plan.h_taps[ox];
-        hc = plan.h_coeff + (size_t)ox * plan.h_width;
-    }
-
-    auto load_row = [&](int r) -> uint2 {
-        // lanes past the right edge read nothing and count as opaque
-        uint2 v = make_uint2(0xff000000u, 0xff000000u);
-        if (r > c.bi.r1) return v;
-        const uint8_t *p = src + (size_t)r * batch.src_stride;
-        if (in1)
-            v = *reinterpret_cast<const uint2 *>(p);
-        else if (in0)
-            v.x = *reinterpret_cast<const uint32_t *>(p);
-        return v;
+    auto load_row = [&](int r) -> uint4 {
+        const uint8_t *row = frame + (size_t)min(r, r1) * batch.src_stride;  // uniform
+        return *reinterpret_cast<const uint4 *>(row + lane_off);
     };
 
     float acc[kSlots][kPix][kCh];
@@ -189,48 +290,39 @@ __device__ bool RunTile(const TileCtx &c) {
 #pragma unroll
             for (int ch = 0; ch < kCh; ++ch) acc[s][p][ch] = 0.0f;
 
-    bool ok   = true;  // this lane has seen nothing that breaks M's assumption
-    uint2 cur = load_row(c.bi.r0), nx1 = load_row(c.bi.r0 + 1);
-    for (int r = c.bi.r0; r <= c.bi.r1; ++r) {
-        const uint2 nx2   = load_row(r + 2);
-        const RowSched rs = c.sched[r - c.bi.r0];
-        if (M == kOpaque) ok = ok && ((cur.x & cur.y) >> 24) == 0xffu;
-        float d0[kCh], d1[kCh];
-        DecodeMode<M>(cur.x, plan.swap_rb, d0);
-        DecodeMode<M>(cur.y, plan.swap_rb, d1);
+    bool ok = true;  // this lane has seen nothing that breaks M's assumption
+    int ev  = 0;     // completed rows so far: picks the staging row
+
+    // One source row: decode, feed the active slots, and -- when an output row
+    // completes -- stage it and run the horizontal pass.  Returns false when the
+    // tile has to be redone with a richer channel set (block-uniform).
+    auto row_step = [&](const uint4 &q, int r) __attribute__((always_inline)) -> bool {
+        const RowSched rs = LoadConstant(c.sched + (r - c.bi.r0));
+        if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
+        float d[kPix][kCh];
+        DecodeMode<M>(q.x, d[0]);
+        DecodeMode<M>(q.y, d[1]);
+        DecodeMode<M>(q.z, d[2]);
+        DecodeMode<M>(q.w, d[3]);
 
         int n_done = 0;
-        int done_y0 = 0, done_y1 = 0;
-        float done_a0 = 0.0f, done_a1 = 0.0f;
-        bool completing = false;
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s) completing = completing || (rs.flags[s] & 4);
-        if (completing) {
-            // the previous horizontal pass must be done with the staging rows
-            if (__any(!ok) && (tid & 63) == 0) *c.fail = 1;
-            __syncthreads();
-            if (*c.fail) return false;
-        }
+        int done_y[kStage] = {0, 0};
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
             const int fl = rs.flags[s];
             if (!(fl & 1)) continue;  // wave-uniform
             const float w = rs.weight[s];
-            if (fl & 2) {
+            // (a slot is zero when its row starts: 0 + x == x, so the first
+            // contribution needs no special case)
 #pragma unroll
-                for (int ch = 0; ch < kCh; ++ch) {
-                    acc[s][0][ch] = d0[ch] * w;
-                    acc[s][1][ch] = d1[ch] * w;
-                }
-            } else {
+            for (int p = 0; p < kPix; ++p)
 #pragma unroll
-                for (int ch = 0; ch < kCh; ++ch) {
-                    acc[s][0][ch] = acc[s][0][ch] + d0[ch] * w;
-                    acc[s][1][ch] = acc[s][1][ch] + d1[ch] * w;
-                }
-            }
+                for (int ch = 0; ch < kCh; ++ch) acc[s][p][ch] = acc[s][p][ch] + d[p][ch] * w;
             if (fl & 4) {
-                float *row = c.stage + (size_t)n_done * kStripCols * kStride;
+                // a second row completing on this source row takes the staging row the
+                // PREVIOUS completion used: wait until every wave is done reading it
+                if (n_done) __syncthreads();
+                float *row = c.stage + (size_t)((ev + n_done) & (kStage - 1)) * kStripCols * kStride;
 #pragma unroll
                 for (int p = 0; p < kPix; ++p) {
                     float *dst = row + (size_t)(tid * kPix + p) * kStride;
@@ -239,7 +331,7 @@ __device__ bool RunTile(const TileCtx &c) {
                         v.x = acc[s][p][0];
                         v.y = acc[s][p][1];
                         v.z = acc[s][p][2];
-                        v.w = kCh > 3 ? acc[s][p][kCh > 3 ? 3 : 0] : 0.0f;
+                        v.w = kCh > 3 ? acc[s][p][kCh > 3 ? 3 : 0] : rs.alpha_sum[s];
                         *reinterpret_cast<float4 *>(dst) = v;
                     } else {
                         float4 v0, v1;
@@ -255,127 +347,45 @@ __device__ bool RunTile(const TileCtx &c) {
                         *reinterpret_cast<float4 *>(dst + 4) = v1;
                     }
                 }
-                if (n_done == 0) {
-                    done_y0 = fl >> 8;
-                    done_a0 = rs.alpha_sum[s];
-                } else {
-                    done_y1 = fl >> 8;
-                    done_a1 = rs.alpha_sum[s];
-                }
+#pragma unroll
+                for (int p = 0; p < kPix; ++p)
+#pragma unroll
+                    for (int ch = 0; ch < kCh; ++ch) acc[s][p][ch] = 0.0f;
+                done_y[n_done & 1] = fl >> 8;
                 ++n_done;
             }
         }
-        if (n_done) {
+        if (n_done) {  // wave- and block-uniform
+            if (M != kFull && __any(!ok) && (tid & 63) == 0) *c.fail = 1;
             __syncthreads();
-            for (int j = 0; j < n_done; ++j) {
-                const int y = j == 0 ? done_y0 : done_y1;
-                if (has_ox) {
-                    const float *base = c.stage + (size_t)j * kStripCols * kStride +
-                                        (size_t)(ht.x - c.si.cx0) * kStride;
-                    float even[kCh], odd[kCh];
-                    float a_even = 0.0f, a_odd = 0.0f;  // kOpaque: alpha chain
-                    const float av = j == 0 ? done_a0 : done_a1;
-#pragma unroll
-                    for (int ch = 0; ch < kCh; ++ch) even[ch] = odd[ch] = 0.0f;
-                    auto tap = [&](int k, float v[kCh]) {
-                        if (kStride == 4) {
-                            const float4 t = *reinterpret_cast<const float4 *>(base + k * 4);
-                            v[0] = t.x;
-                            v[1] = t.y;
-                            v[2] = t.z;
-                            if (kCh > 3) v[kCh > 3 ? 3 : 0] = t.w;
-                        } else {
-                            const float4 t0 = *reinterpret_cast<const float4 *>(base + k * 8);
-                            const float4 t1 = *reinterpret_cast<const float4 *>(base + k * 8 + 4);
-                            v[0] = t0.x;
-                            v[1] = t0.y;
-                            v[2] = t0.z;
-                            v[kCh > 3 ? 3 : 0] = t0.w;
-                            v[kCh > 4 ? 4 : 0] = t1.x;
-                            v[kCh > 5 ? 5 : 0] = t1.y;
-                            v[kCh > 6 ? 6 : 0] = t1.z;
-                        }
-                    };
-                    auto weight = [&](int k) -> float {
-                        return c.lds_coeffs ? c.hcoef[k * c.hrow + tid] : hc[k];
-                    };
-                    float v[kCh];
-                    if (plan.h_sequential) {
-                        for (int k = 0; k < ht.y; ++k) {
-                            const float hw = weight(k);
-                            tap(k, v);
-                            if (k == 0) {
-#pragma unroll
-                                for (int ch = 0; ch < kCh; ++ch) even[ch] = v[ch] * hw;
-                                a_even = av * hw;
-                            } else {
-#pragma unroll
-                                for (int ch = 0; ch < kCh; ++ch) even[ch] = even[ch] + v[ch] * hw;
-                                a_even = a_even + av * hw;
-                            }
-                        }
-                    } else {
-                        {
-                            const float hw = weight(0);
-                            tap(0, v);
-#pragma unroll
-                            for (int ch = 0; ch < kCh; ++ch) even[ch] = v[ch] * hw;
-                            a_even = av * hw;
-                        }
-                        if (ht.y > 1) {
-                            const float hw = weight(1);
-                            tap(1, v);
-#pragma unroll
-                            for (int ch = 0; ch < kCh; ++ch) odd[ch] = v[ch] * hw;
-                            a_odd = av * hw;
-                        }
-                        for (int k = 2; k < ht.y; ++k) {
-                            const float hw = weight(k);
-                            tap(k, v);
-                            if (k & 1) {
-#pragma unroll
-                                for (int ch = 0; ch < kCh; ++ch) odd[ch] = odd[ch] + v[ch] * hw;
-                                a_odd = a_odd + av * hw;
-                            } else {
-#pragma unroll
-                                for (int ch = 0; ch < kCh; ++ch) even[ch] = even[ch] + v[ch] * hw;
-                                a_even = a_even + av * hw;
-                            }
-                        }
-#pragma unroll
-                        for (int ch = 0; ch < kCh; ++ch) even[ch] = even[ch] + odd[ch];
-                        a_even = a_even + a_odd;
-                    }
-                    Px7 px;
-                    if (M == kOpaque) {
-                        px.c[0] = px.c[1] = px.c[2] = 0.0f;
-                        px.c[3] = a_even;
-                        px.c[4] = even[0];
-                        px.c[5] = even[1];
-                        px.c[6] = even[2];
-                        // with alpha == 1 the straight and the weighted sums coincide
-                        px.c[0] = even[0];
-                        px.c[1] = even[1];
-                        px.c[2] = even[2];
-                    } else if (M == kPremult) {
-                        px.c[0] = px.c[1] = px.c[2] = 0.0f;
-                        px.c[3] = even[0];
-                        px.c[4] = even[1];
-                        px.c[5] = even[2];
-                        px.c[6] = even[kCh > 3 ? 3 : 0];
-                        if (px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
-                    } else {
-#pragma unroll
-                        for (int ch = 0; ch < 7; ++ch) px.c[ch] = even[ch < kCh ? ch : 0];
-                    }
-                    const uint32_t out = FinishStreamPixel(px, ox, y, *c.blend, flag);
-                    *reinterpret_cast<uint32_t *>(batch.dst + (size_t)c.f * batch.dst_frame_stride +
-                                                  (size_t)y * batch.dst_stride + (size_t)ox * 4) = out;
-                }
-            }
+            if (M != kFull && *c.fail) return false;
+            for (int j = 0; j < n_done; ++j)
+                HorizontalRow<M>(c, c.stage + (size_t)((ev + j) & (kStage - 1)) * kStripCols * kStride,
+                                 j ? done_y[1] : done_y[0], flag, &ok);
+            if (n_done > 1) __syncthreads();  // both staging rows were in use
+            ev += n_done;
         }
-        cur = nx1;
-        nx1 = nx2;
+        return true;
+    };
+
+    // kPrefetch = 4 source rows in flight per lane; the ring is unrolled so that
+    // "rotating" it is register naming, not moves (a move would have to wait for
+    // its load and collapse the prefetch distance to one row)
+    static_assert(kPrefetch == 4, "the register ring below is written out for 4 rows");
+    uint4 q0 = load_row(c.bi.r0), q1 = load_row(c.bi.r0 + 1), q2 = load_row(c.bi.r0 + 2),
+          q3 = load_row(c.bi.r0 + 3);
+    for (int r = c.bi.r0; r <= r1; r += kPrefetch) {
+        if (!row_step(q0, r)) return false;
+        q0 = load_row(r + 4);
+        if (r + 1 > r1) break;
+        if (!row_step(q1, r + 1)) return false;
+        q1 = load_row(r + 5);
+        if (r + 2 > r1) break;
+        if (!row_step(q2, r + 2)) return false;
+        q2 = load_row(r + 6);
+        if (r + 3 > r1) break;
+        if (!row_step(q3, r + 3)) return false;
+        q3 = load_row(r + 7);
     }
     if (M == kFull) return true;
     if (__any(!ok) && (tid & 63) == 0) *c.fail = 1;
@@ -388,7 +398,7 @@ __device__ bool RunTile(const TileCtx &c) {
 // 0 = not produced yet, 1 = done.  A kernel skips tiles that are done and marks
 // the ones it completes.
 template <int M>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, M == kFull ? 2 : 3)
 ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch,
                   int *tile_state, int hrow) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -399,20 +409,26 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
     c.plan       = &plan;
     c.blend      = &blend;
     c.batch      = &batch;
-    c.si         = tab.strips[blockIdx.x];
-    c.bi         = tab.bands[blockIdx.y];
+    c.si         = LoadConstant(tab.strips + blockIdx.x);
+    c.bi         = LoadConstant(tab.bands + blockIdx.y);
     c.sched      = tab.sched + c.bi.sched;
     c.f          = blockIdx.z;
     c.stage      = lds;
-    c.hcoef      = lds + kStage * kStripCols * ModeTraits<M>::kStride;
+    c.htaps      = reinterpret_cast<int2 *>(lds + kStage * kStripCols * ModeTraits<M>::kStride);
+    c.hcoef      = reinterpret_cast<float *>(c.htaps + hrow);
     c.hrow       = hrow;
     c.fail       = &fail;
-    c.lds_coeffs = plan.h_width <= kLdsCoeffs;
-    if (c.lds_coeffs && (int)threadIdx.x < hrow) {
-        const int ox    = c.si.ox0 + threadIdx.x;
+    for (int o = threadIdx.x; o < hrow; o += kThreads) {
+        const int ox  = c.si.ox0 + o;
+        const bool in = ox < c.si.ox1;
+        int2 ht       = make_int2(0, 1);
+        if (in) {
+            ht = plan.h_taps[ox];
+            ht.x -= c.si.cx0;
+        }
+        c.htaps[o]      = ht;
         const float *hc = plan.h_coeff + (size_t)ox * plan.h_width;
-        for (int k = 0; k < plan.h_width; ++k)
-            c.hcoef[k * hrow + threadIdx.x] = ox < c.si.ox1 ? hc[k] : 0.0f;
+        for (int k = 0; k < plan.h_width; ++k) c.hcoef[k * hrow + o] = in ? hc[k] : 0.0f;
     }
     if (threadIdx.x == 0) fail = 0;
     __syncthreads();
@@ -505,7 +521,7 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     if (p.identity) return no("identity plan");
     if (!p.vertical_first) return no("horizontal-first plan");
     if (p.max_active_rows > kSlots) return no("too many output rows per source row");
-    if (p.in_w & 1) return no("odd source width");
+    if (p.in_w % kPix) return no("source width is not a multiple of 4");
     // slot = y % kSlots must be free again when row y + kSlots starts
     std::vector<int> first(p.out_h), last(p.out_h);
     for (int y = 0; y < p.out_h; ++y) {
@@ -531,7 +547,10 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
         si.cx0  = p.h_taps[ox].n0 & ~(kPix - 1);
         si.pad  = 0;
         int end = ox;
-        while (end < p.out_w && end - ox < kThreads) {
+        // (LDS keeps {taps, weights} per output column: bound the strip's outputs too)
+        const int max_out = kLdsCoeffFloats / std::max(1, p.h_width);
+        if (max_out < 1) return no("horizontal filter too wide for the LDS weight table");
+        while (end < p.out_w && end - ox < max_out) {
             const HTaps &t = p.h_taps[end];
             if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kStripCols) break;
             ++end;
@@ -543,7 +562,9 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     }
     StreamSchedule *ss = new StreamSchedule();
     for (const StripInfo &si : strips) ss->hrow = std::max(ss->hrow, si.ox1 - si.ox0);
-    const int tall     = std::max(1, std::min(p.out_h, 45));
+    int tall = 45;
+    if (const char *e = getenv("TIMG_HIP_BAND_ROWS")) tall = atoi(e) > 0 ? atoi(e) : tall;  // tuning
+    tall = std::max(1, std::min(p.out_h, tall));
     int fine           = tall;
     while (fine > 6 && (size_t)strips.size() * ((p.out_h + fine - 1) / fine) < 512)
         fine = std::max(6, fine / 2);
@@ -575,9 +596,8 @@ template <int M>
 static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
                              const StreamVariant &v, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream) {
-    const bool lds_coeffs = s->plan.h_width <= kLdsCoeffs;
-    const size_t lds = ((size_t)kStage * kStripCols * ModeTraits<M>::kStride +
-                        (lds_coeffs ? (size_t)s->plan.h_width * ss->hrow : 0)) * sizeof(float);
+    const size_t lds = ((size_t)kStage * kStripCols * ModeTraits<M>::kStride + 2 * (size_t)ss->hrow +
+                        (size_t)s->plan.h_width * ss->hrow) * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamKernel<M>,
@@ -595,8 +615,8 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
     if (!ss) return hipErrorNotSupported;
-    // 8-byte loads need 8-byte aligned rows; otherwise the generic kernel runs
-    if (((uintptr_t)batch.src & 7) || (batch.src_stride & 7) || (batch.src_frame_stride & 7))
+    // 16-byte loads need 16-byte aligned rows; otherwise the generic kernel runs
+    if (((uintptr_t)batch.src & 15) || (batch.src_stride & 15) || (batch.src_frame_stride & 15))
         return LaunchScaleGeneric(s->dev, blend, batch, stream);
     const StreamVariant &tall = ss->v[0];
     const bool enough = (size_t)tall.t.n_strips * tall.t.n_bands * batch.n_frames >= 512;

@@ -1,0 +1,82 @@
+// Microbenchmark: VALU issue rate of plain vs packed fp32 mul/add on gfx950.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ void __launch_bounds__(256) Rate(float *out, float w0, float w1, int iters) {
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {  // plain: 16 mul + 16 add, separately rounded
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float t;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(w0));
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(t), "v"(w1));
+            }
+        } else if (MODE == 1) {  // packed: 8 pk_mul + 8 pk_add  (same 32 lane-ops)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                float2v v = {a[i], a[i + 1]}, t, ww0 = {w0, w0}, ww1 = {w1, w1};
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(ww0));
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(v) : "v"(t), "v"(ww1));
+                a[i] = v.x; a[i + 1] = v.y;
+            }
+        } else if (MODE == 2) {  // fma: 16 v_fma
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(w0), "v"(w1));
+        } else if (MODE == 3) {  // cvt ubyte
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                unsigned u = __float_as_uint(a[i]);
+                asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u));
+            }
+        } else if (MODE == 4) {  // pk_fma
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                float2v v = {a[i], a[i + 1]}, ww0 = {w0, w0}, ww1 = {w1, w1};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(v), "v"(ww0), "v"(ww1));
+                a[i] = v.x; a[i + 1] = v.y;
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+void Run(const char *name, int instr_per_iter, int laneops_per_iter) {
+    float *out;
+    const int blocks = 256 * 8, iters = 20000;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    Rate<MODE><<<blocks, 256>>>(out, 1.0001f, 0.5f, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    Rate<MODE><<<blocks, 256>>>(out, 1.0001f, 0.5f, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double waves = blocks * 4.0;
+    const double instr = waves * iters * instr_per_iter;
+    const double simd_cycles = ms * 1e-3 * 2.4e9;  // nominal clock
+    printf("%-10s %.3f ms: %.2f cycles/wave-instr/SIMD (at 2.4 GHz), %.1f lane-ops/clk/CU\n", name, ms,
+           simd_cycles / (instr / 1024.0), waves * iters * laneops_per_iter * 64.0 / (simd_cycles * 256.0));
+    hipFree(out);
+}
+
+int main() {
+    Run<0>("plain", 32, 32);
+    Run<1>("packed", 16, 32);
+    Run<2>("fma", 16, 16);
+    Run<3>("cvt_ubyte", 16, 16);
+    Run<4>("pk_fma", 8, 16);
+    return 0;
+}

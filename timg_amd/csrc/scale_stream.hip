@@ -215,6 +215,7 @@ __device__ __forceinline__ void HorizontalRow(const TileCtx &c, const float *sta
             }
         } else {
             int k = 0;
+#pragma unroll 2
             for (; k + 1 < ht.y; k += 2) {
                 const float w0 = hw[k * c.hrow], w1 = hw[(k + 1) * c.hrow];
                 tap(k, v);
@@ -296,9 +297,20 @@ __device__ bool RunTile(const TileCtx &c) {
     // One source row: decode, feed the active slots, and -- when an output row
     // completes -- stage it and run the horizontal pass.  Returns false when the
     // tile has to be redone with a richer channel set (block-uniform).
+    // The schedule entry of row r+1 is requested while row r is processed (the
+    // table carries one blank entry past the last band): a scalar load issued and
+    // consumed in the same step would expose the scalar-cache latency every row.
+    RowSched rs_next = LoadConstant(c.sched);
     auto row_step = [&](const uint4 &q, int r) __attribute__((always_inline)) -> bool {
-        const RowSched rs = LoadConstant(c.sched + (r - c.bi.r0));
+        const RowSched rs = rs_next;
+        asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));  // rs is complete here ...
+        __builtin_amdgcn_sched_barrier(0);
+        rs_next = LoadConstant(c.sched + (r + 1 - c.bi.r0));  // ... before the next request goes out
         if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
+        // Fully transparent pixels announce filtered alphas of (or below) zero, which
+        // need the straight RGB sums: give the tile to the full channel set right away
+        // instead of discovering it output pixel by output pixel.
+        if (M == kPremult) ok = ok && min(min(q.x, q.y), min(q.z, q.w)) >= 0x01000000u;
         float d[kPix][kCh];
         DecodeMode<M>(q.x, d[0]);
         DecodeMode<M>(q.y, d[1]);
@@ -486,6 +498,11 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
             }
         }
         bands.push_back(b);
+    }
+    {
+        RowSched blank;  // row_step reads one entry ahead
+        memset(&blank, 0, sizeof(blank));
+        sched.push_back(blank);
     }
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_strips = 0;

@@ -1,0 +1,80 @@
+"""The N>1 path on CPU: world_size-2 (and 3) `gloo` runs of the only exchange
+step the hot path has -- the ordered gather of variable-length escape-sequence
+buffers to rank 0 (timg_amd/gather.py; `nccl` = RCCL on the GPUs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from timg_amd.gather import gather_frames_to_root, shard_frames
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _frame(rank, i):
+    rng = np.random.default_rng(1000 * rank + i)
+    n = int(rng.integers(0, 5000)) if i % 4 else 0  # zero-length frames occur (identical animation frames)
+    return rng.integers(0, 256, n, dtype=np.uint8)
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = [_frame(rank, i) for i in range(n_frames)]
+        lens = torch.tensor([len(f) for f in frames], dtype=torch.int64)
+        payload = torch.from_numpy(np.concatenate(frames + [np.zeros(64, np.uint8)]))  # slack behind the data
+        got = gather_frames_to_root(payload, lens)
+        if rank == 0:
+            ok = got is not None and len(got) == world
+            for r in range(world):
+                for i in range(n_frames):
+                    ok = ok and np.array_equal(got[r][i].numpy(), _frame(r, i))
+            q.put(bool(ok))
+        else:
+            assert got is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (3, 5), (2, 1)])
+def test_gather_to_root_in_rank_and_frame_order(world, n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() is True
+
+
+def test_single_process_gather_is_identity():
+    payload = torch.arange(10, dtype=torch.uint8)
+    out = gather_frames_to_root(payload, torch.tensor([3, 0, 7]))
+    assert [t.tolist() for t in out[0]] == [[0, 1, 2], [], [3, 4, 5, 6, 7, 8, 9]]
+
+
+def test_shard_frames_partitions_exactly():
+    for n in (1, 7, 64, 600):
+        for world in (1, 2, 3, 8):
+            for rr in (False, True):
+                owned = [shard_frames(n, world, r, rr) for r in range(world)]
+                flat = sorted(i for o in owned for i in o)
+                assert flat == list(range(n))
+                if rr:
+                    assert all(o == list(range(r, n, world)) for r, o in enumerate(owned))
+                else:
+                    assert all(o == sorted(o) and (not o or o[-1] - o[0] == len(o) - 1) for o in owned)

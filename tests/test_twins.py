@@ -1,0 +1,43 @@
+"""The C++ twins (timg_amd/twins) against the reference's own classes.
+
+build/twin_check links hzeller/timg's ImageScaler / Framebuffer /
+UnicodeBlockCanvas / BufferedWriteSequencer (compiled from /root/reference in
+this container by timg_amd/twins/Makefile) next to HipImageScaler,
+HipUnicodeBlockCanvas and HipSixelCanvas and drives both through the calls the
+renderer makes.  The binary travels to the GPU box with the snapshot."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "timg_amd", "twins", "build", "twin_check")
+
+
+def test_twin_sources_bind_only_the_c_abi():
+    """The twins talk to the device through include/timg_hip.h alone."""
+    tw = os.path.join(ROOT, "timg_amd", "twins")
+    for f in os.listdir(tw):
+        if f.endswith((".cc", ".h")) and f.startswith("hip-"):
+            body = open(os.path.join(tw, f)).read()
+            assert "hip/hip_runtime" not in body and "oracle" not in body, f
+            assert "CpuFallback" not in body, f
+
+
+@pytest.mark.gpu
+def test_twins_match_reference_classes(oracle, tmp_path):
+    if not os.path.exists(BIN):
+        pytest.skip("timg_amd/twins/build/twin_check not built (needs /root/reference at build time)")
+    dump = tmp_path / "sixel.bin"
+    r = subprocess.run([BIN, "all", str(dump)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all twins match" in r.stdout
+    # the sixel twin's stream: two frames, each decodable to a 200x114 raster
+    data = dump.read_bytes()
+    frames = [b"\x1bP" + part.split(b"\x1b\\")[0] + b"\x1b\\" for part in data.split(b"\x1bP")[1:]]
+    assert len(frames) == 2
+    for fr in frames:
+        img, ncolors = oracle.sixel_decode(fr)
+        assert img.shape[:2] == (114, 200) and 2 <= ncolors <= 256
+        assert (img[..., 3] == 255).all()  # every pixel drawn (pad rows blended, not transparent)

@@ -29,8 +29,10 @@ def gather_frames_to_root(payload: torch.Tensor, lengths: torch.Tensor, root: in
     if world == 1:
         offs = torch.cumsum(lengths, 0) - lengths
         return [[payload[int(o):int(o) + int(n)] for o, n in zip(offs.tolist(), lengths.tolist())]]
-    all_len = torch.empty((world, lengths.numel()), dtype=torch.int64, device=lengths.device)
+    # (flat output: gloo's allgather_base insists on it, RCCL accepts either)
+    all_len = torch.empty(world * lengths.numel(), dtype=torch.int64, device=lengths.device)
     dist.all_gather_into_tensor(all_len, lengths.contiguous())
+    all_len = all_len.view(world, lengths.numel())
     totals = all_len.sum(1).tolist()
     if rank != root:
         dist.send(payload[:int(totals[rank])].contiguous(), dst=root)

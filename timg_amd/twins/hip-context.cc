@@ -1,5 +1,6 @@
 #include "hip-context.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -19,6 +20,11 @@ timg_hip_ctx *SharedHipContext() {
         if (timg_hip_init(d ? atoi(d) : 0, &ctx) != TIMG_HIP_OK) ctx = nullptr;
     });
     return ctx;
+}
+
+void HipFatal(timg_hip_ctx *ctx, const char *what) {
+    fprintf(stderr, "timg: HIP back-end failed in %s: %s\n", what, timg_hip_last_error(ctx));
+    abort();
 }
 
 }  // namespace timg

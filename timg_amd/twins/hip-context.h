@@ -19,5 +19,11 @@ timg_hip_ctx *SharedHipContext();
 // GPU selection: TIMG_HIP_DEVICE=<n> (default 0), TIMG_HIP=0 disables.
 bool HipTwinsEnabled();
 
+// A device call failed after the GPU back-end had been selected: print
+// timg_hip_last_error() and terminate.  The twins never substitute CPU results
+// for a failed device call -- nothing in Scale()/Send() can fail in the
+// reference either, so there is no error path to return through.
+[[noreturn]] void HipFatal(timg_hip_ctx *ctx, const char *what);
+
 }  // namespace timg
 #endif

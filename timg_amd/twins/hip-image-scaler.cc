@@ -28,20 +28,13 @@ std::unique_ptr<ImageScaler> HipImageScaler::Create(int in_width, int in_height,
 
 HipImageScaler::~HipImageScaler() { timg_hip_scaler_destroy(scaler_); }
 
-void HipImageScaler::CpuFallback(Framebuffer &in, Framebuffer *out) {
-    // Nothing in Scale() can fail in the reference; on a device error hand the
-    // frame to whatever ImageScaler::Create builds (the CPU back-end).
-    auto cpu = ImageScaler::Create(in_w_, in_h_, fmt_, out_w_, out_h_);
-    if (cpu && cpu.get() != this) cpu->Scale(in, out);
-}
-
 void HipImageScaler::Scale(Framebuffer &in, Framebuffer *out) {
     if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ ||
         out->height() != out_h_ ||
         timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0,
                              (uint8_t *)out->begin(), 0, 0, 0, 1, nullptr, nullptr,
                              nullptr) != TIMG_HIP_OK)
-        CpuFallback(in, out);
+        HipFatal(ctx_, "HipImageScaler::Scale");
 }
 
 void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
@@ -50,11 +43,8 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
     int transparent = 0;
     if (timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0,
                              (uint8_t *)out->begin(), 0, 0, 0, 1, nullptr, &transparent,
-                             nullptr) != TIMG_HIP_OK) {
-        CpuFallback(in, out);
-        out->AlphaComposeBackground(get_bg, pattern, pattern_width, pattern_height);
-        return;
-    }
+                             nullptr) != TIMG_HIP_OK)
+        HipFatal(ctx_, "HipImageScaler::ScaleAndCompose");
     if (!get_bg || !transparent) return;  // src/framebuffer.cc:111,117: getter not consulted
     timg_hip_blend b;
     b.enabled   = 1;
@@ -65,8 +55,7 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
     b.start_row = 0;
     if (timg_hip_alpha_compose(ctx_, (uint8_t *)out->begin(), out_w_, out_h_, 0, 0, 0, 1, &b,
                                nullptr, nullptr) != TIMG_HIP_OK)
-        out->AlphaComposeBackground([&b]() { rgba_t c; memcpy(&c, &b.bg, 4); return c; },
-                                    pattern, pattern_width, pattern_height);
+        HipFatal(ctx_, "timg_hip_alpha_compose");
 }
 
 }  // namespace timg

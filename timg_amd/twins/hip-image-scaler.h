@@ -38,7 +38,6 @@ private:
                    int in_h, ColorFmt fmt, int out_w, int out_h)
         : ctx_(ctx), scaler_(scaler), in_w_(in_w), in_h_(in_h), fmt_(fmt),
           out_w_(out_w), out_h_(out_h) {}
-    void CpuFallback(Framebuffer &in, Framebuffer *out);
 
     timg_hip_ctx *const ctx_;
     timg_hip_scaler *const scaler_;

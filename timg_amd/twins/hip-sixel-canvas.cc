@@ -20,7 +20,9 @@ HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_po
                                const DisplayOptions &display_opts)
     : TerminalCanvas(ws), options_(display_opts), full_cell_jump_(sixel_options.full_cell_jump),
       broken_cursor_(sixel_options.known_broken_cursor_placement), executor_(thread_pool),
-      ctx_(SharedHipContext()) {}
+      ctx_(SharedHipContext()) {
+    if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
+}
 
 int HipSixelCanvas::cell_height_for_pixels(int pixels) const {  // src/sixel-canvas.cc:157-172
     assert(pixels <= 0);
@@ -60,10 +62,10 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     const std::function<OutBuffer()> encode_fun = [=]() {
         OutBuffer out(buffer, offset - buffer);
         size_t len = 0;
-        if (ctx && timg_hip_sixel_encode(ctx, pixels->data(), w, h, 0, 0, 0, 1, flags, &pad,
-                                         offset, cap - (size_t)(offset - buffer), 0, &len,
-                                         nullptr) == TIMG_HIP_OK)
-            out.size += len;
+        if (timg_hip_sixel_encode(ctx, pixels->data(), w, h, 0, 0, 0, 1, flags, &pad, offset,
+                                  cap - (size_t)(offset - buffer), 0, &len, nullptr) != TIMG_HIP_OK)
+            HipFatal(ctx, "timg_hip_sixel_encode");
+        out.size += len;
         return out;
     };
     write_sequencer_->WriteBuffer(executor_->ExecAsync(encode_fun), seq_type, end_of_frame);

@@ -25,9 +25,6 @@ public:
     void Send(int x, int dy, const Framebuffer &framebuffer, SeqType sequence_type,
               Duration end_of_frame) override;
 
-    // False when no device is usable: construct a timg::SixelCanvas instead.
-    bool usable() const { return ctx_ != nullptr; }
-
 private:
     const DisplayOptions &options_;
     const bool full_cell_jump_;

@@ -1,27 +1,22 @@
 // timg_amd/twins/hip-unicode-block-canvas.h -- GPU twin of
 // timg::UnicodeBlockCanvas (src/unicode-block-canvas.h:31-80): same
-// constructor, same TerminalCanvas interface, byte-identical output.
-//
-// Frames that the reference would encode completely (first frame of an image,
-// every frame in --grid mode: emit_difference false,
-// src/unicode-block-canvas.cc:344-346) are encoded on the GPU.  Frames of an
-// animation that the reference encodes as a difference to its backing store go
-// through the wrapped reference canvas, which is kept in sync by also showing
-// it every GPU-encoded frame's pixels (its output for those is discarded).
+// constructor, same TerminalCanvas interface, byte-identical output --
+// including the frame-difference encoding of animations, whose backing store
+// (the previous frame) lives on the device inside a timg_hip_block_canvas.
 #ifndef TIMG_AMD_TWINS_HIP_UNICODE_BLOCK_CANVAS_H
 #define TIMG_AMD_TWINS_HIP_UNICODE_BLOCK_CANVAS_H
-
-#include <memory>
 
 #include "buffered-write-sequencer.h"
 #include "terminal-canvas.h"
 #include "timg_hip.h"
-#include "unicode-block-canvas.h"
 
 namespace timg {
 
 class HipUnicodeBlockCanvas final : public TerminalCanvas {
 public:
+    // Terminates the process with a message when no HIP device is usable:
+    // construct a timg::UnicodeBlockCanvas instead if HipTwinsEnabled() /
+    // SharedHipContext() say so (src/timg.cc:319-345).
     HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool use_quarter,
                           bool use_upper_half_block, bool use_256_color);
     ~HipUnicodeBlockCanvas() override;
@@ -31,16 +26,8 @@ public:
               Duration end_of_frame) override;
 
 private:
-    const bool use_quarter_blocks_;
-    const bool use_upper_half_block_;
-    const bool use_256_color_;
     timg_hip_ctx *const ctx_;
-    int last_framebuffer_height_ = 0;
-    int last_x_indent_           = 0;
-    // difference frames: the reference implementation on a private sequencer
-    // whose output is forwarded (or dropped when it only serves to sync state)
-    struct DiffPath;
-    std::unique_ptr<DiffPath> diff_;
+    timg_hip_block_canvas *canvas_ = nullptr;
 };
 
 }  // namespace timg

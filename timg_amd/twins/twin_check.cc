@@ -1,0 +1,208 @@
+// timg_amd/twins/twin_check.cc -- TEST DRIVER (not part of the product).
+//
+// Links the reference's own classes (compiled from /root/reference where they
+// lie) next to the GPU twins and drives both through the SAME calls the
+// renderer makes (ImageScaler::Create/Scale, AlphaComposeBackground,
+// TerminalCanvas::Send through a BufferedWriteSequencer), then compares bytes.
+// Built by timg_amd/twins/Makefile into build/twin_check (git-ignored, travels
+// to the GPU box); tests/test_twins.py runs it under -m gpu.
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <csignal>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "buffered-write-sequencer.h"
+#include "display-options.h"
+#include "framebuffer.h"
+#include "hip-context.h"
+#include "hip-image-scaler.h"
+#include "hip-sixel-canvas.h"
+#include "hip-unicode-block-canvas.h"
+#include "image-scaler.h"
+#include "thread-pool.h"
+#include "unicode-block-canvas.h"
+
+using namespace timg;
+
+static uint32_t rng_state = 12345;
+static uint32_t Rand() {
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return rng_state >> 8;
+}
+
+static void Fill(Framebuffer *fb, int mode) {
+    for (int y = 0; y < fb->height(); ++y) {
+        for (int x = 0; x < fb->width(); ++x) {
+            rgba_t c;
+            c.r = (uint8_t)(mode == 2 ? (x * 7 + y * 3) & 0xc0 : Rand());
+            c.g = (uint8_t)(mode == 2 ? (x + y * 5) & 0xc0 : Rand());
+            c.b = (uint8_t)(mode == 2 ? (x * 2 + y) & 0xc0 : Rand());
+            c.a = mode == 1 ? (uint8_t)Rand() : 255;
+            if (mode == 1 && (Rand() & 3) == 0) c.a = (Rand() & 1) ? 0 : 255;
+            fb->SetPixel(x, y, c);
+        }
+    }
+    // The reference allocates one scratch row behind the image and leaves it
+    // uninitialised (src/framebuffer.cc:57-62); AppendDoubleRow<2> reads its first
+    // pixel for odd widths (src/unicode-block-canvas.cc:242-243).  Pin it to
+    // transparent black -- the value the device path defines for that pixel.
+    memset((void *)fb->end(), 0, (size_t)fb->width() * 4);
+}
+
+static std::string Slurp(int fd) {
+    const off_t n = lseek(fd, 0, SEEK_END);
+    std::string s((size_t)n, '\0');
+    if (n && pread(fd, &s[0], (size_t)n, 0) != n) s.clear();
+    return s;
+}
+
+static int failures = 0;
+#define CHECK(cond, ...)                   \
+    do {                                   \
+        if (!(cond)) {                     \
+            ++failures;                    \
+            fprintf(stderr, "FAIL: ");     \
+            fprintf(stderr, __VA_ARGS__);  \
+            fprintf(stderr, "\n");         \
+        }                                  \
+    } while (0)
+
+static void CheckScaler() {
+    const int geoms[][4] = {{640, 480, 67, 50}, {320, 200, 100, 56}, {1920, 1080, 400, 225},
+                            {50, 40, 120, 90}, {64, 64, 64, 64}, {3840, 2160, 800, 450}};
+    for (const auto &g : geoms) {
+        for (int mode = 0; mode < 2; ++mode) {
+            for (auto fmt : {ImageScaler::ColorFmt::kRGBA, ImageScaler::ColorFmt::kRGB32}) {
+                Framebuffer in(g[0], g[1]);
+                Fill(&in, mode);
+                Framebuffer want(g[2], g[3]), got(g[2], g[3]);
+                auto cpu = ImageScaler::Create(g[0], g[1], fmt, g[2], g[3]);
+                auto gpu = HipImageScaler::Create(g[0], g[1], fmt, g[2], g[3]);
+                CHECK(cpu && gpu, "scaler creation %dx%d", g[0], g[1]);
+                if (!cpu || !gpu) continue;
+                cpu->Scale(in, &want);
+                gpu->Scale(in, &got);
+                const size_t n = (size_t)g[2] * g[3] * 4;
+                CHECK(memcmp(want.begin(), got.begin(), n) == 0, "Scale %dx%d -> %dx%d mode %d", g[0],
+                      g[1], g[2], g[3], mode);
+                // scale + compose in one call vs the reference's two calls
+                rgba_t bg, pat;
+                bg.r = 30; bg.g = 30; bg.b = 46; bg.a = 255;
+                pat.r = 200; pat.g = 190; pat.b = 180; pat.a = 255;
+                int calls_cpu = 0, calls_gpu = 0;
+                want.AlphaComposeBackground([&]() { ++calls_cpu; return bg; }, pat, 9, 9);
+                static_cast<HipImageScaler *>(gpu.get())->ScaleAndCompose(
+                    in, &got, [&]() { ++calls_gpu; return bg; }, pat, 9, 9);
+                CHECK(memcmp(want.begin(), got.begin(), n) == 0, "ScaleAndCompose %dx%d mode %d", g[0],
+                      g[1], mode);
+                CHECK(calls_cpu == calls_gpu, "bg getter laziness: %d vs %d", calls_cpu, calls_gpu);
+            }
+        }
+    }
+    printf("scaler twin: checked\n");
+    fflush(stdout);
+}
+
+static void CheckBlockCanvas() {
+    for (int flags = 0; flags < 8; ++flags) {
+        const bool quarter = flags & 1, upper = flags & 2, c256 = flags & 4;
+        volatile sig_atomic_t intr = 0;
+        const int fd_ref = memfd_create("ref", 0), fd_hip = memfd_create("hip", 0);
+        {
+            BufferedWriteSequencer seq_ref(fd_ref, false, 4, true, intr);
+            BufferedWriteSequencer seq_hip(fd_hip, false, 4, true, intr);
+            UnicodeBlockCanvas ref(&seq_ref, quarter, upper, c256);
+            HipUnicodeBlockCanvas hip(&seq_hip, quarter, upper, c256);
+            auto both = [&](int x, int dy, const Framebuffer &fb) {
+                ref.Send(x, dy, fb, SeqType::FrameImmediate, {});
+                hip.Send(x, dy, fb, SeqType::FrameImmediate, {});
+            };
+            // a grid row: three images side by side (cursor moves queued like the renderer does)
+            Framebuffer a(100, 56);
+            for (int col = 0; col < 3; ++col) {
+                Fill(&a, col);
+                if (col > 0) {
+                    ref.MoveCursorDY(-ref.cell_height_for_pixels(-56));
+                    hip.MoveCursorDY(-hip.cell_height_for_pixels(-56));
+                }
+                both(col * 102, 0, a);
+            }
+            // an animation: same place, small changes, one unchanged frame
+            Framebuffer anim(67, 51);
+            Fill(&anim, 2);
+            both(4, 0, anim);
+            for (int f = 0; f < 6; ++f) {
+                if (f != 3) {
+                    rgba_t c;
+                    c.r = (uint8_t)(40 * f); c.g = 200; c.b = 10; c.a = 255;
+                    for (int x = 5 * f; x < 5 * f + 9; ++x) anim.SetPixel(x, (7 * f) % 51, c);
+                }
+                both(4, -51, anim);
+            }
+        }  // sequencers flush on destruction
+        const std::string r = Slurp(fd_ref), h = Slurp(fd_hip);
+        CHECK(r == h && !r.empty(), "block canvas flags %d: %zu vs %zu bytes", flags, r.size(), h.size());
+        close(fd_ref);
+        close(fd_hip);
+    }
+    printf("block canvas twin: checked\n");
+    fflush(stdout);
+}
+
+static void CheckSixelCanvas(const char *dump_path) {
+    volatile sig_atomic_t intr = 0;
+    const int fd = memfd_create("six", 0);
+    {
+        // the pool must outlive the sequencer: ~ThreadPool drops queued work, and the
+        // sequencer's final flush would wait for those futures forever (timg.cc keeps the
+        // same order: the encoder pool is deleted after the sequencer has been flushed)
+        ThreadPool pool(2);
+        BufferedWriteSequencer seq(fd, false, 4, true, intr);
+        DisplayOptions opts;
+        opts.cell_x_px      = 9;
+        opts.cell_y_px      = 18;
+        opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+        SixelOptions so;
+        HipSixelCanvas canvas(&seq, &pool, so, opts);
+        Framebuffer fb(200, 113);  // pads to 114 rows
+        Fill(&fb, 2);
+        canvas.Send(0, 0, fb, SeqType::FrameImmediate, {});
+        canvas.Send(18, -113, fb, SeqType::FrameImmediate, {});
+    }
+    const std::string s = Slurp(fd);
+    CHECK(s.size() > 1000 && s.find("\033P") != std::string::npos && s.find("\033\\") != std::string::npos,
+          "sixel canvas output malformed (%zu bytes)", s.size());
+    if (dump_path) {
+        FILE *f = fopen(dump_path, "wb");
+        if (f) {
+            fwrite(s.data(), 1, s.size(), f);
+            fclose(f);
+        }
+    }
+    close(fd);
+    printf("sixel canvas twin: %zu bytes\n", s.size());
+}
+
+int main(int argc, char **argv) {
+    // twin_check [all|scaler|block|sixel] [sixel-dump-path]
+    const std::string what = argc > 1 ? argv[1] : "all";
+    if (!SharedHipContext()) {
+        fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
+        return 2;
+    }
+    if (what == "all" || what == "scaler") CheckScaler();
+    if (what == "all" || what == "block") CheckBlockCanvas();
+    if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
+    if (failures) {
+        fprintf(stderr, "twin_check: %d failure(s)\n", failures);
+        return 1;
+    }
+    printf("twin_check: all twins match the reference classes\n");
+    fflush(stdout);
+    return 0;
+}

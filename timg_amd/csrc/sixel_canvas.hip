@@ -16,6 +16,7 @@
 //   K5 EncodeBand               one workgroup per 6-row band: colour runs ->
 //                               nodes -> libsixel's greedy packing -> RLE bytes
 //   K6 AssembleFrame / CopyBands  header, palette, band offsets, compaction
+#include <algorithm>
 #include <cstring>
 
 #include "context.h"
@@ -37,6 +38,7 @@ struct SixelGeom {
     int broken_cursor;
     uint32_t sample_stride_px, n_samples;
     size_t band_cap;     // scratch bytes per band
+    int band_ne;         // entry / node slots per band (6 * w rounded up to 64)
 };
 
 // per-frame device scratch
@@ -53,6 +55,14 @@ struct SixelFrameScratch {
     char *band_bytes;      // [bands * band_cap]
     int *band_meta;        // [bands * 4]: len, first colour, last colour, first tag len
     uint32_t *band_off;    // [bands * 2]: output offset, elided bytes
+    // per band, band_ne slots each (see the K5 kernels)
+    uint32_t *band_ent;    // (colour, x, mask) entries sorted by colour, x
+    uint32_t *band_nkey;   // nodes sorted by sx asc, mx desc, colour asc
+    uint16_t *band_nfirst; // first entry of each node
+    uint32_t *band_pi;     // per node: pass << 16 | index inside the pass
+    uint16_t *band_xs;     // per node: pen position when it is put
+    uint32_t *band_pbase;  // [bands * 256] output slot of the first node of every pass
+    int *band_cnt;         // [bands * 4]: entries, nodes
 };
 
 struct SixelBatch {
@@ -64,6 +74,9 @@ struct SixelBatch {
     char *band_bytes;
     int *band_meta;
     uint32_t *band_off;
+    uint32_t *band_ent, *band_nkey, *band_pi, *band_pbase;
+    uint16_t *band_nfirst, *band_xs;
+    int *band_cnt;
     char *out;
     size_t out_cap;
     unsigned long long *out_len;
@@ -84,6 +97,14 @@ __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, c
     s.band_bytes = b.band_bytes + (size_t)f * g.bands * g.band_cap;
     s.band_meta  = b.band_meta + (size_t)f * g.bands * 4;
     s.band_off   = b.band_off + (size_t)f * g.bands * 2;
+    const size_t fb = (size_t)f * g.bands;
+    s.band_ent    = b.band_ent + fb * g.band_ne;
+    s.band_nkey   = b.band_nkey + fb * g.band_ne;
+    s.band_nfirst = b.band_nfirst + fb * g.band_ne;
+    s.band_pi     = b.band_pi + fb * g.band_ne;
+    s.band_xs     = b.band_xs + fb * g.band_ne;
+    s.band_pbase  = b.band_pbase + fb * 256;
+    s.band_cnt    = b.band_cnt + fb * 4;
     return s;
 }
 
@@ -456,44 +477,80 @@ __device__ __forceinline__ void ApplyErr(int v[3], uint32_t packed, int num) {
     v[2] = ClampAdd(v[2], (int)((packed >> 20) & 0x3ffu) - 256, num);
 }
 
-__global__ void __launch_bounds__(64) DitherKernel(SixelGeom g, SixelBatch b) {
+// One workgroup per frame, one wave per 64 consecutive rows, one lane per row.
+// Inside a wave row y runs two columns behind row y-1 (the minimum Floyd-
+// Steinberg allows: pixel (x,y) needs e(x+1,y-1)), the lane above hands its
+// errors down through DPP shuffles.  Between waves the last row of wave k
+// publishes its errors in an LDS boundary row plus a progress counter, and the
+// first row of wave k+1 follows it as closely as the data allows: the waves of a
+// frame form a pipeline, so a frame costs W + 2*(H-1) steps instead of
+// ceil(H/64) * (W + 2*63).  Frames taller than kDitherMaxWaves*64 rows go round
+// again (wave 0 then follows the last wave of the previous round).
+constexpr int kDitherMaxWaves = 16;
+constexpr int kDitherAhead    = 8;  // source pixels are requested this many steps early
+
+__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
-    uint32_t *lut      = lds;            // 32768 entries
-    uint32_t *boundary = lds + 32768;    // w packed errors of the row above the block
+    const int W = g.w, H = g.h6;
+    const int n_waves  = blockDim.x >> 6;
+    uint32_t *lut      = lds;                       // 32768 entries
+    uint32_t *boundary = lds + 32768;               // [n_waves][W] packed errors of a wave's last row
+    volatile int *progress = reinterpret_cast<volatile int *>(boundary + (size_t)n_waves * W);
     const int f               = blockIdx.x;
-    const int lane            = threadIdx.x;
+    const int tid             = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
-    for (int i = lane; i < 32768; i += 64) lut[i] = s.lut[i];
-    for (int i = lane; i < g.w; i += 64) boundary[i] = kZeroErr;
+    for (int i = tid; i < 32768; i += blockDim.x) lut[i] = s.lut[i];
+    if (tid < n_waves) progress[tid] = 0;
     const bool dither = s.meta[1] != 0;
     __syncthreads();
 
-    const int W = g.w, H = g.h6;
-    for (int row0 = 0; row0 < H; row0 += 64) {
-        const int row      = row0 + lane;
+    const int rows_per_round = n_waves * 64;
+    const int steps          = W + 2 * 63;
+    for (int round = 0; round * rows_per_round + wave * 64 < H; ++round) {
+        const int row      = round * rows_per_round + wave * 64 + lane;
         const bool has_row = row < H;
-        // history of this lane's own (diffusable) errors, newest first
-        uint32_t h1 = kZeroErr, h2 = kZeroErr, h3 = kZeroErr, h4 = kZeroErr, h5 = kZeroErr;
+        // whose last row lies directly above this wave's first row
+        const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
+        const int producer_round = wave == 0 ? round - 1 : round;
+        const bool follows       = producer_round >= 0;
+        const uint32_t *b_in     = boundary + (size_t)producer * W;
+        uint32_t *b_out          = boundary + (size_t)wave * W;
+        const int in_base        = producer_round * W;   // progress value before the producer's round
+        const int out_base       = round * W;
+        int avail = 0;                                   // boundary entries known to be published
+
+        // this lane's own (diffusable) errors, newest first: e(x-1), e(x-2), e(x-3)
+        uint32_t h1 = kZeroErr, h2 = kZeroErr, h3 = kZeroErr;
         uint32_t first_err = kZeroErr;  // e(0,row) for the x == W-1 quirk
         uint32_t packed_idx = 0;
-        const int steps = W + 4 * 63;
-        // source pixels are fetched four steps ahead of their use
-        uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
-        for (int t = -4; t < steps; ++t) {
-            // the lane above is 4 columns ahead: its h3/h4/h5 are e(x+1), e(x), e(x-1)
-            uint32_t up_r = __shfl_up(h3, 1), up_c = __shfl_up(h4, 1), up_l = __shfl_up(h5, 1);
-            const int x = t - 4 * lane;
-            if (lane == 0) {
-                up_l = (x - 1 >= 0 && x - 1 < W) ? boundary[x - 1] : kZeroErr;
-                up_c = (x >= 0 && x < W) ? boundary[x] : kZeroErr;
-                up_r = (x + 1 >= 0 && x + 1 < W) ? boundary[x + 1] : kZeroErr;
+        // lane 0 of a following wave: boundary values above x-1, x, x+1
+        uint32_t bl = kZeroErr, bc = kZeroErr, br = kZeroErr;
+        if (follows) {
+            int need = min(2, W);
+            while (avail < need) {
+                avail = progress[producer] - in_base;
+                if (avail < need) __builtin_amdgcn_s_sleep(1);
             }
-            const uint32_t px = pf0;
-            pf0               = pf1;
-            pf1               = pf2;
-            pf2               = pf3;
-            pf3 = (has_row && x + 4 >= 0 && x + 4 < W) ? PaddedPixel(frame, g, x + 4, row) : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bc = b_in[0];
+            br = W > 1 ? b_in[1] : kZeroErr;
+        }
+
+        auto fetch = [&](int t) -> uint32_t {
+            const int x = t - 2 * lane;
+            return (has_row && x >= 0 && x < W) ? PaddedPixel(frame, g, x, row) : 0u;
+        };
+        auto step = [&](int t, uint32_t px) __attribute__((always_inline)) {
+            // the lane above is 2 columns ahead: its h1/h2/h3 are e(x+1), e(x), e(x-1)
+            uint32_t up_r = __shfl_up(h1, 1), up_c = __shfl_up(h2, 1), up_l = __shfl_up(h3, 1);
+            const int x = t - 2 * lane;
+            if (lane == 0) {
+                up_l = bl;
+                up_c = bc;
+                up_r = br;
+            }
             uint32_t mine = kZeroErr;
             if (has_row && x >= 0 && x < W) {
                 int v[3] = {(int)(px & 0xffu), (int)((px >> 8) & 0xffu), (int)((px >> 16) & 0xffu)};
@@ -523,44 +580,73 @@ __global__ void __launch_bounds__(64) DitherKernel(SixelGeom g, SixelBatch b) {
                         for (int k = 0; k < nb; ++k) dst[k] = (uint8_t)(packed_idx >> (8 * k));
                     packed_idx = 0;
                 }
-                if (lane == 63) boundary[x] = mine;  // row above the next block
+                if (lane == 63) {  // the row above the next wave's first row
+                    b_out[x] = mine;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    progress[wave] = out_base + x + 1;
+                }
             }
-            h5 = h4;
-            h4 = h3;
             h3 = h2;
             h2 = h1;
             h1 = mine;
-        }
-        __syncthreads();
-    }
-}
-
-// ---- K5: one workgroup per band ---------------------------------------------------------
-// Bitonic sort of n (power of two) 32-bit keys in LDS with an optional 16-bit payload.
-__device__ void BitonicSort(uint32_t *keys, uint16_t *vals, int n) {
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up    = (i & k) == 0;
-                    const uint32_t a = keys[i], c = keys[ixj];
-                    if ((a > c) == up) {
-                        keys[i]   = c;
-                        keys[ixj] = a;
-                        if (vals) {
-                            const uint16_t t = vals[i];
-                            vals[i]          = vals[ixj];
-                            vals[ixj]        = t;
-                        }
+            // lane 0's window over the boundary row moves one column to the right
+            if (follows && t + 1 < W) {  // wave-uniform: lane 0 is at x = t
+                const int nx = t + 3;    // the step after this one needs boundary[t + 2]
+                if (nx <= W) {
+                    while (avail < nx) {
+                        avail = progress[producer] - in_base;
+                        if (avail < nx) __builtin_amdgcn_s_sleep(1);
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
+                bl = bc;
+                bc = br;
+                br = t + 2 < W ? b_in[t + 2] : kZeroErr;
             }
-            __syncthreads();
+        };
+
+        static_assert(kDitherAhead == 8, "the pixel ring below is written out for 8 steps");
+        uint32_t p0 = fetch(0), p1 = fetch(1), p2 = fetch(2), p3 = fetch(3), p4 = fetch(4),
+                 p5 = fetch(5), p6 = fetch(6), p7 = fetch(7);
+        for (int t = 0; t < steps; t += 8) {
+            step(t, p0);
+            p0 = fetch(t + 8);
+            if (t + 1 >= steps) break;
+            step(t + 1, p1);
+            p1 = fetch(t + 9);
+            if (t + 2 >= steps) break;
+            step(t + 2, p2);
+            p2 = fetch(t + 10);
+            if (t + 3 >= steps) break;
+            step(t + 3, p3);
+            p3 = fetch(t + 11);
+            if (t + 4 >= steps) break;
+            step(t + 4, p4);
+            p4 = fetch(t + 12);
+            if (t + 5 >= steps) break;
+            step(t + 5, p5);
+            p5 = fetch(t + 13);
+            if (t + 6 >= steps) break;
+            step(t + 6, p6);
+            p6 = fetch(t + 14);
+            if (t + 7 >= steps) break;
+            step(t + 7, p7);
+            p7 = fetch(t + 15);
         }
     }
 }
 
+// ---- K5: band encode, three kernels --------------------------------------------------------
+// libsixel encodes a 6-row band as "nodes" (a colour's run of columns, gaps of < 10
+// empty columns merged), sorts them by (start asc, end desc, colour asc) and packs them
+// greedily into left-to-right passes separated by '$'.  Per band:
+//   K5a BandNodes  (256 lanes)  entries in column order -> stable radix sort by colour
+//                               -> nodes -> bucket sort by start column
+//   K5b BandPack   (ONE wave)   the greedy packing is first-fit over the passes' pen
+//                               positions in sorted node order: serial by nature, so it
+//                               runs one wave per band with no LDS and every band of the
+//                               batch in flight at once
+//   K5c BandEmit   (256 lanes)  pass-major output order, byte size per node, scan, bytes
 __device__ __forceinline__ int NumLen(uint32_t v) {
     return v >= 10000 ? 5 : v >= 1000 ? 4 : v >= 100 ? 3 : v >= 10 ? 2 : 1;
 }
@@ -641,176 +727,336 @@ __device__ int EmitNode(char *p, const uint32_t *entries, int first_entry, int c
     return n;
 }
 
-// LDS carve-up of EncodeBandKernel (bytes): 3 x 32 KiB + 3 x 16 KiB + 1 KiB
-constexpr size_t kBandLdsBytes =
-    (size_t)kMaxEntries * (3 * sizeof(uint32_t) + 3 * sizeof(uint16_t)) + kMaxEntries / 8;
 
-__global__ void __launch_bounds__(256) EncodeBandKernel(SixelGeom g, SixelBatch b) {
+__device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_tmp, uint32_t *total) {
+    // 256 threads; s_tmp: 5 words of LDS.  Returns the exclusive prefix of v.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl  = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();  // s_tmp may still be read from a previous scan
+    if (lane == 63) s_tmp[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int q = 0; q < wv; ++q) before += s_tmp[q];
+    if (total) *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    return before + incl - v;
+}
+
+// distinct colours of one column of a band: up to 6 (colour, row mask) pairs in
+// order of first occurrence
+__device__ __forceinline__ int ColumnEntries(const uint8_t *rows, int W, int x, uint32_t ent[6]) {
+    uint32_t c[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) c[r] = rows[(size_t)r * W + x];
+    uint32_t done = 0;
+    int n         = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        if (done & (1u << r)) continue;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int q = r; q < 6; ++q)
+            if (c[q] == c[r]) mask |= 1u << q;
+        done |= mask;
+        ent[n++] = (c[r] << 22) | ((uint32_t)x << 6) | mask;
+    }
+    return n;
+}
+
+__global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
-    uint32_t *ent      = lds;                    // colour<<22 | x<<6 | mask, sorted
-    uint32_t *node_key = lds + kMaxEntries;      // sx<<20 | (4095-mx)<<8 | colour, sorted
-    uint32_t *node_off = lds + 2 * kMaxEntries;  // per output slot: byte size, then offset
-    uint16_t *node_ent = reinterpret_cast<uint16_t *>(lds + 3 * kMaxEntries);  // first entry
-    uint16_t *order    = node_ent + kMaxEntries;  // output slot -> node | new_pass << 15
-    uint16_t *x_start  = order + kMaxEntries;     // pen position when the node is put
-    uint32_t *alive    = reinterpret_cast<uint32_t *>(x_start + kMaxEntries);
-    __shared__ int s_count[2];
-    __shared__ uint32_t s_scan[5];
-    __shared__ int s_overflow;
+    const int NE       = g.band_ne;
+    uint32_t *ent_a    = lds;            // sorted entries end up here
+    uint32_t *ent_b    = lds + NE;       // radix partner, then the unsorted node keys
+    uint16_t *nfirst_u = reinterpret_cast<uint16_t *>(lds + 2 * NE);  // first entry of node k
+    uint32_t *aux      = lds + 2 * NE + NE / 2;  // 4096 words: radix histogram / column buckets
+    __shared__ uint32_t s_tmp[5];
 
-    const int band            = blockIdx.x;
-    const int f               = blockIdx.y;
-    const int tid             = threadIdx.x;
+    const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const int W               = g.w;
     const uint8_t *rows       = s.index + (size_t)band * 6 * W;
+    const size_t slot         = (size_t)band * NE;
 
-    if (tid < 2) s_count[tid] = 0;
-    if (tid == 0) s_overflow = 0;
-    for (int i = tid; i < kMaxEntries; i += 256) ent[i] = 0xffffffffu;
+    // ---- entries, column-major: count, scan, write
+    const int per_c = (W + 255) / 256;
+    const int x0 = min(W, tid * per_c), x1 = min(W, x0 + per_c);
+    uint32_t mine = 0;
+    uint32_t e6[6];
+    for (int x = x0; x < x1; ++x) mine += (uint32_t)ColumnEntries(rows, W, x, e6);
+    uint32_t n_ent_u;
+    uint32_t at = BlockExclusiveScan(mine, s_tmp, &n_ent_u);
+    const int n_ent = (int)n_ent_u;
+    for (int x = x0; x < x1; ++x) {
+        const int n = ColumnEntries(rows, W, x, e6);
+        for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
+        at += (uint32_t)n;
+    }
     __syncthreads();
-    // (colour, x, mask) entries: one per distinct colour of every column
-    for (int x = tid; x < W; x += 256) {
-        uint32_t c[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) c[r] = rows[(size_t)r * W + x];
-        uint32_t done = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            if (done & (1u << r)) continue;
-            uint32_t mask = 0;
-#pragma unroll
-            for (int q = r; q < 6; ++q)
-                if (c[q] == c[r]) mask |= 1u << q;
-            done |= mask;
-            const int at = atomicAdd(&s_count[0], 1);
-            ent[at]      = (c[r] << 22) | ((uint32_t)x << 6) | mask;
+
+    // ---- stable LSD radix sort by colour: two 4-bit passes, a contiguous chunk per lane
+    const int per_e = (n_ent + 255) / 256;
+    const int e0 = min(n_ent, tid * per_e), e1 = min(n_ent, e0 + per_e);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift     = 22 + 4 * pass;
+        const uint32_t *src = pass ? ent_b : ent_a;
+        uint32_t *dst       = pass ? ent_a : ent_b;
+        for (int d = 0; d < 16; ++d) aux[d * 256 + tid] = 0;
+        for (int i = e0; i < e1; ++i) aux[((src[i] >> shift) & 15u) * 256 + tid] += 1;
+        __syncthreads();
+        // exclusive scan over the 4096 counters in (digit, lane) order
+        uint32_t sum = 0;
+        for (int j = 0; j < 16; ++j) sum += aux[tid * 16 + j];
+        uint32_t run = BlockExclusiveScan(sum, s_tmp, nullptr);
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t t  = aux[tid * 16 + j];
+            aux[tid * 16 + j] = run;
+            run += t;
         }
+        __syncthreads();
+        for (int i = e0; i < e1; ++i) {
+            const uint32_t e = src[i];
+            const uint32_t d = (e >> shift) & 15u;
+            dst[aux[d * 256 + tid]++] = e;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int n_ent = s_count[0];
-    int n_pow       = 64;
-    while (n_pow < n_ent) n_pow <<= 1;
-    BitonicSort(ent, nullptr, n_pow);
 
-    // A node starts at a new colour or after a gap of >= 10 empty columns
-    // (libsixel merges shorter gaps into the node).
-    for (int i = tid; i < kMaxEntries; i += 256) {
-        node_key[i] = 0xffffffffu;
-        node_ent[i] = 0;
-    }
-    __syncthreads();
+    // ---- nodes: a node starts at a new colour or after a gap of >= 10 empty columns
     auto breaks = [&](int i) {  // is there a node boundary between entries i-1 and i?
-        const uint32_t p = ent[i - 1], e = ent[i];
+        const uint32_t p = ent_a[i - 1], e = ent_a[i];
         return (p >> 22) != (e >> 22) ||
                (int)((e >> 6) & 0xffffu) - (int)((p >> 6) & 0xffffu) - 1 >= 10;
     };
-    for (int i = tid; i < n_ent; i += 256) {
-        if (i != 0 && !breaks(i)) continue;
-        int j = i;
-        while (j + 1 < n_ent && !breaks(j + 1)) ++j;
-        const uint32_t e  = ent[i];
-        const uint32_t sx = (e >> 6) & 0xffffu, mx = ((ent[j] >> 6) & 0xffffu) + 1;
-        const int at      = atomicAdd(&s_count[1], 1);
-        node_key[at]      = (sx << 20) | ((4095u - mx) << 8) | (e >> 22);
-        node_ent[at]      = (uint16_t)i;
+    uint32_t starts = 0;
+    for (int i = e0; i < e1; ++i) starts += (i == 0 || breaks(i)) ? 1u : 0u;
+    uint32_t n_nodes_u;
+    uint32_t k = BlockExclusiveScan(starts, s_tmp, &n_nodes_u);
+    const int n_nodes = (int)n_nodes_u;
+    for (int i = e0; i < e1; ++i)
+        if (i == 0 || breaks(i)) nfirst_u[k++] = (uint16_t)i;
+    for (int x = tid; x <= W; x += 256) {
+        aux[x]         = 0;  // nodes starting in column x
+        aux[2048 + x]  = 0;  // fill counter
     }
     __syncthreads();
-    const int n_nodes = s_count[1];
-    n_pow             = 64;
-    while (n_pow < n_nodes) n_pow <<= 1;
-    BitonicSort(node_key, node_ent, n_pow);  // by sx asc, mx desc, colour asc
-
-    // libsixel's greedy packing: sweep the sorted list, taking every node that
-    // starts at or after the pen position; repeat until none is left.  One wave.
-    const int n_words = (n_nodes + 31) / 32;
-    for (int i = tid; i < kMaxEntries / 32; i += 256) {
-        const int base = i * 32;
-        uint32_t m     = 0;
-        if (base + 32 <= n_nodes)
-            m = 0xffffffffu;
-        else if (base < n_nodes)
-            m = (1u << (n_nodes - base)) - 1u;
-        alive[i] = m;
+    uint32_t *key_u = ent_b;
+    for (int n = tid; n < n_nodes; n += 256) {
+        const int first   = nfirst_u[n];
+        const int last    = (n + 1 < n_nodes ? (int)nfirst_u[n + 1] : n_ent) - 1;
+        const uint32_t e  = ent_a[first];
+        const uint32_t sx = (e >> 6) & 0xffffu, mx = ((ent_a[last] >> 6) & 0xffffu) + 1;
+        key_u[n]          = (sx << 20) | ((4095u - mx) << 8) | (e >> 22);
+        atomicAdd(&aux[sx], 1u);
     }
     __syncthreads();
-    if (tid < 64) {
-        const int lane = tid;
-        int emitted = 0, head_word = 0, x = 0, search_from = 0;
-        bool new_pass = true, first_pass = true;
-        while (emitted < n_nodes) {
-            int start;
-            if (new_pass) {
-                while (head_word < n_words && alive[head_word] == 0) ++head_word;
-                start = head_word * 32;
-            } else {
-                // lower bound of sx >= x in [search_from, n_nodes), 64-way per round
-                int lo = search_from, hi = n_nodes;
-                while (hi > lo) {
-                    const int step = (hi - lo + 63) / 64;
-                    const int idx  = lo + lane * step;
-                    const bool lt  = idx < hi && (int)(node_key[idx] >> 20) < x;
-                    const int cnt  = __popcll(__ballot(lt));  // sorted: lt lanes are a prefix
-                    if (cnt == 0) {
-                        hi = lo;
-                    } else {
-                        const int last_lt = lo + (cnt - 1) * step;
-                        const int nhi     = last_lt + step;
-                        lo                = last_lt + 1;
-                        hi                = nhi < hi ? nhi : hi;
-                    }
-                }
-                start = lo;
-            }
-            int found = -1;
-            for (int w0 = start >> 5; w0 < n_words && found < 0; w0 += 64) {
-                const int w = w0 + lane;
-                uint32_t m  = w < n_words ? alive[w] : 0u;
-                if (w == (start >> 5)) m &= ~((1u << (start & 31)) - 1u);
-                const unsigned long long any = __ballot(m != 0);
-                if (any) {
-                    const int l       = __ffsll((long long)any) - 1;
-                    const uint32_t mm = __shfl(m, l);
-                    found             = (w0 + l) * 32 + (__ffs((int)mm) - 1);
-                }
-            }
-            if (found < 0) {  // sweep exhausted: carriage return, next pass
-                new_pass = true;
-                continue;
-            }
-            if (lane == 0) {
-                order[emitted]   = (uint16_t)((uint32_t)found | ((new_pass && !first_pass) ? 0x8000u : 0u));
-                x_start[emitted] = (uint16_t)(new_pass ? 0 : x);
-                alive[found >> 5] &= ~(1u << (found & 31));
-            }
-            x = 4095 - (int)((node_key[found] >> 8) & 0xfffu);  // pen moves to the node's mx
-            ++emitted;
-            new_pass    = false;
-            first_pass  = false;
-            search_from = found + 1;
+    // bucket bases: exclusive scan over the columns
+    {
+        const int per_x = (W + 256) / 256;
+        const int c0 = min(W + 1, tid * per_x), c1 = min(W + 1, c0 + per_x);
+        uint32_t sum = 0;
+        for (int x = c0; x < c1; ++x) sum += aux[x];
+        uint32_t run = BlockExclusiveScan(sum, s_tmp, nullptr);
+        for (int x = c0; x < c1; ++x) {
+            const uint32_t t = aux[x];
+            aux[x]           = run;
+            run += t;
         }
     }
     __syncthreads();
+    uint32_t *nkey   = s.band_nkey + slot;
+    uint16_t *nfirst = s.band_nfirst + slot;
+    for (int n = tid; n < n_nodes; n += 256) {
+        const uint32_t key = key_u[n];
+        const uint32_t sx  = key >> 20;
+        const uint32_t pos = aux[sx] + atomicAdd(&aux[2048 + sx], 1u);
+        nkey[pos]          = key;
+        nfirst[pos]        = nfirst_u[n];
+    }
+    __syncthreads();  // (also orders the global writes above inside the workgroup)
+    // nodes starting in the same column (at most 6: one per colour of the column):
+    // order them by end desc, colour asc = ascending key
+    for (int x = tid; x < W; x += 256) {
+        const int c = (int)aux[2048 + x];
+        if (c < 2) continue;
+        const uint32_t base = aux[x];
+        uint32_t kk[6];
+        uint16_t ff[6];
+        for (int j = 0; j < c && j < 6; ++j) {
+            kk[j] = nkey[base + j];
+            ff[j] = nfirst[base + j];
+        }
+        for (int i = 1; i < c && i < 6; ++i) {  // insertion sort
+            const uint32_t kv = kk[i];
+            const uint16_t fv = ff[i];
+            int j             = i - 1;
+            while (j >= 0 && kk[j] > kv) {
+                kk[j + 1] = kk[j];
+                ff[j + 1] = ff[j];
+                --j;
+            }
+            kk[j + 1] = kv;
+            ff[j + 1] = fv;
+        }
+        for (int j = 0; j < c && j < 6; ++j) {
+            nkey[base + j]   = kk[j];
+            nfirst[base + j] = ff[j];
+        }
+    }
+    uint32_t *ent_g = s.band_ent + slot;
+    for (int i = tid; i < n_ent; i += 256) ent_g[i] = ent_a[i];
+    if (tid == 0) {
+        s.band_cnt[band * 4 + 0] = n_ent;
+        s.band_cnt[band * 4 + 1] = n_nodes;
+    }
+}
 
-    auto describe = [&](int k, int *node_first, int *color, int *sx, int *mx, bool *tag, bool *cr) {
-        const uint32_t o   = order[k];
-        const int node     = (int)(o & 0x7fffu);
-        const uint32_t key = node_key[node];
-        *node_first        = node_ent[node];
+// K5b: one wave per band.  Pass p's pen position lives in lane p % 64 of register p / 64
+// (a fresh pass has pen 0, so first-fit opens passes in order by itself); 256 passes are
+// always enough: the passes needed = the largest number of nodes crossing one column <=
+// the number of colours.
+// v[lane idx] = val for wave-uniform val and idx
+__device__ __forceinline__ void WriteLane(uint32_t &v, uint32_t val, int idx) {
+    // (gfx9: one SGPR operand per VALU instruction, so the lane select travels in M0,
+    // which is saved and restored around the write)
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(v), "=&s"(saved_m0)
+                 : "s"(val), "s"(idx));
+}
+
+__global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b, int n_frames) {
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // band of the batch
+    if (unit >= g.bands * n_frames) return;                // whole wave
+    const int f = unit / g.bands, band = unit % g.bands;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const size_t slot         = (size_t)band * g.band_ne;
+    const uint32_t *nkey      = s.band_nkey + slot;
+    uint32_t *pi              = s.band_pi + slot;
+    uint16_t *xs              = s.band_xs + slot;
+    const int n_nodes         = s.band_cnt[band * 4 + 1];
+
+    uint32_t pen0 = 0, pen1 = 0, pen2 = 0, pen3 = 0;
+    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    uint32_t key_next = lane < n_nodes ? nkey[lane] : 0u;
+    for (int i0 = 0; i0 < n_nodes; i0 += 64) {
+        const uint32_t key = key_next;
+        key_next = (i0 + 64 + lane < n_nodes) ? nkey[i0 + 64 + lane] : 0u;
+        uint32_t res_pi = 0, res_xs = 0;
+        const int m = min(64, n_nodes - i0);
+        for (int j = 0; j < m; ++j) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+            const uint32_t sx = kj >> 20, mx = 4095u - ((kj >> 8) & 0xfffu);
+            unsigned long long fit = __ballot(pen0 <= sx);
+            uint32_t old_pen, old_cnt, pass;
+            if (fit) {
+                const int p = __ffsll((long long)fit) - 1;
+                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen0, p);
+                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt0, p);
+                WriteLane(pen0, mx, p);
+                WriteLane(cnt0, (old_cnt + 1), p);
+                pass        = (uint32_t)p;
+            } else if ((fit = __ballot(pen1 <= sx)) != 0) {
+                const int p = __ffsll((long long)fit) - 1;
+                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen1, p);
+                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt1, p);
+                WriteLane(pen1, mx, p);
+                WriteLane(cnt1, (old_cnt + 1), p);
+                pass        = 64u + (uint32_t)p;
+            } else if ((fit = __ballot(pen2 <= sx)) != 0) {
+                const int p = __ffsll((long long)fit) - 1;
+                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen2, p);
+                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt2, p);
+                WriteLane(pen2, mx, p);
+                WriteLane(cnt2, (old_cnt + 1), p);
+                pass        = 128u + (uint32_t)p;
+            } else {
+                fit         = __ballot(pen3 <= sx);
+                const int p = fit ? __ffsll((long long)fit) - 1 : 63;
+                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen3, p);
+                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt3, p);
+                WriteLane(pen3, mx, p);
+                WriteLane(cnt3, (old_cnt + 1), p);
+                pass        = 192u + (uint32_t)p;
+            }
+            WriteLane(res_pi, ((pass << 16) | old_cnt), j);
+            WriteLane(res_xs, old_pen, j);
+        }
+        if (i0 + lane < n_nodes) {
+            pi[i0 + lane] = res_pi;
+            xs[i0 + lane] = (uint16_t)res_xs;
+        }
+    }
+    // output slot of the first node of every pass: exclusive scan of the 256 counts
+    uint32_t c[4] = {cnt0, cnt1, cnt2, cnt3};
+    uint32_t carry = 0;
+    uint32_t *pbase = s.band_pbase + (size_t)band * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t incl = c[q];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        pbase[q * 64 + lane] = carry + incl - c[q];
+        carry += __shfl(incl, 63);
+    }
+}
+
+__global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t lds[];
+    const int NE       = g.band_ne;
+    uint32_t *node_off = lds;                                          // per output slot: size, then offset
+    uint16_t *order    = reinterpret_cast<uint16_t *>(lds + NE);       // output slot -> node
+    __shared__ uint32_t s_pbase[256];
+    __shared__ uint32_t s_scan[5];
+    __shared__ int s_overflow;
+
+    const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const size_t slot         = (size_t)band * NE;
+    const uint32_t *ent       = s.band_ent + slot;
+    const uint32_t *nkey      = s.band_nkey + slot;
+    const uint16_t *nfirst    = s.band_nfirst + slot;
+    const uint32_t *pi        = s.band_pi + slot;
+    const uint16_t *xs        = s.band_xs + slot;
+    const int n_nodes         = s.band_cnt[band * 4 + 1];
+    s_pbase[tid] = s.band_pbase[(size_t)band * 256 + tid];
+    if (tid == 0) s_overflow = 0;
+    __syncthreads();
+    for (int i = tid; i < n_nodes; i += 256) {
+        const uint32_t v               = pi[i];
+        order[s_pbase[v >> 16] + (v & 0xffffu)] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    auto describe = [&](int k, int *node_first, int *color, int *sx, int *mx, int *x_start, bool *tag,
+                        bool *cr) {
+        const int node     = order[k];
+        const uint32_t key = nkey[node];
+        const uint32_t v   = pi[node];
+        *node_first        = nfirst[node];
         *color             = (int)(key & 0xffu);
         *sx                = (int)(key >> 20);
         *mx                = 4095 - (int)((key >> 8) & 0xfffu);
-        *cr                = (o & 0x8000u) != 0;
+        *x_start           = xs[node];
+        *cr                = (v & 0xffffu) == 0 && (v >> 16) != 0;  // first node of a later pass: '$'
         // "#c" only when the active colour changes (first node: always, fixed up later)
-        *tag = k == 0 || (int)(node_key[order[k - 1] & 0x7fffu] & 0xffu) != *color;
+        *tag = k == 0 || (int)(nkey[order[k - 1]] & 0xffu) != *color;
     };
     // phase 1: byte size of every output slot
     for (int k = tid; k < n_nodes; k += 256) {
-        int first_e, color, sx, mx;
+        int first_e, color, sx, mx, x_start;
         bool tag, cr;
-        describe(k, &first_e, &color, &sx, &mx, &tag, &cr);
+        describe(k, &first_e, &color, &sx, &mx, &x_start, &tag, &cr);
         char *none = nullptr;
-        node_off[k] = (uint32_t)EmitNode<false>(none, ent, first_e, color, sx, mx, x_start[k], tag) +
+        node_off[k] = (uint32_t)EmitNode<false>(none, ent, first_e, color, sx, mx, x_start, tag) +
                       (cr ? 1u : 0u);
     }
     __syncthreads();
@@ -849,18 +1095,18 @@ __global__ void __launch_bounds__(256) EncodeBandKernel(SixelGeom g, SixelBatch 
     } else {
         if (tid == 0 && lead) out_band[0] = '-';
         for (int k = tid; k < n_nodes; k += 256) {
-            int first_e, color, sx, mx;
+            int first_e, color, sx, mx, x_start;
             bool tag, cr;
-            describe(k, &first_e, &color, &sx, &mx, &tag, &cr);
+            describe(k, &first_e, &color, &sx, &mx, &x_start, &tag, &cr);
             char *p = out_band + node_off[k];
             if (cr) *p++ = '$';
-            EmitNode<true>(p, ent, first_e, color, sx, mx, x_start[k], tag);
+            EmitNode<true>(p, ent, first_e, color, sx, mx, x_start, tag);
         }
     }
     __syncthreads();
     if (tid == 0) {
-        const int first_color = n_nodes ? (int)(node_key[order[0] & 0x7fffu] & 0xffu) : -1;
-        const int last_color  = n_nodes ? (int)(node_key[order[n_nodes - 1] & 0x7fffu] & 0xffu) : -1;
+        const int first_color = n_nodes ? (int)(nkey[order[0]] & 0xffu) : -1;
+        const int last_color  = n_nodes ? (int)(nkey[order[n_nodes - 1]] & 0xffu) : -1;
         // an overflowing band reports a length no caller buffer can hold
         s.band_meta[band * 4 + 0] = s_overflow ? 0x3fffffff : (int)band_len;
         s.band_meta[band * 4 + 1] = first_color;
@@ -1059,6 +1305,15 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_bb    = carve(nf * g.bands * g.band_cap);
     const size_t o_bm    = carve(nf * g.bands * 4 * sizeof(int));
     const size_t o_bo    = carve(nf * g.bands * 2 * sizeof(uint32_t));
+    g.band_ne            = ((6 * w + 63) / 64) * 64;
+    const size_t n_band  = nf * g.bands;
+    const size_t o_bent  = carve(n_band * g.band_ne * 4);
+    const size_t o_bkey  = carve(n_band * g.band_ne * 4);
+    const size_t o_bfst  = carve(n_band * g.band_ne * 2);
+    const size_t o_bpi   = carve(n_band * g.band_ne * 4);
+    const size_t o_bxs   = carve(n_band * g.band_ne * 2);
+    const size_t o_bpb   = carve(n_band * 256 * 4);
+    const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
     const size_t o_len   = carve(nf * sizeof(unsigned long long));
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
     char *base = (char *)ctx->dev[5].ptr;
@@ -1076,19 +1331,33 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.band_bytes = base + o_bb;
     b.band_meta  = (int *)(base + o_bm);
     b.band_off   = (uint32_t *)(base + o_bo);
+    b.band_ent    = (uint32_t *)(base + o_bent);
+    b.band_nkey   = (uint32_t *)(base + o_bkey);
+    b.band_nfirst = (uint16_t *)(base + o_bfst);
+    b.band_pi     = (uint32_t *)(base + o_bpi);
+    b.band_xs     = (uint16_t *)(base + o_bxs);
+    b.band_pbase  = (uint32_t *)(base + o_bpb);
+    b.band_cnt    = (int *)(base + o_bcnt);
     b.out        = dout;
     b.out_cap    = out_cap;
     b.out_len    = (unsigned long long *)(base + o_len);
 
-    const size_t dither_lds = (32768 + (size_t)w) * sizeof(uint32_t);
-    const size_t band_lds   = kBandLdsBytes;
+    // one wave per 64 rows, as many as the boundary rows leave room for next to the 128 KiB LUT
+    int dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + 63) / 64));
+    auto dither_bytes = [&](int waves) {
+        return (32768 + (size_t)waves * w + kDitherMaxWaves) * sizeof(uint32_t);
+    };
+    while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
+    const size_t dither_lds = dither_bytes(dither_waves);
+    const size_t nodes_lds  = ((size_t)2 * g.band_ne + g.band_ne / 2 + 4096) * sizeof(uint32_t);
+    const size_t emit_lds   = ((size_t)g.band_ne + g.band_ne / 2) * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dither_lds));
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)EncodeBandKernel,
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)BandNodesKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)band_lds));
+                                          (int)nodes_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kCutLdsBytes));
@@ -1100,8 +1369,11 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(64), kCutLdsBytes, st, g, b);
     hipLaunchKernelGGL(BuildLutKernel, dim3(128, n_frames), dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(DitherKernel, dim3(n_frames), dim3(64), dither_lds, st, g, b);
-    hipLaunchKernelGGL(EncodeBandKernel, dim3(g.bands, n_frames), dim3(256), band_lds, st, g, b);
+    hipLaunchKernelGGL(DitherKernel, dim3(n_frames), dim3(dither_waves * 64), dither_lds, st, g, b);
+    hipLaunchKernelGGL(BandNodesKernel, dim3(g.bands, n_frames), dim3(256), nodes_lds, st, g, b);
+    hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * n_frames + 3) / 4), dim3(256), 0, st, g, b,
+                       n_frames);
+    hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, n_frames), dim3(256), emit_lds, st, g, b);
     hipLaunchKernelGGL(AssembleFrameKernel, dim3(n_frames), dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(CopyBandsKernel, dim3(g.bands, n_frames), dim3(256), 0, st, g, b);
     TIMG_HIP_TRY(ctx, hipGetLastError());

@@ -151,16 +151,23 @@ __global__ void __launch_bounds__(256) MarkFirstKernel(SixelGeom g, SixelBatch b
     s.entries[k] = e;
 }
 
-// ---- K2: median cut, one wave per frame -------------------------------------------
-// The split order of libsixel's median cut is inherently serial (always the
-// largest remaining box), so a frame gets one wave; a batch of frames fills the
-// chip.  The colour table lives in LDS (ping-pong halves, global-memory
-// fallback for > kCutLdsEntries colours) and a split costs a few hundred
-// instructions: boxes of <= 64 colours are sorted in registers with ballots,
-// larger ones by a stable per-lane-segment counting sort on the 5-bit key.
-constexpr int kCutLdsEntries = 16384;
+// ---- K2: median cut, one workgroup per frame -------------------------------------------
+// libsixel's median cut always splits the largest remaining box, which reads as 255
+// dependent steps.  But what a split DOES (plane choice, stable sort of the box's colours,
+// median) depends on that box alone -- only WHICH boxes get split depends on the order.
+// So every round the kCutWaves waves split, concurrently and speculatively, the first
+// kCutWaves splittable boxes of the list (one wave each, into the other half of the
+// ping-pong colour table, leaving the source intact), and one wave then replays
+// libsixel's list bookkeeping with the prepared results for as long as the box it
+// needs next has been prepared.  Boxes near the head of the sum-ordered list are exactly
+// the ones the serial algorithm takes next, so almost no speculation is wasted.
+// Inside a split: boxes of <= 64 colours are sorted in registers with ballots, larger
+// ones by a stable per-lane-segment counting sort on the 5-bit key.
+constexpr int kCutWaves      = 8;
+constexpr int kCutLdsEntries = 8192;              // colour table kept in LDS up to this size
+constexpr int kCutScratch    = 64 * 33 + 96;      // words of per-wave scratch
 constexpr size_t kCutLdsBytes =
-    (size_t)2 * kCutLdsEntries * sizeof(uint32_t) + (size_t)64 * 33 * sizeof(uint32_t);
+    ((size_t)2 * kCutLdsEntries + (size_t)kCutWaves * kCutScratch) * sizeof(uint32_t);
 
 __device__ __forceinline__ uint32_t PlaneKey(uint32_t entry, int plane) {
     return (entry >> (10 - 5 * plane)) & 0x1fu;  // plane 0=r 1=g 2=b
@@ -168,43 +175,218 @@ __device__ __forceinline__ uint32_t PlaneKey(uint32_t entry, int plane) {
 
 struct CutBox {
     uint32_t ind, colors, sum, buf;  // buf: which half of the ping-pong table holds it
+    uint32_t median, lowersum;       // prepared split (valid when ready != 0)
+    uint32_t ready, pad;
 };
 
-__global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b) {
+// Memory traffic of ONE wave needs no barrier (its operations are issued in order);
+// this drains them and keeps the compiler from moving or caching accesses across the point.
+#define TIMG_WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+
+// Prepares the split of `box` by one wave: sorts its colours (stable, by the plane
+// with the largest luminosity-weighted spread) into the other table half and finds
+// the median.  scratch: kCutScratch words owned by this wave.
+__device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *scratch, int lane,
+                         uint32_t *median_out, uint32_t *lowersum_out) {
+    uint32_t *lane_cnt    = scratch;             // [64][33]
+    uint32_t *s_key_total = scratch + 64 * 33;   // [32]
+    uint32_t *s_key_base  = s_key_total + 32;    // [32]
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t *src = tab[box.buf] + box.ind;
+    uint32_t *dst       = tab[box.buf ^ 1u] + box.ind;
+    const uint32_t half = box.sum / 2;
+    uint32_t median, lowersum;
+
+    // per-plane extent of the box (5-bit keys)
+    uint32_t mn[3] = {31, 31, 31}, mx[3] = {0, 0, 0};
+    for (uint32_t i = lane; i < box.colors; i += 64) {
+        const uint32_t e = src[i];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t k = PlaneKey(e, p);
+            mn[p] = k < mn[p] ? k : mn[p];
+            mx[p] = k > mx[p] ? k : mx[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t a = __shfl_xor(mn[p], d), c = __shfl_xor(mx[p], d);
+            mn[p] = a < mn[p] ? a : mn[p];
+            mx[p] = c > mx[p] ? c : mx[p];
+        }
+    }
+    // SIXEL_LARGE_LUM: plane with the largest luminosity-weighted spread
+    int plane = 0;
+    {
+        const double lum[3] = {0.2989, 0.5866, 0.1145};
+        double best         = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const double spread = lum[p] * (double)((mx[p] - mn[p]) << 3);
+            if (spread > best) {
+                plane = p;
+                best  = spread;
+            }
+        }
+    }
+
+    if (box.colors <= 64) {
+        // ---- small box: stable LSD radix sort on the key, in registers -----
+        const bool live = (uint32_t)lane < box.colors;
+        uint32_t e      = live ? src[lane] : 0xffffffffu;
+#pragma unroll
+        for (int bit = 0; bit < 6; ++bit) {
+            // dead lanes carry key 32 so that they sort behind everything
+            const uint32_t key = e == 0xffffffffu ? 32u : PlaneKey(e, plane);
+            const bool one     = (key >> bit) & 1u;
+            const unsigned long long ones = __ballot(one);
+            const int n_zero   = 64 - __popcll(ones);
+            const int dest     = one ? n_zero + __popcll(ones & lt_mask) : __popcll(~ones & lt_mask);
+            // forward permutation through LDS (the lane-count scratch is free here)
+            lane_cnt[dest] = e;
+            TIMG_WAVE_SYNC();
+            e = lane_cnt[lane];
+            TIMG_WAVE_SYNC();
+        }
+        if (live) dst[lane] = e;
+        const uint32_t c = live ? (e >> 15) : 0u;
+        uint32_t incl    = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const uint32_t pre = incl - c;  // P(lane): pixels in front of entry `lane`
+        const unsigned long long hit = __ballot(live && lane >= 1 && pre >= half);
+        median = hit ? (uint32_t)__ffsll((long long)hit) - 1 : box.colors - 1;
+        if (median > box.colors - 1) median = box.colors - 1;
+        lowersum = __shfl(pre, (int)median);
+    } else {
+        // ---- large box: stable counting sort, one contiguous segment per lane -
+        // (odd segment length keeps the lanes on different LDS banks)
+        const uint32_t seg = (((box.colors + 63) / 64) | 1u);
+        const uint32_t a   = min(box.colors, (uint32_t)lane * seg);
+        const uint32_t z   = min(box.colors, a + seg);
+        uint32_t *mine     = lane_cnt + lane * 33;
+        for (int k = 0; k < 32; ++k) mine[k] = 0;
+        for (uint32_t i = a; i < z; ++i) mine[PlaneKey(src[i], plane)] += 1;
+        TIMG_WAVE_SYNC();
+        // exclusive prefix over the lanes, per key: lanes 0-31 take key = lane for the
+        // lower half of the lanes, lanes 32-63 the same key for the upper half
+        {
+            const int key = lane & 31, l0 = (lane >> 5) * 32;
+            uint32_t run = 0;
+            for (int l = l0; l < l0 + 32; ++l) {
+                const uint32_t t       = lane_cnt[l * 33 + key];
+                lane_cnt[l * 33 + key] = run;
+                run += t;
+            }
+            TIMG_WAVE_SYNC();
+            const uint32_t lower = __shfl(run, key);        // total of lanes 0-31 for this key
+            if (lane >= 32)
+                for (int l = 32; l < 64; ++l) lane_cnt[l * 33 + key] += lower;
+            const uint32_t total = lower + __shfl(run, 32 + key);
+            if (lane < 32) s_key_total[lane] = total;
+            uint32_t incl = lane < 32 ? total : 0u;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((lane & 31) >= d) incl += o;
+            }
+            if (lane < 32) s_key_base[lane] = incl - total;
+        }
+        TIMG_WAVE_SYNC();
+        for (uint32_t i = a; i < z; ++i) {
+            const uint32_t e   = src[i];
+            const uint32_t k   = PlaneKey(e, plane);
+            const uint32_t off = mine[k];
+            mine[k]            = off + 1;
+            dst[s_key_base[k] + off] = e;
+        }
+        __threadfence_block();
+        TIMG_WAVE_SYNC();
+        // median: the lane whose segment of the sorted box holds the crossing walks it
+        uint32_t seg_sum = 0;
+        for (uint32_t i = a; i < z; ++i) seg_sum += dst[i] >> 15;
+        uint32_t incl = seg_sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        uint32_t run  = incl - seg_sum;  // P(a)
+        uint32_t cand = 0xffffffffu, cand_sum = 0;
+        for (uint32_t i = a; i < z; ++i) {
+            if (i >= 1 && run >= half) {
+                cand     = i;
+                cand_sum = run;
+                break;
+            }
+            run += dst[i] >> 15;
+        }
+        const unsigned long long hit = __ballot(cand != 0xffffffffu);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;  // lowest lane = lowest index
+            median      = __shfl(cand, l);
+            lowersum    = __shfl(cand_sum, l);
+        } else {
+            median   = box.colors - 1;
+            lowersum = 0;
+        }
+        if (median >= box.colors - 1) {
+            median   = box.colors - 1;
+            lowersum = box.sum - (dst[box.colors - 1] >> 15);
+        }
+    }
+    *median_out   = median;
+    *lowersum_out = lowersum;
+}
+
+__global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t cut_lds[];
-    uint32_t *lane_cnt = cut_lds + 2 * kCutLdsEntries;  // [64][33]
     __shared__ CutBox box_a[kMaxColors], box_b[kMaxColors];
-    __shared__ uint32_t s_min[3], s_max[3], s_key_total[32], s_key_base[32];
+    __shared__ uint32_t s_n, s_total, s_nboxes, s_done, s_flip;
     const int f    = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t *scratch = cut_lds + 2 * kCutLdsEntries + wave * kCutScratch;
 
-    // compact the first-seen entries (stable) into tab_a
-    uint32_t n = 0, total = 0;
-    for (uint32_t k0 = 0; k0 < g.n_samples; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
-        const unsigned long long m = __ballot(e != 0);
-        if (e) s.tab_a[n + __popcll(m & lt_mask)] = e;
-        n += __popcll(m);
-        uint32_t c = e >> 15;
+    // compact the first-seen entries (stable) into tab_a  (one wave: order matters)
+    if (wave == 0) {
+        uint32_t n = 0, total = 0;
+        for (uint32_t k0 = 0; k0 < g.n_samples; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
+            const unsigned long long m = __ballot(e != 0);
+            if (e) s.tab_a[n + __popcll(m & lt_mask)] = e;
+            n += __popcll(m);
+            uint32_t c = e >> 15;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-        total += c;
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+            total += c;
+        }
+        if (lane == 0) {
+            s_n     = n;
+            s_total = total;
+        }
     }
     __threadfence_block();
     __syncthreads();
+    const uint32_t n = s_n;
 
     if (n <= (uint32_t)kMaxColors) {
         // few enough colours: palette = the histogram colours, no diffusion
-        for (uint32_t i = lane; i < n; i += 64) {
+        for (uint32_t i = tid; i < n; i += blockDim.x) {
             const uint32_t e     = s.tab_a[i];
             s.palette[i * 3 + 0] = (uint8_t)(((e >> 10) & 0x1f) << 3);
             s.palette[i * 3 + 1] = (uint8_t)(((e >> 5) & 0x1f) << 3);
             s.palette[i * 3 + 2] = (uint8_t)((e & 0x1f) << 3);
         }
-        if (lane == 0) {
+        if (tid == 0) {
             s.meta[0] = (int)n;
             s.meta[1] = 0;
         }
@@ -214,208 +396,118 @@ __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b)
     if (n <= (uint32_t)kCutLdsEntries) {
         tab[0] = cut_lds;
         tab[1] = cut_lds + kCutLdsEntries;
-        for (uint32_t i = lane; i < n; i += 64) tab[0][i] = s.tab_a[i];
+        for (uint32_t i = tid; i < n; i += blockDim.x) tab[0][i] = s.tab_a[i];
     } else {
         tab[0] = s.tab_a;
         tab[1] = s.tab_b;
     }
-    CutBox *boxes = box_a, *boxes_next = box_b;
-    if (lane == 0) boxes[0] = CutBox{0, n, total, 0};
-    uint32_t nboxes = 1;
+    if (tid == 0) {
+        box_a[0]  = CutBox{0, n, s_total, 0, 0, 0, 0, 0};
+        s_nboxes  = 1;
+        s_done    = 0;
+        s_flip    = 0;
+    }
     __syncthreads();
 
-    while (nboxes < (uint32_t)kMaxColors) {
-        // first box (in sum-descending order) that still holds >= 2 colours
-        uint32_t bi = 0xffffffffu;
-        for (uint32_t i0 = 0; i0 < nboxes && bi == 0xffffffffu; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const unsigned long long m = __ballot(i < nboxes && boxes[i].colors >= 2);
-            if (m) bi = i0 + (uint32_t)__ffsll((long long)m) - 1;
-        }
-        if (bi == 0xffffffffu) break;
-        const CutBox box    = boxes[bi];
-        const uint32_t *src = tab[box.buf] + box.ind;
-        uint32_t *dst       = tab[box.buf ^ 1u] + box.ind;
-        const uint32_t half = box.sum / 2;
-        uint32_t median, lowersum;
-
-        // per-plane extent of the box (5-bit keys)
-        if (lane < 3) {
-            s_min[lane] = 31;
-            s_max[lane] = 0;
-        }
-        __syncthreads();
+    for (;;) {
+        CutBox *boxes = s_flip ? box_b : box_a;
+        const uint32_t nboxes = s_nboxes;
+        // ---- speculative splits: wave w prepares the w-th unprepared splittable box
         {
-            uint32_t mn[3] = {31, 31, 31}, mx[3] = {0, 0, 0};
-            for (uint32_t i = lane; i < box.colors; i += 64) {
-                const uint32_t e = src[i];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const uint32_t k = PlaneKey(e, p);
-                    mn[p] = k < mn[p] ? k : mn[p];
-                    mx[p] = k > mx[p] ? k : mx[p];
+            uint32_t mine = 0xffffffffu, seen = 0;
+            for (uint32_t i0 = 0; i0 < nboxes && mine == 0xffffffffu; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool cand  = i < nboxes && boxes[i].colors >= 2 && boxes[i].ready == 0;
+                const unsigned long long m = __ballot(cand);
+                const uint32_t c = (uint32_t)__popcll(m);
+                if (seen + c > (uint32_t)wave) {  // the (wave - seen)-th set bit of m
+                    unsigned long long mm = m;
+                    for (uint32_t k = seen; k < (uint32_t)wave; ++k) mm &= mm - 1;
+                    mine = i0 + (uint32_t)__ffsll((long long)mm) - 1;
+                }
+                seen += c;
+            }
+            if (mine != 0xffffffffu) {
+                const CutBox box = boxes[mine];
+                uint32_t median, lowersum;
+                SplitBox(box, tab, scratch, lane, &median, &lowersum);
+                if (lane == 0) {
+                    boxes[mine].median   = median;
+                    boxes[mine].lowersum = lowersum;
+                    boxes[mine].ready    = 1;
                 }
             }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                atomicMin(&s_min[p], mn[p]);
-                atomicMax(&s_max[p], mx[p]);
-            }
         }
+        __threadfence_block();
         __syncthreads();
-        // SIXEL_LARGE_LUM: plane with the largest luminosity-weighted spread
-        int plane = 0;
-        {
-            const double lum[3] = {0.2989, 0.5866, 0.1145};
-            double best         = 0.0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const double spread = lum[p] * (double)((s_max[p] - s_min[p]) << 3);
-                if (spread > best) {
-                    plane = p;
-                    best  = spread;
+        // ---- replay of the serial bookkeeping (wave 0)
+        if (wave == 0) {
+            CutBox *cur = boxes, *next = s_flip ? box_a : box_b;
+            uint32_t nb = nboxes, flip = s_flip, done = 0;
+            while (nb < (uint32_t)kMaxColors) {
+                // first box (in sum-descending order) that still holds >= 2 colours
+                uint32_t bi = 0xffffffffu;
+                for (uint32_t i0 = 0; i0 < nb && bi == 0xffffffffu; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const unsigned long long m = __ballot(i < nb && cur[i].colors >= 2);
+                    if (m) bi = i0 + (uint32_t)__ffsll((long long)m) - 1;
                 }
-            }
-        }
-
-        if (box.colors <= 64) {
-            // ---- small box: stable LSD radix sort on the key, in registers -----
-            const bool live = (uint32_t)lane < box.colors;
-            uint32_t e      = live ? src[lane] : 0xffffffffu;
-#pragma unroll
-            for (int bit = 0; bit < 6; ++bit) {
-                // dead lanes carry key 32 so that they sort behind everything
-                const uint32_t key = e == 0xffffffffu ? 32u : PlaneKey(e, plane);
-                const bool one     = (key >> bit) & 1u;
-                const unsigned long long ones = __ballot(one);
-                const int n_zero   = 64 - __popcll(ones);
-                const int dest     = one ? n_zero + __popcll(ones & lt_mask) : __popcll(~ones & lt_mask);
-                // forward permutation through LDS (the lane-count scratch is free here)
-                lane_cnt[dest] = e;
-                __syncthreads();
-                e = lane_cnt[lane];
-                __syncthreads();
-            }
-            if (live) dst[lane] = e;
-            const uint32_t c = live ? (e >> 15) : 0u;
-            uint32_t incl    = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            const uint32_t pre = incl - c;  // P(lane): pixels in front of entry `lane`
-            const unsigned long long hit = __ballot(live && lane >= 1 && pre >= half);
-            median = hit ? (uint32_t)__ffsll((long long)hit) - 1 : box.colors - 1;
-            if (median > box.colors - 1) median = box.colors - 1;
-            lowersum = __shfl(pre, (int)median);
-        } else {
-            // ---- large box: stable counting sort, one contiguous segment per lane -
-            // (odd segment length keeps the lanes on different LDS banks)
-            const uint32_t seg = (((box.colors + 63) / 64) | 1u);
-            const uint32_t a   = min(box.colors, (uint32_t)lane * seg);
-            const uint32_t z   = min(box.colors, a + seg);
-            uint32_t *mine     = lane_cnt + lane * 33;
-            for (int k = 0; k < 32; ++k) mine[k] = 0;
-            for (uint32_t i = a; i < z; ++i) mine[PlaneKey(src[i], plane)] += 1;
-            __syncthreads();
-            if (lane < 32) {  // exclusive prefix over the lanes, per key
-                uint32_t run = 0;
-                for (int l = 0; l < 64; ++l) {
-                    const uint32_t t       = lane_cnt[l * 33 + lane];
-                    lane_cnt[l * 33 + lane] = run;
-                    run += t;
-                }
-                s_key_total[lane] = run;
-            }
-            __syncthreads();
-            if (lane < 32) {
-                uint32_t incl = s_key_total[lane];
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) {
-                    const uint32_t o = __shfl_up(incl, d);
-                    if (lane >= d) incl += o;
-                }
-                s_key_base[lane] = incl - s_key_total[lane];
-            }
-            __syncthreads();
-            for (uint32_t i = a; i < z; ++i) {
-                const uint32_t e   = src[i];
-                const uint32_t k   = PlaneKey(e, plane);
-                const uint32_t off = mine[k];
-                mine[k]            = off + 1;
-                dst[s_key_base[k] + off] = e;
-            }
-            __threadfence_block();
-            __syncthreads();
-            // median: the lane whose segment of the sorted box holds the crossing walks it
-            uint32_t seg_sum = 0;
-            for (uint32_t i = a; i < z; ++i) seg_sum += dst[i] >> 15;
-            uint32_t incl = seg_sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            uint32_t run  = incl - seg_sum;  // P(a)
-            uint32_t cand = 0xffffffffu, cand_sum = 0;
-            for (uint32_t i = a; i < z; ++i) {
-                if (i >= 1 && run >= half) {
-                    cand     = i;
-                    cand_sum = run;
+                if (bi == 0xffffffffu) {
+                    done = 1;
                     break;
                 }
-                run += dst[i] >> 15;
+                const CutBox box = cur[bi];
+                if (!box.ready) break;  // its split has not been prepared yet: next round
+                const uint32_t median = box.median, lowersum = box.lowersum;
+                // replace the box by its halves and restore the stable sum-descending order:
+                // the low half keeps the parent's place in the pre-sort sequence, the high
+                // half is appended (libsixel qsorts the whole vector; pinned as stable).
+                const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 0};
+                const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u,
+                                0, 0, 0, 0};
+                uint32_t cnt_gt_lo = 0, cnt_ge_hi = 0;
+                for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool other = i < nb && i != bi;
+                    const uint32_t sm = other ? cur[i].sum : 0u;
+                    cnt_gt_lo += (uint32_t)__popcll(__ballot(other && sm > lo.sum));
+                    cnt_ge_hi += (uint32_t)__popcll(__ballot(other && sm >= hi.sum));
+                }
+                for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < nb && i != bi) {
+                        const CutBox o = cur[i];
+                        const uint32_t pos = (i < bi ? i : i - 1) + (o.sum > lo.sum ? 0u : 1u) +
+                                             (o.sum >= hi.sum ? 0u : 1u);
+                        next[pos] = o;
+                    }
+                }
+                if (lane == 0) {
+                    next[cnt_gt_lo + (lo.sum < hi.sum ? 1u : 0u)]  = lo;
+                    next[cnt_ge_hi + (lo.sum >= hi.sum ? 1u : 0u)] = hi;
+                }
+                ++nb;
+                CutBox *t = cur;
+                cur       = next;
+                next      = t;
+                flip ^= 1u;
+                TIMG_WAVE_SYNC();
             }
-            const unsigned long long hit = __ballot(cand != 0xffffffffu);
-            if (hit) {
-                const int l = __ffsll((long long)hit) - 1;  // lowest lane = lowest index
-                median      = __shfl(cand, l);
-                lowersum    = __shfl(cand_sum, l);
-            } else {
-                median   = box.colors - 1;
-                lowersum = 0;
-            }
-            if (median >= box.colors - 1) {
-                median   = box.colors - 1;
-                lowersum = box.sum - (dst[box.colors - 1] >> 15);
+            if (nb >= (uint32_t)kMaxColors) done = 1;
+            if (lane == 0) {
+                s_nboxes = nb;
+                s_flip   = flip;
+                s_done   = done;
             }
         }
-
-        // replace the box by its halves and restore the stable sum-descending order:
-        // the low half keeps the parent's place in the pre-sort sequence, the high
-        // half is appended (libsixel qsorts the whole vector; pinned as stable).
-        const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u};
-        const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u};
-        uint32_t cnt_gt_lo = 0, cnt_ge_hi = 0;
-        for (uint32_t i0 = 0; i0 < nboxes; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const bool other = i < nboxes && i != bi;
-            const uint32_t sm = other ? boxes[i].sum : 0u;
-            cnt_gt_lo += (uint32_t)__popcll(__ballot(other && sm > lo.sum));
-            cnt_ge_hi += (uint32_t)__popcll(__ballot(other && sm >= hi.sum));
-        }
-        for (uint32_t i0 = 0; i0 < nboxes; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            if (i < nboxes && i != bi) {
-                const CutBox o = boxes[i];
-                const uint32_t pos = (i < bi ? i : i - 1) + (o.sum > lo.sum ? 0u : 1u) +
-                                     (o.sum >= hi.sum ? 0u : 1u);
-                boxes_next[pos] = o;
-            }
-        }
-        if (lane == 0) {
-            boxes_next[cnt_gt_lo + (lo.sum < hi.sum ? 1u : 0u)]  = lo;
-            boxes_next[cnt_ge_hi + (lo.sum >= hi.sum ? 1u : 0u)] = hi;
-        }
-        ++nboxes;
-        CutBox *t  = boxes;
-        boxes      = boxes_next;
-        boxes_next = t;
+        __threadfence_block();
         __syncthreads();
+        if (s_done) break;
     }
+    const CutBox *boxes   = s_flip ? box_b : box_a;
+    const uint32_t nboxes = s_nboxes;
     // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
-    for (uint32_t bi = lane; bi < nboxes; bi += 64) {
+    for (uint32_t bi = tid; bi < nboxes; bi += blockDim.x) {
         const CutBox box    = boxes[bi];
         const uint32_t *src = tab[box.buf] + box.ind;
         uint32_t sum[3]     = {0, 0, 0};
@@ -429,7 +521,7 @@ __global__ void __launch_bounds__(64) MedianCutKernel(SixelGeom g, SixelBatch b)
         s.palette[bi * 3 + 1] = (uint8_t)(sum[1] / box.colors);
         s.palette[bi * 3 + 2] = (uint8_t)(sum[2] / box.colors);
     }
-    if (lane == 0) {
+    if (tid == 0) {
         s.meta[0] = (int)nboxes;
         s.meta[1] = 1;  // more colours than palette entries: diffuse
     }
@@ -1367,7 +1459,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const dim3 sgrid((g.n_samples + 255) / 256, n_frames);
     hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(64), kCutLdsBytes, st, g, b);
+    hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(kCutWaves * 64), kCutLdsBytes, st, g, b);
     hipLaunchKernelGGL(BuildLutKernel, dim3(128, n_frames), dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(DitherKernel, dim3(n_frames), dim3(dither_waves * 64), dither_lds, st, g, b);
     hipLaunchKernelGGL(BandNodesKernel, dim3(g.bands, n_frames), dim3(256), nodes_lds, st, g, b);

@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(in_w, in_h, out_w, out_h, bg, n_sample_frames, frames):
+def cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, frames, target_seconds=12.0):
     """The reference's CPU path on the host cores, on a bounded sample of the
     same workload: the REAL reference (oracle/_ref, hzeller/timg sources) for
     scale + alpha-compose where it was built, the oracle's restatement for the
@@ -42,7 +42,7 @@ def cpu_baseline(in_w, in_h, out_w, out_h, bg, n_sample_frames, frames):
     import oracle_lib
     orc = oracle_lib.Oracle()
     ref = oracle_lib.Ref.try_load()
-    cores = max(1, min(os.cpu_count() or 1, n_sample_frames))
+    cores = max(1, cores)
     distinct = [np.ascontiguousarray(f) for f in frames]  # a few of the GPU's own input frames
     scaler = ref if ref is not None else orc
 
@@ -53,14 +53,22 @@ def cpu_baseline(in_w, in_h, out_w, out_h, bg, n_sample_frames, frames):
             orc.sixel_encode(fb, bg=bg, lookup_mode=0)
 
     work([0])  # warm-up
-    shards = [list(range(t, n_sample_frames, cores)) for t in range(cores)]
-    threads = [threading.Thread(target=work, args=(s,)) for s in shards]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t0
+    def run(n):
+        shards = [list(range(t, n, cores)) for t in range(cores)]
+        threads = [threading.Thread(target=work, args=(s,)) for s in shards]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return time.perf_counter() - t0
+
+    # bounded sample: one calibration round, then enough frames for ~12 s of wall time
+    # on these cores (at most 40 rounds)
+    t_round = run(cores)
+    rounds = max(1, min(40, int(target_seconds / max(t_round, 1e-3))))
+    n_sample_frames = cores * rounds
+    dt = run(n_sample_frames)
     mpx = n_sample_frames * in_w * in_h / 1e6 / dt
     return {
         "value": round(mpx, 2), "unit": "Mpixels/s", "cores": cores,
@@ -82,7 +90,8 @@ def main():
     ap.add_argument("--mode", default="sixel", choices=["sixel", "quarter", "half"])
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU sample")
     args = ap.parse_args()
 
     import torch
@@ -208,10 +217,10 @@ def main():
             pass
 
     if rank == 0 and not args.no_cpu_baseline:
-        n_cpu = args.cpu_frames or 2 * max(1, min(os.cpu_count() or 1, 32))
+        cores = args.cpu_threads or (os.cpu_count() or 1)
         host_frames = src[:min(4, args.frames)].cpu().numpy()
-        result["cpu_baseline"] = cpu_baseline(in_w, in_h, out_w, out_h, bg, n_cpu, host_frames) \
-            if args.mode == "sixel" else None
+        result["cpu_baseline"] = cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, host_frames,
+                                              args.cpu_seconds) if args.mode == "sixel" else None
     if rank == 0:
         print(json.dumps(result), flush=True)
     pipe.close()

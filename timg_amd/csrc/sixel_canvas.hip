@@ -39,6 +39,7 @@ struct SixelGeom {
     uint32_t sample_stride_px, n_samples;
     size_t band_cap;     // scratch bytes per band
     int band_ne;         // entry / node slots per band (6 * w rounded up to 64)
+    int idx_stride;      // bytes per row of the palette-index image (w rounded up to 4)
 };
 
 // per-frame device scratch
@@ -93,7 +94,7 @@ __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, c
     s.lut        = b.lut + (size_t)f * 32768;
     s.palette    = b.palette + (size_t)f * 768;
     s.meta       = b.meta + (size_t)f * 4;
-    s.index      = b.index + (size_t)f * g.h6 * g.w;
+    s.index      = b.index + (size_t)f * g.h6 * g.idx_stride;
     s.band_bytes = b.band_bytes + (size_t)f * g.bands * g.band_cap;
     s.band_meta  = b.band_meta + (size_t)f * g.bands * 4;
     s.band_off   = b.band_off + (size_t)f * g.bands * 2;
@@ -552,48 +553,90 @@ __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b)
 }
 
 // ---- K4: lookup + Floyd-Steinberg -----------------------------------------------------
-// Errors travel packed: three signed 9-bit values biased by 256 in 10-bit fields.
-__device__ __forceinline__ uint32_t PackErr(int r, int g, int b) {
-    return (uint32_t)(r + 256) | ((uint32_t)(g + 256) << 10) | ((uint32_t)(b + 256) << 20);
-}
-constexpr uint32_t kZeroErr = 256u | (256u << 10) | (256u << 20);
+// libsixel diffuses in place on 8-bit data: every contribution is added with
+// C integer division (err * num / 16, truncating toward zero) and clamped to
+// 0..255 before the next one arrives, so order and rounding of each term matter.
+// The pixel that PRODUCES an error computes its four terms once (7/16 right,
+// 3/16 below-left, 5/16 below, 1/16 below-right), each packed as three signed
+// bytes (r, g, b); consumers only add and clamp.
+struct ErrTerms {
+    uint32_t q7, q5, q3, q1;
+};
 
-__device__ __forceinline__ int ClampAdd(int v, int err, int num) {
-    const int c = v + err * num / 16;  // C division: truncates toward zero
-    return c < 0 ? 0 : (c > 255 ? 255 : c);
+__device__ __forceinline__ uint32_t PackBytes(int r, int g, int b) {
+    return ((uint32_t)r & 0xffu) | (((uint32_t)g & 0xffu) << 8) | (((uint32_t)b & 0xffu) << 16);
 }
 
-__device__ __forceinline__ void ApplyErr(int v[3], uint32_t packed, int num) {
-    v[0] = ClampAdd(v[0], (int)(packed & 0x3ffu) - 256, num);
-    v[1] = ClampAdd(v[1], (int)((packed >> 10) & 0x3ffu) - 256, num);
-    v[2] = ClampAdd(v[2], (int)((packed >> 20) & 0x3ffu) - 256, num);
+__device__ __forceinline__ ErrTerms MakeTerms(int er, int eg, int eb) {
+    // trunc(e * n / 16) == (e * n + (e < 0 ? 15 : 0)) >> 4   (arithmetic shift)
+    const int sr = (er >> 31) & 15, sg = (eg >> 31) & 15, sb = (eb >> 31) & 15;
+    ErrTerms t;
+    t.q7 = PackBytes((er * 7 + sr) >> 4, (eg * 7 + sg) >> 4, (eb * 7 + sb) >> 4);
+    t.q5 = PackBytes((er * 5 + sr) >> 4, (eg * 5 + sg) >> 4, (eb * 5 + sb) >> 4);
+    t.q3 = PackBytes((er * 3 + sr) >> 4, (eg * 3 + sg) >> 4, (eb * 3 + sb) >> 4);
+    t.q1 = PackBytes((er + sr) >> 4, (eg + sg) >> 4, (eb + sb) >> 4);
+    return t;
+}
+
+__device__ __forceinline__ int Clamp255(int c) { return c < 0 ? 0 : (c > 255 ? 255 : c); }
+
+__device__ __forceinline__ void ApplyTerm(int v[3], uint32_t q) {
+    v[0] = Clamp255(v[0] + (int)(int8_t)(q & 0xffu));
+    v[1] = Clamp255(v[1] + (int)(int8_t)((q >> 8) & 0xffu));
+    v[2] = Clamp255(v[2] + (int)(int8_t)((q >> 16) & 0xffu));
 }
 
 // One workgroup per frame, one wave per 64 consecutive rows, one lane per row.
 // Inside a wave row y runs two columns behind row y-1 (the minimum Floyd-
 // Steinberg allows: pixel (x,y) needs e(x+1,y-1)), the lane above hands its
-// errors down through DPP shuffles.  Between waves the last row of wave k
-// publishes its errors in an LDS boundary row plus a progress counter, and the
+// terms down through DPP shuffles.  Between waves the last row of wave k
+// publishes its terms in LDS boundary rows plus a progress counter, and the
 // first row of wave k+1 follows it as closely as the data allows: the waves of a
 // frame form a pipeline, so a frame costs W + 2*(H-1) steps instead of
 // ceil(H/64) * (W + 2*63).  Frames taller than kDitherMaxWaves*64 rows go round
 // again (wave 0 then follows the last wave of the previous round).
+// LDS: the cell -> palette index table as bytes (32 KiB), the palette, and three
+// boundary rows per wave.
 constexpr int kDitherMaxWaves = 16;
 constexpr int kDitherAhead    = 8;  // source pixels are requested this many steps early
+
+// wave_shr:1 -- every lane receives the value of the lane below it in index (lane 0 keeps
+// its own): the hand-down of error terms from row y-1 to row y costs one VALU move
+__device__ __forceinline__ uint32_t FromLaneAbove(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
 
 __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
-    uint32_t *lut      = lds;                       // 32768 entries
-    uint32_t *boundary = lds + 32768;               // [n_waves][W] packed errors of a wave's last row
-    volatile int *progress = reinterpret_cast<volatile int *>(boundary + (size_t)n_waves * W);
+    const int n_pad    = H - g.h;                            // rows SixelCanvas::Send appends
+    uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);   // 32768 palette indices
+    uint32_t *pal      = lds + 8192;                         // 256 x (idx | r<<8 | g<<16 | b<<24)
+    uint32_t *padpix   = pal + 256;                          // [n_pad][W] pixels of the pad rows
+    uint32_t *boundary = padpix + (size_t)n_pad * W;         // [n_waves][3][W]: q1, q5, q3 of a wave's last row
+    // columns published by each wave's last row.  All hand-over traffic is LDS traffic of
+    // the form "data, then counter" from ONE wave, which the LDS executes in order: no
+    // fence is needed (a workgroup fence would also drain the wave's global prefetches and
+    // stores, i.e. put a memory round trip into every step) -- only the compiler has to keep
+    // the order, hence the relaxed atomics and the empty asm barriers below.
+    __shared__ int progress[kDitherMaxWaves];
     const int f               = blockIdx.x;
     const int tid             = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
-    for (int i = tid; i < 32768; i += blockDim.x) lut[i] = s.lut[i];
+    for (int i = tid; i < 8192; i += blockDim.x) {  // four cells per word
+        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i];
+        lds[i]        = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
+    }
+    for (int i = tid; i < 256; i += blockDim.x) {
+        const int n = s.meta[0];
+        pal[i]      = i < n ? ((uint32_t)i | ((uint32_t)s.palette[i * 3] << 8) |
+                          ((uint32_t)s.palette[i * 3 + 1] << 16) | ((uint32_t)s.palette[i * 3 + 2] << 24))
+                       : 0u;
+    }
+    for (int i = tid; i < n_pad * W; i += blockDim.x) padpix[i] = PaddedPixel(frame, g, i % W, g.h + i / W);
     if (tid < n_waves) progress[tid] = 0;
     const bool dither = s.meta[1] != 0;
     __syncthreads();
@@ -603,128 +646,159 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     for (int round = 0; round * rows_per_round + wave * 64 < H; ++round) {
         const int row      = round * rows_per_round + wave * 64 + lane;
         const bool has_row = row < H;
+        // where this lane's pixels come from: a frame row in memory or a pad row in LDS
+        const bool is_pad       = row >= g.h;
+        const uint8_t *src_row  = frame + (size_t)min(row, g.h - 1) * g.stride;
+        const uint32_t *pad_row = padpix + (size_t)(is_pad && has_row ? row - g.h : 0) * W;
+        uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
+        const bool diffuses     = dither && row < H - 1;
         // whose last row lies directly above this wave's first row
         const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
         const int producer_round = wave == 0 ? round - 1 : round;
         const bool follows       = producer_round >= 0;
-        const uint32_t *b_in     = boundary + (size_t)producer * W;
-        uint32_t *b_out          = boundary + (size_t)wave * W;
+        const uint32_t *b_in     = boundary + (size_t)producer * 3 * W;
+        uint32_t *b_out          = boundary + (size_t)wave * 3 * W;
         const int in_base        = producer_round * W;   // progress value before the producer's round
         const int out_base       = round * W;
         int avail = 0;                                   // boundary entries known to be published
 
-        // this lane's own (diffusable) errors, newest first: e(x-1), e(x-2), e(x-3)
-        uint32_t h1 = kZeroErr, h2 = kZeroErr, h3 = kZeroErr;
-        uint32_t first_err = kZeroErr;  // e(0,row) for the x == W-1 quirk
+        // terms of this lane's own recent errors:
+        //   own7 = 7/16 of e(x-1)  -> this row's next pixel
+        //   a1   = 3/16 of e(x-1), b2 = 5/16 of e(x-2), c3 = 1/16 of e(x-3) -> the row below
+        uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;
+        uint32_t first_q3 = 0;  // 3/16 of e(0,row) for the x == W-1 quirk
         uint32_t packed_idx = 0;
-        // lane 0 of a following wave: boundary values above x-1, x, x+1
-        uint32_t bl = kZeroErr, bc = kZeroErr, br = kZeroErr;
+        // lane 0 of a following wave: boundary terms above x-1 (1/16), x (5/16), x+1 (3/16)
+        uint32_t bl = 0, bc = 0, br = 0;
         if (follows) {
             int need = min(2, W);
             while (avail < need) {
-                avail = progress[producer] - in_base;
+                avail = __hip_atomic_load(&progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                        in_base;
                 if (avail < need) __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            bc = b_in[0];
-            br = W > 1 ? b_in[1] : kZeroErr;
+            asm volatile("" ::: "memory");
+            bc = b_in[W + 0];                       // q5 above x = 0
+            br = W > 1 ? b_in[2 * W + 1] : 0u;      // q3 above x + 1 = 1
         }
 
-        auto fetch = [&](int t) -> uint32_t {
+        // Source pixels come from the frame in memory or, for the rows SixelCanvas::Send
+        // appends, from the pad table in LDS.  The two are requested into SEPARATE registers
+        // and merged only when consumed: a merged register would make the LDS read wait for
+        // the global load (write-after-write), i.e. a memory round trip per step.
+        const bool wave_has_pad = __any(is_pad && has_row);
+        auto fetch_frame = [&](int t) -> uint32_t {
             const int x = t - 2 * lane;
-            return (has_row && x >= 0 && x < W) ? PaddedPixel(frame, g, x, row) : 0u;
+            uint32_t v  = 0u;
+            if (has_row && !is_pad && x >= 0 && x < W)
+                v = *reinterpret_cast<const uint32_t *>(src_row + (size_t)x * 4);
+            return v;
         };
-        auto step = [&](int t, uint32_t px) __attribute__((always_inline)) {
-            // the lane above is 2 columns ahead: its h1/h2/h3 are e(x+1), e(x), e(x-1)
-            uint32_t up_r = __shfl_up(h1, 1), up_c = __shfl_up(h2, 1), up_l = __shfl_up(h3, 1);
+        auto fetch_pad = [&](int t) -> uint32_t {
+            const int x = t - 2 * lane;
+            uint32_t v  = 0u;
+            if (wave_has_pad && has_row && is_pad && x >= 0 && x < W) v = pad_row[x];
+            return v;
+        };
+        auto step = [&](int t, uint32_t px_frame, uint32_t px_pad) __attribute__((always_inline)) {
+            const uint32_t px = is_pad ? px_pad : px_frame;
+            // the lane above is 2 columns ahead: its a1/b2/c3 belong to e(x+1), e(x), e(x-1)
+            uint32_t up_r = FromLaneAbove(a1), up_c = FromLaneAbove(b2), up_l = FromLaneAbove(c3);
             const int x = t - 2 * lane;
             if (lane == 0) {
                 up_l = bl;
                 up_c = bc;
                 up_r = br;
             }
-            uint32_t mine = kZeroErr;
+            ErrTerms mine = {0, 0, 0, 0};
             if (has_row && x >= 0 && x < W) {
                 int v[3] = {(int)(px & 0xffu), (int)((px >> 8) & 0xffu), (int)((px >> 16) & 0xffu)};
                 // arrival order of the contributions in raster order:
                 // (x-1,y-1) 1/16, (x,y-1) 5/16, (x+1,y-1) 3/16, [(0,y) 3/16], (x-1,y) 7/16
-                ApplyErr(v, up_l, 1);
-                ApplyErr(v, up_c, 5);
-                ApplyErr(v, up_r, 3);
-                if (x == W - 1 && W > 2) ApplyErr(v, first_err, 3);
-                ApplyErr(v, h1, 7);
-                if (x == W - 1 && W == 2) ApplyErr(v, first_err, 3);  // same source pixel: 7/16 first
+                ApplyTerm(v, up_l);
+                ApplyTerm(v, up_c);
+                ApplyTerm(v, up_r);
+                // the last pixel of a row also receives 3/16 of the row's FIRST error (its
+                // "below-left" neighbour in libsixel's linear addressing); for W == 2 that is
+                // the same source pixel as the 7/16 term, which then arrives first
+                const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
+                if (W > 2) {
+                    ApplyTerm(v, wrap);
+                    ApplyTerm(v, own7);
+                } else {
+                    ApplyTerm(v, own7);
+                    ApplyTerm(v, wrap);
+                }
                 const uint32_t cell = ((uint32_t)(v[0] >> 3) << 10) | ((uint32_t)(v[1] >> 3) << 5) |
                                       (uint32_t)(v[2] >> 3);
-                const uint32_t e = lut[cell];
-                if (dither && x < W - 1 && row < H - 1)
-                    mine = PackErr(v[0] - (int)((e >> 8) & 0xffu), v[1] - (int)((e >> 16) & 0xffu),
-                                   v[2] - (int)(e >> 24));
-                if (x == 0) first_err = mine;
-                // four indices per 32-bit store
+                const uint32_t e = pal[lut8[cell]];
+                const bool spread = diffuses && x < W - 1;
+                const int er = spread ? v[0] - (int)((e >> 8) & 0xffu) : 0;
+                const int eg = spread ? v[1] - (int)((e >> 16) & 0xffu) : 0;
+                const int eb = spread ? v[2] - (int)(e >> 24) : 0;
+                mine         = MakeTerms(er, eg, eb);
+                first_q3     = x == 0 ? mine.q3 : first_q3;
+                // four indices per 32-bit store (rows of the index image are padded to 4)
                 packed_idx |= (e & 0xffu) << (8 * (x & 3));
                 if ((x & 3) == 3 || x == W - 1) {
-                    uint8_t *dst = s.index + (size_t)row * W + (x & ~3);
-                    const int nb = (x & 3) + 1;
-                    if (nb == 4 && ((W & 3) == 0))
-                        *reinterpret_cast<uint32_t *>(dst) = packed_idx;
-                    else
-                        for (int k = 0; k < nb; ++k) dst[k] = (uint8_t)(packed_idx >> (8 * k));
+                    *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx;
                     packed_idx = 0;
                 }
                 if (lane == 63) {  // the row above the next wave's first row
-                    b_out[x] = mine;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    progress[wave] = out_base + x + 1;
+                    b_out[x]         = mine.q1;
+                    b_out[W + x]     = mine.q5;
+                    b_out[2 * W + x] = mine.q3;
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            h3 = h2;
-            h2 = h1;
-            h1 = mine;
+            own7 = mine.q7;
+            c3   = c2;
+            c2   = c1;
+            c1   = mine.q1;
+            b2   = b1;
+            b1   = mine.q5;
+            a1   = mine.q3;
             // lane 0's window over the boundary row moves one column to the right
             if (follows && t + 1 < W) {  // wave-uniform: lane 0 is at x = t
-                const int nx = t + 3;    // the step after this one needs boundary[t + 2]
+                const int nx = t + 3;    // the step after this one needs column t + 2
                 if (nx <= W) {
                     while (avail < nx) {
-                        avail = progress[producer] - in_base;
+                        avail = __hip_atomic_load(&progress[producer], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP) - in_base;
                         if (avail < nx) __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    asm volatile("" ::: "memory");
                 }
-                bl = bc;
-                bc = br;
-                br = t + 2 < W ? b_in[t + 2] : kZeroErr;
+                // next step lane 0 is at x = t + 1: 1/16 of column t, 5/16 of t + 1, 3/16 of t + 2
+                bl = b_in[t];
+                bc = b_in[W + t + 1];
+                br = t + 2 < W ? b_in[2 * W + t + 2] : 0u;
             }
         };
 
         static_assert(kDitherAhead == 8, "the pixel ring below is written out for 8 steps");
-        uint32_t p0 = fetch(0), p1 = fetch(1), p2 = fetch(2), p3 = fetch(3), p4 = fetch(4),
-                 p5 = fetch(5), p6 = fetch(6), p7 = fetch(7);
+        uint32_t p0 = fetch_frame(0), p1 = fetch_frame(1), p2 = fetch_frame(2), p3 = fetch_frame(3),
+                 p4 = fetch_frame(4), p5 = fetch_frame(5), p6 = fetch_frame(6), p7 = fetch_frame(7);
+        uint32_t q0 = fetch_pad(0), q1 = fetch_pad(1), q2 = fetch_pad(2), q3 = fetch_pad(3),
+                 q4 = fetch_pad(4), q5 = fetch_pad(5), q6 = fetch_pad(6), q7 = fetch_pad(7);
+#define TIMG_DITHER_STEP(k, P, Q)           \
+    if (t + k >= steps) break;              \
+    step(t + k, P, Q);                      \
+    P = fetch_frame(t + k + kDitherAhead);  \
+    Q = fetch_pad(t + k + kDitherAhead);
         for (int t = 0; t < steps; t += 8) {
-            step(t, p0);
-            p0 = fetch(t + 8);
-            if (t + 1 >= steps) break;
-            step(t + 1, p1);
-            p1 = fetch(t + 9);
-            if (t + 2 >= steps) break;
-            step(t + 2, p2);
-            p2 = fetch(t + 10);
-            if (t + 3 >= steps) break;
-            step(t + 3, p3);
-            p3 = fetch(t + 11);
-            if (t + 4 >= steps) break;
-            step(t + 4, p4);
-            p4 = fetch(t + 12);
-            if (t + 5 >= steps) break;
-            step(t + 5, p5);
-            p5 = fetch(t + 13);
-            if (t + 6 >= steps) break;
-            step(t + 6, p6);
-            p6 = fetch(t + 14);
-            if (t + 7 >= steps) break;
-            step(t + 7, p7);
-            p7 = fetch(t + 15);
+            TIMG_DITHER_STEP(0, p0, q0)
+            TIMG_DITHER_STEP(1, p1, q1)
+            TIMG_DITHER_STEP(2, p2, q2)
+            TIMG_DITHER_STEP(3, p3, q3)
+            TIMG_DITHER_STEP(4, p4, q4)
+            TIMG_DITHER_STEP(5, p5, q5)
+            TIMG_DITHER_STEP(6, p6, q6)
+            TIMG_DITHER_STEP(7, p7, q7)
         }
+#undef TIMG_DITHER_STEP
     }
 }
 
@@ -840,10 +914,10 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_t
 
 // distinct colours of one column of a band: up to 6 (colour, row mask) pairs in
 // order of first occurrence
-__device__ __forceinline__ int ColumnEntries(const uint8_t *rows, int W, int x, uint32_t ent[6]) {
+__device__ __forceinline__ int ColumnEntries(const uint8_t *rows, int stride, int x, uint32_t ent[6]) {
     uint32_t c[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) c[r] = rows[(size_t)r * W + x];
+    for (int r = 0; r < 6; ++r) c[r] = rows[(size_t)r * stride + x];
     uint32_t done = 0;
     int n         = 0;
 #pragma unroll
@@ -871,7 +945,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const int W               = g.w;
-    const uint8_t *rows       = s.index + (size_t)band * 6 * W;
+    const uint8_t *rows       = s.index + (size_t)band * 6 * g.idx_stride;
     const size_t slot         = (size_t)band * NE;
 
     // ---- entries, column-major: count, scan, write
@@ -879,12 +953,12 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     const int x0 = min(W, tid * per_c), x1 = min(W, x0 + per_c);
     uint32_t mine = 0;
     uint32_t e6[6];
-    for (int x = x0; x < x1; ++x) mine += (uint32_t)ColumnEntries(rows, W, x, e6);
+    for (int x = x0; x < x1; ++x) mine += (uint32_t)ColumnEntries(rows, g.idx_stride, x, e6);
     uint32_t n_ent_u;
     uint32_t at = BlockExclusiveScan(mine, s_tmp, &n_ent_u);
     const int n_ent = (int)n_ent_u;
     for (int x = x0; x < x1; ++x) {
-        const int n = ColumnEntries(rows, W, x, e6);
+        const int n = ColumnEntries(rows, g.idx_stride, x, e6);
         for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
         at += (uint32_t)n;
     }
@@ -1393,7 +1467,8 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_lut   = carve(nf * 32768 * 4);
     const size_t o_pal   = carve(nf * 768);
     const size_t o_meta  = carve(nf * 4 * sizeof(int));
-    const size_t o_idx   = carve(nf * (size_t)g.h6 * w);
+    g.idx_stride         = (w + 3) & ~3;
+    const size_t o_idx   = carve(nf * (size_t)g.h6 * g.idx_stride);
     const size_t o_bb    = carve(nf * g.bands * g.band_cap);
     const size_t o_bm    = carve(nf * g.bands * 4 * sizeof(int));
     const size_t o_bo    = carve(nf * g.bands * 2 * sizeof(uint32_t));
@@ -1434,10 +1509,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.out_cap    = out_cap;
     b.out_len    = (unsigned long long *)(base + o_len);
 
-    // one wave per 64 rows, as many as the boundary rows leave room for next to the 128 KiB LUT
+    // one wave per 64 rows, as many as the boundary rows leave room for next to the tables
     int dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + 63) / 64));
     auto dither_bytes = [&](int waves) {
-        return (32768 + (size_t)waves * w + kDitherMaxWaves) * sizeof(uint32_t);
+        return (8192 + 256 + (size_t)(g.h6 - h) * w + (size_t)waves * 3 * w) * sizeof(uint32_t);
     };
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);

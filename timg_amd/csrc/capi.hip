@@ -94,6 +94,11 @@ void timg_hip_destroy(timg_hip_ctx *ctx) {
     for (auto &b : ctx->dev) b.Release();
     for (auto &b : ctx->pin) b.Release();
     (void)hipStreamDestroy(ctx->stream);
+    for (auto st : ctx->side)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto ev : ctx->join_event)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     delete ctx;
 }
 

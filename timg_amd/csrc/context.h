@@ -61,6 +61,25 @@ struct timg_hip_ctx {
     TimgBuffer dev[8];
     TimgBuffer pin[4];
 
+    // Side streams for kernels that are latency-bound on a handful of CUs (the serial
+    // stages of the sixel canvas): a batch is cut into groups whose chains run
+    // concurrently, forked from and joined to the caller's stream with events.
+    static constexpr int kSideStreams = 4;
+    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr, join_event[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t EnsureSideStreams() {
+        if (fork_event) return hipSuccess;
+        for (auto &st : side) {
+            hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+        }
+        for (auto &ev : join_event) {
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        return hipEventCreateWithFlags(&fork_event, hipEventDisableTiming);
+    }
+
     timg_hip_ctx() {
         for (auto &p : pin) p.pinned = true;
     }

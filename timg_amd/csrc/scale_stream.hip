@@ -310,7 +310,7 @@ __device__ bool RunTile(const TileCtx &c) {
         // Fully transparent pixels announce filtered alphas of (or below) zero, which
         // need the straight RGB sums: give the tile to the full channel set right away
         // instead of discovering it output pixel by output pixel.
-        if (M == kPremult) ok = ok && min(min(q.x, q.y), min(q.z, q.w)) >= 0x01000000u;
+        if (M == kPremult) ok = ok && min(min(q.x, q.y), min(q.z, q.w)) >= (uint32_t)0x01000000u;
         float d[kPix][kCh];
         DecodeMode<M>(q.x, d[0]);
         DecodeMode<M>(q.y, d[1]);

@@ -17,6 +17,7 @@
 //                               nodes -> libsixel's greedy packing -> RLE bytes
 //   K6 AssembleFrame / CopyBands  header, palette, band offsets, compaction
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "context.h"
@@ -1528,21 +1529,72 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kCutLdsBytes));
-    const size_t nbins = nf * 32768;
-    hipLaunchKernelGGL(InitHistKernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, st,
-                       b.hist_cnt, b.hist_first, nbins);
-    const dim3 sgrid((g.n_samples + 255) / 256, n_frames);
-    hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(MedianCutKernel, dim3(n_frames), dim3(kCutWaves * 64), kCutLdsBytes, st, g, b);
-    hipLaunchKernelGGL(BuildLutKernel, dim3(128, n_frames), dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(DitherKernel, dim3(n_frames), dim3(dither_waves * 64), dither_lds, st, g, b);
-    hipLaunchKernelGGL(BandNodesKernel, dim3(g.bands, n_frames), dim3(256), nodes_lds, st, g, b);
-    hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * n_frames + 3) / 4), dim3(256), 0, st, g, b,
-                       n_frames);
-    hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, n_frames), dim3(256), emit_lds, st, g, b);
-    hipLaunchKernelGGL(AssembleFrameKernel, dim3(n_frames), dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(CopyBandsKernel, dim3(g.bands, n_frames), dim3(256), 0, st, g, b);
+    // The palette (median cut) and diffusion kernels are serial per frame: one workgroup
+    // per frame, microseconds of dependent steps, a few dozen CUs busy.  The batch can be
+    // cut into groups whose kernel chains run on side streams (one group's median cut next
+    // to another group's diffusion).  MEASURED on MI355X / ROCm 7.2: every extra group costs
+    // ~1.8 ms of cross-queue event hand-over per 64-frame batch (1 group 2.8 ms, 2 groups
+    // 4.7 ms, 4 groups 6.3 ms), far more than the overlap wins -- so the default is ONE
+    // group; TIMG_HIP_SIXEL_GROUPS keeps the experiment reproducible.
+    int n_groups = 1;
+    if (const char *e = getenv("TIMG_HIP_SIXEL_GROUPS"))  // tuning
+        n_groups = std::max(1, std::min(atoi(e), std::min(n_frames, (int)timg_hip_ctx::kSideStreams)));
+    if (n_groups > 1) {
+        TIMG_HIP_TRY(ctx, ctx->EnsureSideStreams());
+        TIMG_HIP_TRY(ctx, hipEventRecord(ctx->fork_event, st));
+    }
+    for (int grp = 0; grp < n_groups; ++grp) {
+        const int f0 = (int)((long long)n_frames * grp / n_groups);
+        const int f1 = (int)((long long)n_frames * (grp + 1) / n_groups);
+        const int nfr = f1 - f0;
+        if (nfr <= 0) continue;
+        hipStream_t gs = n_groups > 1 ? ctx->side[grp] : st;
+        if (n_groups > 1) TIMG_HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->fork_event, 0));
+        // the group's view of the batch: every per-frame array starts at frame f0
+        SixelBatch gb = b;
+        const size_t o = (size_t)f0;
+        gb.fb          = b.fb + o * g.frame_stride;
+        gb.hist_cnt    = b.hist_cnt + o * 32768;
+        gb.hist_first  = b.hist_first + o * 32768;
+        gb.entries     = b.entries + o * g.n_samples;
+        gb.tab_a       = b.tab_a + o * 32768;
+        gb.tab_b       = b.tab_b + o * 32768;
+        gb.lut         = b.lut + o * 32768;
+        gb.palette     = b.palette + o * 768;
+        gb.meta        = b.meta + o * 4;
+        gb.index       = b.index + o * g.h6 * g.idx_stride;
+        gb.band_bytes  = b.band_bytes + o * g.bands * g.band_cap;
+        gb.band_meta   = b.band_meta + o * g.bands * 4;
+        gb.band_off    = b.band_off + o * g.bands * 2;
+        gb.band_ent    = b.band_ent + o * g.bands * g.band_ne;
+        gb.band_nkey   = b.band_nkey + o * g.bands * g.band_ne;
+        gb.band_nfirst = b.band_nfirst + o * g.bands * g.band_ne;
+        gb.band_pi     = b.band_pi + o * g.bands * g.band_ne;
+        gb.band_xs     = b.band_xs + o * g.bands * g.band_ne;
+        gb.band_pbase  = b.band_pbase + o * g.bands * 256;
+        gb.band_cnt    = b.band_cnt + o * g.bands * 4;
+        gb.out         = b.out + o * b.out_cap;
+        gb.out_len     = b.out_len + o;
+
+        const size_t nbins = (size_t)nfr * 32768;
+        hipLaunchKernelGGL(InitHistKernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, gs,
+                           gb.hist_cnt, gb.hist_first, nbins);
+        const dim3 sgrid((g.n_samples + 255) / 256, nfr);
+        hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
+        hipLaunchKernelGGL(BuildLutKernel, dim3(128, nfr), dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(DitherKernel, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+        hipLaunchKernelGGL(BandNodesKernel, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
+        hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * nfr + 3) / 4), dim3(256), 0, gs, g, gb, nfr);
+        hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, nfr), dim3(256), emit_lds, gs, g, gb);
+        hipLaunchKernelGGL(AssembleFrameKernel, dim3(nfr), dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(CopyBandsKernel, dim3(g.bands, nfr), dim3(256), 0, gs, g, gb);
+        if (n_groups > 1) {
+            TIMG_HIP_TRY(ctx, hipEventRecord(ctx->join_event[grp], gs));
+            TIMG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->join_event[grp], 0));
+        }
+    }
     TIMG_HIP_TRY(ctx, hipGetLastError());
 
     TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * nf));

@@ -230,6 +230,34 @@ def test_sixel_batch_device_resident(hip, oracle):
     hip.free(d)
 
 
+@pytest.mark.parametrize("kind,w,h", [
+    ("noise", 800, 450),   # > 8192 distinct colours: median cut runs on the global-memory table
+    ("photo", 64, 1100),   # 1104 padded rows: the diffusion pipeline goes round twice (16 waves x 64 rows)
+    ("alpha", 801, 77),    # odd width: padded index rows, pad rows (77 -> 78) with a checkerboard
+    ("photo", 1365, 30),   # widest frame the band encoder takes
+    ("noise", 3, 130),     # narrower than the row skew
+])
+def test_sixel_geometry_corner_cases(hip, oracle, kind, w, h):
+    fb = synth.make(kind, w, h, seed=17)
+    got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3),
+                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 5, 3, lookup_mode=1)
+    assert len(got) == len(want) and got == want, (len(got), len(want))
+
+
+def test_sixel_round_trip_decodes_to_the_palette_image(hip, oracle):
+    """Size-independent property at the BASELINE frame size: the stream decodes (independent
+    decoder) to a full 800x450 raster whose every pixel is a palette colour close to the
+    source -- mean error well below a just-noticeable step thanks to the diffusion."""
+    fb = synth.photo(800, 450, seed=21)
+    data = hip.sixel_encode(fb, 800, 450, pad_blend=timg_amd.Blend.make(BG))[0]
+    img, ncolors = oracle.sixel_decode(data)
+    assert img.shape[:2] == (450, 800) and 2 <= ncolors <= 256
+    assert (img[..., 3] == 255).all()
+    err = np.abs(img[..., :3].astype(np.int32) - fb[..., :3].astype(np.int32))
+    assert err.mean() < 12.0 and np.percentile(err, 99) < 80
+
+
 def test_sixel_too_wide_is_refused(hip):
     fb = np.zeros((6, 1400, 4), np.uint8)
     with pytest.raises(timg_amd.TimgHipError) as e:
@@ -273,6 +301,36 @@ def test_streaming_batch_with_blend_matches_generic(hip):
         outs.append(dst.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     sc.close()
+
+
+def test_baseline_config5_8k_alpha_checkerboard_sixel(hip, oracle):
+    """BASELINE.json config 5, one frame: 7680x4320 RGBA with alpha -> 800x450 with a
+    checkerboard background (-b colour -B colour) -> sixel, against the oracle end to end."""
+    src = synth.alpha(7680, 4320, seed=5)
+    blend = timg_amd.Blend.make(BG, PAT, 18, 18)
+    got = hip.scale(src, 800, 450, blend=blend)
+    want, _ = oracle.alpha_compose(oracle.scale(src, 800, 450), BG, PAT, 18, 18)
+    assert np.array_equal(got, want)
+    six = hip.sixel_encode(got, 800, 450, pad_blend=blend)[0]
+    assert six == oracle.sixel_encode(want, BG, PAT, 18, 18, lookup_mode=1)
+
+
+def test_baseline_config4_video_frames_round_robin(hip, oracle):
+    """BASELINE.json config 4 in miniature: a stream of frames sharded round-robin over
+    `world` ranks, every rank encodes its share as one batch, the gather restores stream
+    order.  (Ranks are emulated in-process: the exchange itself is covered by
+    tests/test_gather_gloo.py, the GPUs by bench.py --gpus N.)"""
+    from timg_amd.gather import shard_frames
+    n, world, w, h = 12, 4, 160, 90
+    frames = [synth.photo(w, h, seed=100 + i) for i in range(n)]
+    per_rank = []
+    for rank in range(world):
+        mine = shard_frames(n, world, rank, round_robin=True)
+        batch = np.stack([frames[i] for i in mine])
+        per_rank.append(dict(zip(mine, hip.sixel_encode(batch, w, h, n_frames=len(mine),
+                                                        pad_blend=timg_amd.Blend.make(BG)))))
+    for i in range(n):
+        assert per_rank[i % world][i] == oracle.sixel_encode(frames[i], BG), i
 
 
 def test_streaming_fallback_chain_on_mixed_tiles(hip, oracle):

@@ -39,7 +39,9 @@ constexpr int kPix       = 4;    // source columns per lane (16-byte loads)
 constexpr int kSlots     = 5;    // output rows in flight per lane
 constexpr int kThreads   = 256;
 constexpr int kStripCols = kPix * kThreads;
-constexpr int kStage     = 2;    // staging rows (and: rows that may complete on one source row)
+// staging rows in LDS: two for the 3/4-channel sets (one barrier per completed row), one
+// for the 7-channel set (a second barrier per completed row, but half the LDS: two
+// workgroups per CU instead of one)
 constexpr int kPrefetch  = 4;    // source rows in flight per lane
 constexpr int kLdsCoeffFloats = 12 * 1024;  // horizontal weights kept in LDS up to this many
 
@@ -104,9 +106,9 @@ __device__ __forceinline__ T LoadConstant(const T *p) {
 // with the next one, so the result never depends on the shortcut.
 enum Mode { kOpaque = 0, kPremult = 1, kFull = 2 };
 template <int M> struct ModeTraits;
-template <> struct ModeTraits<kOpaque>  { static constexpr int kCh = 3, kStride = 4; };
-template <> struct ModeTraits<kPremult> { static constexpr int kCh = 4, kStride = 4; };
-template <> struct ModeTraits<kFull>    { static constexpr int kCh = 7, kStride = 8; };
+template <> struct ModeTraits<kOpaque>  { static constexpr int kCh = 3, kStride = 4, kStage = 2; };
+template <> struct ModeTraits<kPremult> { static constexpr int kCh = 4, kStride = 4, kStage = 2; };
+template <> struct ModeTraits<kFull>    { static constexpr int kCh = 7, kStride = 8, kStage = 1; };
 
 template <int M>
 __device__ __forceinline__ void DecodeMode(uint32_t px, float out[ModeTraits<M>::kCh]) {
@@ -163,7 +165,7 @@ struct TileCtx {
     BandInfo bi;
     const RowSched *sched;
     int f;
-    float *stage;    // kStage * kStripCols * kStride floats
+    float *stage;    // ModeTraits::kStage * kStripCols * kStride floats
     float *hcoef;    // h_width * hrow floats (k-major)
     int2 *htaps;     // hrow entries {first tap - cx0, tap count}
     int hrow;        // outputs per strip rounded up (row length of hcoef)
@@ -276,10 +278,11 @@ __device__ bool RunTile(const TileCtx &c) {
     const uint32_t lane_off = (uint32_t)min(col0, plan.in_w - kPix) * 4u;
     const uint8_t *frame    = batch.src + (size_t)c.f * batch.src_frame_stride;
     int *flag               = batch.transparent_flags ? batch.transparent_flags + c.f : nullptr;
-    const int r1            = c.bi.r1;
+    const int r1            = c.bi.r1;                   // may lie past the image: see BuildVariant
+    const int r_last        = min(r1, plan.in_h - 1);    // last row that exists
 
     auto load_row = [&](int r) -> uint4 {
-        const uint8_t *row = frame + (size_t)min(r, r1) * batch.src_stride;  // uniform
+        const uint8_t *row = frame + (size_t)min(r, r_last) * batch.src_stride;  // uniform
         return *reinterpret_cast<const uint4 *>(row + lane_off);
     };
 
@@ -317,8 +320,10 @@ __device__ bool RunTile(const TileCtx &c) {
         DecodeMode<M>(q.z, d[2]);
         DecodeMode<M>(q.w, d[3]);
 
-        int n_done = 0;
-        int done_y[kStage] = {0, 0};
+        // (the schedule never lets two output rows complete on the same source row)
+        bool done = false;
+        int done_y = 0;
+        constexpr int kStage = ModeTraits<M>::kStage;
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
             const int fl = rs.flags[s];
@@ -331,10 +336,7 @@ __device__ bool RunTile(const TileCtx &c) {
 #pragma unroll
                 for (int ch = 0; ch < kCh; ++ch) acc[s][p][ch] = acc[s][p][ch] + d[p][ch] * w;
             if (fl & 4) {
-                // a second row completing on this source row takes the staging row the
-                // PREVIOUS completion used: wait until every wave is done reading it
-                if (n_done) __syncthreads();
-                float *row = c.stage + (size_t)((ev + n_done) & (kStage - 1)) * kStripCols * kStride;
+                float *row = c.stage + (size_t)(ev & (kStage - 1)) * kStripCols * kStride;
 #pragma unroll
                 for (int p = 0; p < kPix; ++p) {
                     float *dst = row + (size_t)(tid * kPix + p) * kStride;
@@ -363,19 +365,18 @@ __device__ bool RunTile(const TileCtx &c) {
                 for (int p = 0; p < kPix; ++p)
 #pragma unroll
                     for (int ch = 0; ch < kCh; ++ch) acc[s][p][ch] = 0.0f;
-                done_y[n_done & 1] = fl >> 8;
-                ++n_done;
+                done   = true;
+                done_y = fl >> 8;
             }
         }
-        if (n_done) {  // wave- and block-uniform
+        if (done) {  // wave- and block-uniform
             if (M != kFull && __any(!ok) && (tid & 63) == 0) *c.fail = 1;
             __syncthreads();
             if (M != kFull && *c.fail) return false;
-            for (int j = 0; j < n_done; ++j)
-                HorizontalRow<M>(c, c.stage + (size_t)((ev + j) & (kStage - 1)) * kStripCols * kStride,
-                                 j ? done_y[1] : done_y[0], flag, &ok);
-            if (n_done > 1) __syncthreads();  // both staging rows were in use
-            ev += n_done;
+            HorizontalRow<M>(c, c.stage + (size_t)(ev & (kStage - 1)) * kStripCols * kStride, done_y, flag,
+                             &ok);
+            if (kStage == 1) __syncthreads();  // the single staging row is free again
+            ++ev;
         }
         return true;
     };
@@ -426,7 +427,7 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
     c.sched      = tab.sched + c.bi.sched;
     c.f          = blockIdx.z;
     c.stage      = lds;
-    c.htaps      = reinterpret_cast<int2 *>(lds + kStage * kStripCols * ModeTraits<M>::kStride);
+    c.htaps      = reinterpret_cast<int2 *>(lds + ModeTraits<M>::kStage * kStripCols * ModeTraits<M>::kStride);
     c.hcoef      = reinterpret_cast<float *>(c.htaps + hrow);
     c.hrow       = hrow;
     c.fail       = &fail;
@@ -476,7 +477,18 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
         b.oy0   = oy;
         b.oy1   = std::min(p.out_h, oy + band_rows);
         b.r0    = first[b.oy0];
-        b.r1    = last[b.oy1 - 1];
+        // The kernel stages at most one completed output row per source row.  Where the
+        // clamped edge makes two rows end on the same source row (the last two rows of a
+        // frame), the later one is completed one row further down by a tap of weight 0 on a
+        // virtual source row (it re-reads the last real row): acc + d * 0 == acc, so the sum
+        // is untouched.  comp[y] = source row on which output row y is staged.
+        std::vector<int> comp(b.oy1 - b.oy0);
+        for (int y = b.oy0; y < b.oy1; ++y) {
+            int c = last[y];
+            if (y > b.oy0) c = std::max(c, comp[y - 1 - b.oy0] + 1);
+            comp[y - b.oy0] = c;
+        }
+        b.r1    = comp.back();
         b.sched = (int)sched.size();
         RowSched blank;
         memset(&blank, 0, sizeof(blank));
@@ -489,13 +501,21 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
                 const float w = p.v_coeff[r.first + j];
                 alpha         = j == 0 ? 1.0f * w : alpha + 1.0f * w;
             }
+            const int s      = y % kSlots;
+            const int done_r = comp[y - b.oy0];
             for (int j = 0; j < r.count; ++j) {
-                RowSched &e = sched[(size_t)b.sched + (size_t)(p.v_rows[r.first + j] - b.r0)];
-                const int s = y % kSlots;
-                e.weight[s] = p.v_coeff[r.first + j];
-                e.flags[s]  = 1 | (j == 0 ? 2 : 0) | (j == r.count - 1 ? 4 : 0) | (y << 8);
-                if (j == r.count - 1) e.alpha_sum[s] = alpha;
+                const int row = p.v_rows[r.first + j];
+                RowSched &e   = sched[(size_t)b.sched + (size_t)(row - b.r0)];
+                e.weight[s]   = p.v_coeff[r.first + j];
+                e.flags[s]    = 1 | (y << 8);
             }
+            RowSched &e = sched[(size_t)b.sched + (size_t)(done_r - b.r0)];
+            if (!(e.flags[s] & 1)) {  // virtual tap of weight 0
+                e.weight[s] = 0.0f;
+                e.flags[s]  = 1 | (y << 8);
+            }
+            e.flags[s] |= 4;
+            e.alpha_sum[s] = alpha;
         }
         bands.push_back(b);
     }
@@ -549,12 +569,17 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
         for (int j = 1; j < r.count; ++j)
             if (p.v_rows[r.first + j] <= p.v_rows[r.first + j - 1]) return no("rows not ascending");
     }
-    for (int y = 0; y + kSlots < p.out_h; ++y)
-        if (last[y] >= first[y + kSlots]) return no("slot reuse conflict");
+    {
+        // the row an output row is staged on (BuildVariant spreads rows that end together;
+        // per band it can only be earlier than this whole-frame bound)
+        int comp = -1;
+        for (int y = 0; y < p.out_h; ++y) {
+            comp = std::max(last[y], comp + 1);
+            if (y + kSlots < p.out_h && comp >= first[y + kSlots]) return no("slot reuse conflict");
+        }
+    }
     for (int y = 1; y < p.out_h; ++y)
         if (last[y] < last[y - 1] || first[y] < first[y - 1]) return no("non-monotonic rows");
-    for (int y = 0; y + kStage < p.out_h; ++y)
-        if (last[y] == last[y + kStage]) return no("too many rows complete together");
 
     // strips: as many output columns as fit with all their taps in kStripCols source columns
     std::vector<StripInfo> strips;
@@ -613,7 +638,7 @@ template <int M>
 static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
                              const StreamVariant &v, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream) {
-    const size_t lds = ((size_t)kStage * kStripCols * ModeTraits<M>::kStride + 2 * (size_t)ss->hrow +
+    const size_t lds = ((size_t)ModeTraits<M>::kStage * kStripCols * ModeTraits<M>::kStride + 2 * (size_t)ss->hrow +
                         (size_t)s->plan.h_width * ss->hrow) * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {

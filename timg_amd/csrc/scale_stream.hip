@@ -106,8 +106,14 @@ __device__ __forceinline__ T LoadConstant(const T *p) {
 // with the next one, so the result never depends on the shortcut.
 enum Mode { kOpaque = 0, kPremult = 1, kFull = 2 };
 template <int M> struct ModeTraits;
-template <> struct ModeTraits<kOpaque>  { static constexpr int kCh = 3, kStride = 4, kStage = 2; };
-template <> struct ModeTraits<kPremult> { static constexpr int kCh = 4, kStride = 4, kStage = 2; };
+#ifndef TIMG_STAGE_ROWS
+#define TIMG_STAGE_ROWS 2
+#endif
+#ifndef TIMG_OPAQUE_WAVES
+#define TIMG_OPAQUE_WAVES 3
+#endif
+template <> struct ModeTraits<kOpaque>  { static constexpr int kCh = 3, kStride = 4, kStage = TIMG_STAGE_ROWS; };
+template <> struct ModeTraits<kPremult> { static constexpr int kCh = 4, kStride = 4, kStage = TIMG_STAGE_ROWS; };
 template <> struct ModeTraits<kFull>    { static constexpr int kCh = 7, kStride = 8, kStage = 1; };
 
 template <int M>
@@ -313,7 +319,7 @@ __device__ bool RunTile(const TileCtx &c) {
         // Fully transparent pixels announce filtered alphas of (or below) zero, which
         // need the straight RGB sums: give the tile to the full channel set right away
         // instead of discovering it output pixel by output pixel.
-        if (M == kPremult) ok = ok && min(min(q.x, q.y), min(q.z, q.w)) >= (uint32_t)0x01000000u;
+        if (M == kPremult) ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
         float d[kPix][kCh];
         DecodeMode<M>(q.x, d[0]);
         DecodeMode<M>(q.y, d[1]);
@@ -411,7 +417,7 @@ __device__ bool RunTile(const TileCtx &c) {
 // 0 = not produced yet, 1 = done.  A kernel skips tiles that are done and marks
 // the ones it completes.
 template <int M>
-__global__ void __launch_bounds__(kThreads, M == kFull ? 2 : 3)
+__global__ void __launch_bounds__(kThreads, M == kFull ? 2 : (M == kOpaque ? TIMG_OPAQUE_WAVES : 3))
 ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch,
                   int *tile_state, int hrow) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

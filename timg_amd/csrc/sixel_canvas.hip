@@ -354,26 +354,44 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     const int tid  = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t *scratch = cut_lds + 2 * kCutLdsEntries + wave * kCutScratch;
 
-    // compact the first-seen entries (stable) into tab_a  (one wave: order matters)
-    if (wave == 0) {
-        uint32_t n = 0, total = 0;
-        for (uint32_t k0 = 0; k0 < g.n_samples; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
-            const unsigned long long m = __ballot(e != 0);
-            if (e) s.tab_a[n + __popcll(m & lt_mask)] = e;
-            n += __popcll(m);
-            uint32_t c = e >> 15;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-            total += c;
+    // compact the first-seen entries (stable: sample order) into tab_a -- a contiguous
+    // chunk of samples per thread, block-wide exclusive scan of the chunk counts
+    {
+        __shared__ uint32_t s_wave_cnt[kCutWaves], s_wave_sum[kCutWaves];
+        const uint32_t per = (g.n_samples + blockDim.x - 1) / blockDim.x;
+        const uint32_t k0 = min(g.n_samples, (uint32_t)tid * per), k1 = min(g.n_samples, k0 + per);
+        uint32_t cnt = 0, sum = 0;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t e = s.entries[k];
+            cnt += e != 0 ? 1u : 0u;
+            sum += e >> 15;
         }
-        if (lane == 0) {
-            s_n     = n;
-            s_total = total;
+        uint32_t incl = cnt, tot = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+        if (lane == 63) s_wave_cnt[wave] = incl;
+        if (lane == 0) s_wave_sum[wave] = tot;
+        __syncthreads();
+        uint32_t at = incl - cnt, n_all = 0, sum_all = 0;
+        for (int w = 0; w < kCutWaves; ++w) {
+            if (w < wave) at += s_wave_cnt[w];
+            n_all += s_wave_cnt[w];
+            sum_all += s_wave_sum[w];
+        }
+        for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t e = s.entries[k];
+            if (e) s.tab_a[at++] = e;
+        }
+        if (tid == 0) {
+            s_n     = n_all;
+            s_total = sum_all;
         }
     }
     __threadfence_block();
@@ -533,24 +551,27 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b) {
     const int f               = blockIdx.y;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    __shared__ uint8_t pal[768];
+    __shared__ uint32_t pal[kMaxColors];  // r | g << 8 | b << 16: one broadcast read per entry
     const int ncolors = s.meta[0];
-    for (int i = threadIdx.x; i < ncolors * 3; i += 256) pal[i] = s.palette[i];
+    for (int i = threadIdx.x; i < ncolors; i += 256)
+        pal[i] = (uint32_t)s.palette[i * 3] | ((uint32_t)s.palette[i * 3 + 1] << 8) |
+                 ((uint32_t)s.palette[i * 3 + 2] << 16);
     __syncthreads();
     const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
     const int r = (int)(((cell >> 10) & 0x1f) << 3 | 4), gg = (int)(((cell >> 5) & 0x1f) << 3 | 4),
               bl = (int)((cell & 0x1f) << 3 | 4);
     int best = 0, diff = 0x7fffffff;
+#pragma unroll 4
     for (int i = 0; i < ncolors; ++i) {
-        const int dr = r - pal[i * 3], dg = gg - pal[i * 3 + 1], db = bl - pal[i * 3 + 2];
+        const uint32_t c = pal[i];
+        const int dr = r - (int)(c & 0xffu), dg = gg - (int)((c >> 8) & 0xffu), db = bl - (int)((c >> 16) & 0xffu);
         const int d  = dr * dr + dg * dg + db * db;
-        if (d < diff) {
+        if (d < diff) {  // strict: the first of equally near entries wins
             diff = d;
             best = i;
         }
     }
-    s.lut[cell] = (uint32_t)best | ((uint32_t)pal[best * 3] << 8) |
-                  ((uint32_t)pal[best * 3 + 1] << 16) | ((uint32_t)pal[best * 3 + 2] << 24);
+    s.lut[cell] = (uint32_t)best | (pal[best] << 8);
 }
 
 // ---- K4: lookup + Floyd-Steinberg -----------------------------------------------------

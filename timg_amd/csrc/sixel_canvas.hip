@@ -166,8 +166,11 @@ __global__ void __launch_bounds__(256) MarkFirstKernel(SixelGeom g, SixelBatch b
 // Inside a split: boxes of <= 64 colours are sorted in registers with ballots, larger
 // ones by a stable per-lane-segment counting sort on the 5-bit key.
 constexpr int kCutWaves      = 8;
-constexpr int kCutLdsEntries = 8192;              // colour table kept in LDS up to this size
-constexpr int kCutScratch    = 64 * 33 + 96;      // words of per-wave scratch
+constexpr int kCutLdsEntries = 12288;             // colour table kept in LDS up to this size
+// words of per-wave scratch: [64][33] 16-bit counters (a lane's segment of a box and every
+// exclusive prefix stay below 65536: a box has at most 32768 colours), 32 + 32 key totals /
+// bases, and 64 words for the register sort's permutation
+constexpr int kCutScratch    = 64 * 33 / 2 + 64 + 64;
 constexpr size_t kCutLdsBytes =
     ((size_t)2 * kCutLdsEntries + (size_t)kCutWaves * kCutScratch) * sizeof(uint32_t);
 
@@ -190,9 +193,10 @@ struct CutBox {
 // the median.  scratch: kCutScratch words owned by this wave.
 __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *scratch, int lane,
                          uint32_t *median_out, uint32_t *lowersum_out) {
-    uint32_t *lane_cnt    = scratch;             // [64][33]
-    uint32_t *s_key_total = scratch + 64 * 33;   // [32]
-    uint32_t *s_key_base  = s_key_total + 32;    // [32]
+    uint16_t *lane_cnt    = reinterpret_cast<uint16_t *>(scratch);  // [64][33]
+    uint32_t *s_key_total = scratch + 64 * 33 / 2;                  // [32]
+    uint32_t *s_key_base  = s_key_total + 32;                       // [32]
+    uint32_t *perm        = s_key_base + 32;                        // [64]
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t *src = tab[box.buf] + box.ind;
     uint32_t *dst       = tab[box.buf ^ 1u] + box.ind;
@@ -246,10 +250,10 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
             const unsigned long long ones = __ballot(one);
             const int n_zero   = 64 - __popcll(ones);
             const int dest     = one ? n_zero + __popcll(ones & lt_mask) : __popcll(~ones & lt_mask);
-            // forward permutation through LDS (the lane-count scratch is free here)
-            lane_cnt[dest] = e;
+            // forward permutation through LDS
+            perm[dest] = e;
             TIMG_WAVE_SYNC();
-            e = lane_cnt[lane];
+            e = perm[lane];
             TIMG_WAVE_SYNC();
         }
         if (live) dst[lane] = e;
@@ -271,7 +275,7 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         const uint32_t seg = (((box.colors + 63) / 64) | 1u);
         const uint32_t a   = min(box.colors, (uint32_t)lane * seg);
         const uint32_t z   = min(box.colors, a + seg);
-        uint32_t *mine     = lane_cnt + lane * 33;
+        uint16_t *mine     = lane_cnt + lane * 33;
         for (int k = 0; k < 32; ++k) mine[k] = 0;
         for (uint32_t i = a; i < z; ++i) mine[PlaneKey(src[i], plane)] += 1;
         TIMG_WAVE_SYNC();
@@ -282,13 +286,13 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
             uint32_t run = 0;
             for (int l = l0; l < l0 + 32; ++l) {
                 const uint32_t t       = lane_cnt[l * 33 + key];
-                lane_cnt[l * 33 + key] = run;
+                lane_cnt[l * 33 + key] = (uint16_t)run;
                 run += t;
             }
             TIMG_WAVE_SYNC();
             const uint32_t lower = __shfl(run, key);        // total of lanes 0-31 for this key
             if (lane >= 32)
-                for (int l = 32; l < 64; ++l) lane_cnt[l * 33 + key] += lower;
+                for (int l = 32; l < 64; ++l) lane_cnt[l * 33 + key] = (uint16_t)(lane_cnt[l * 33 + key] + lower);
             const uint32_t total = lower + __shfl(run, 32 + key);
             if (lane < 32) s_key_total[lane] = total;
             uint32_t incl = lane < 32 ? total : 0u;
@@ -304,7 +308,7 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
             const uint32_t e   = src[i];
             const uint32_t k   = PlaneKey(e, plane);
             const uint32_t off = mine[k];
-            mine[k]            = off + 1;
+            mine[k]            = (uint16_t)(off + 1);
             dst[s_key_base[k] + off] = e;
         }
         __threadfence_block();
@@ -348,7 +352,12 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
 
 __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t cut_lds[];
-    __shared__ CutBox box_a[kMaxColors], box_b[kMaxColors];
+#ifdef TIMG_CUT_TRACE
+    const long long t_kernel = wall_clock64();
+#endif
+    __shared__ CutBox box_a[2 * kMaxColors];
+    CutBox *box_b = box_a + kMaxColors;
+    __shared__ uint32_t l_id[2][kMaxColors], l_sum[2][kMaxColors], l_col[2][kMaxColors];
     __shared__ uint32_t s_n, s_total, s_nboxes, s_done, s_flip;
     const int f    = blockIdx.x;
     const int tid  = threadIdx.x;
@@ -356,38 +365,41 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     const SixelFrameScratch s = FrameScratch(b, g, f);
     uint32_t *scratch = cut_lds + 2 * kCutLdsEntries + wave * kCutScratch;
 
-    // compact the first-seen entries (stable: sample order) into tab_a -- a contiguous
-    // chunk of samples per thread, block-wide exclusive scan of the chunk counts
+    // compact the first-seen entries (stable: sample order) into tab_a: every wave takes a
+    // contiguous range of samples in coalesced chunks of 64, counts with ballots, and the
+    // ranges are stitched together by a scan over the waves
     {
         __shared__ uint32_t s_wave_cnt[kCutWaves], s_wave_sum[kCutWaves];
-        const uint32_t per = (g.n_samples + blockDim.x - 1) / blockDim.x;
-        const uint32_t k0 = min(g.n_samples, (uint32_t)tid * per), k1 = min(g.n_samples, k0 + per);
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        const uint32_t chunks = (g.n_samples + 63) / 64;
+        const uint32_t per    = (chunks + kCutWaves - 1) / kCutWaves;
+        const uint32_t c0 = min(chunks, (uint32_t)wave * per), c1 = min(chunks, c0 + per);
         uint32_t cnt = 0, sum = 0;
-        for (uint32_t k = k0; k < k1; ++k) {
-            const uint32_t e = s.entries[k];
-            cnt += e != 0 ? 1u : 0u;
+        for (uint32_t c = c0; c < c1; ++c) {
+            const uint32_t k = c * 64 + lane;
+            const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
+            cnt += (uint32_t)__popcll(__ballot(e != 0));
             sum += e >> 15;
         }
-        uint32_t incl = cnt, tot = sum;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) {
+            s_wave_cnt[wave] = cnt;
+            s_wave_sum[wave] = sum;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-        if (lane == 63) s_wave_cnt[wave] = incl;
-        if (lane == 0) s_wave_sum[wave] = tot;
         __syncthreads();
-        uint32_t at = incl - cnt, n_all = 0, sum_all = 0;
+        uint32_t at = 0, n_all = 0, sum_all = 0;
         for (int w = 0; w < kCutWaves; ++w) {
             if (w < wave) at += s_wave_cnt[w];
             n_all += s_wave_cnt[w];
             sum_all += s_wave_sum[w];
         }
-        for (uint32_t k = k0; k < k1; ++k) {
-            const uint32_t e = s.entries[k];
-            if (e) s.tab_a[at++] = e;
+        for (uint32_t c = c0; c < c1; ++c) {
+            const uint32_t k = c * 64 + lane;
+            const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
+            const unsigned long long m = __ballot(e != 0);
+            if (e) s.tab_a[at + (uint32_t)__popcll(m & lt_mask)] = e;
+            at += (uint32_t)__popcll(m);
         }
         if (tid == 0) {
             s_n     = n_all;
@@ -421,63 +433,99 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         tab[0] = s.tab_a;
         tab[1] = s.tab_b;
     }
+    // Boxes live in a pool and never move; the sum-descending LIST holds, per position,
+    // the box id plus copies of what the bookkeeping scans: sum and colour count (bit 31 of
+    // the count = "split prepared").  Two copies of the list (ping-pong on every replace).
+    CutBox *pool = box_a;  // 2 * kMaxColors - 1 boxes at most: box_a and box_b are contiguous
+    (void)box_b;
     if (tid == 0) {
-        box_a[0]  = CutBox{0, n, s_total, 0, 0, 0, 0, 0};
-        s_nboxes  = 1;
-        s_done    = 0;
-        s_flip    = 0;
+        pool[0]     = CutBox{0, n, s_total, 0, 0, 0, 0, 0};
+        l_id[0][0]  = 0;
+        l_sum[0][0] = s_total;
+        l_col[0][0] = n;
+        s_nboxes    = 1;
+        s_done      = 0;
+        s_flip      = 0;
     }
     __syncthreads();
 
+    constexpr uint32_t kReady = 0x80000000u;
+#ifdef TIMG_CUT_TRACE
+    long long t_mark = wall_clock64(), t_split = 0, t_replay = 0;
+    int n_rounds = 0;
+    if (tid == 0 && f == 0) printf("cut: n=%u setup %lld ticks\n", n, wall_clock64() - t_kernel);
+#endif
     for (;;) {
-        CutBox *boxes = s_flip ? box_b : box_a;
+        const uint32_t flip   = s_flip;
         const uint32_t nboxes = s_nboxes;
+#ifdef TIMG_CUT_TRACE
+        t_mark = wall_clock64();
+#endif
         // ---- speculative splits: wave w prepares the w-th unprepared splittable box
         {
             uint32_t mine = 0xffffffffu, seen = 0;
             for (uint32_t i0 = 0; i0 < nboxes && mine == 0xffffffffu; i0 += 64) {
                 const uint32_t i = i0 + lane;
-                const bool cand  = i < nboxes && boxes[i].colors >= 2 && boxes[i].ready == 0;
+                const uint32_t c = i < nboxes ? l_col[flip][i] : 0u;
+                const bool cand  = c >= 2 && !(c & kReady);
                 const unsigned long long m = __ballot(cand);
-                const uint32_t c = (uint32_t)__popcll(m);
-                if (seen + c > (uint32_t)wave) {  // the (wave - seen)-th set bit of m
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (seen + cnt > (uint32_t)wave) {  // the (wave - seen)-th set bit of m
                     unsigned long long mm = m;
                     for (uint32_t k = seen; k < (uint32_t)wave; ++k) mm &= mm - 1;
                     mine = i0 + (uint32_t)__ffsll((long long)mm) - 1;
                 }
-                seen += c;
+                seen += cnt;
             }
             if (mine != 0xffffffffu) {
-                const CutBox box = boxes[mine];
+                const uint32_t id = l_id[flip][mine];
+                const CutBox box  = pool[id];
                 uint32_t median, lowersum;
                 SplitBox(box, tab, scratch, lane, &median, &lowersum);
                 if (lane == 0) {
-                    boxes[mine].median   = median;
-                    boxes[mine].lowersum = lowersum;
-                    boxes[mine].ready    = 1;
+                    pool[id].median   = median;
+                    pool[id].lowersum = lowersum;
+                    l_col[flip][mine] = box.colors | kReady;
                 }
             }
         }
         __threadfence_block();
         __syncthreads();
+#ifdef TIMG_CUT_TRACE
+        {
+            const long long now = wall_clock64();
+            t_split += now - t_mark;
+            t_mark = now;
+            ++n_rounds;
+        }
+#endif
         // ---- replay of the serial bookkeeping (wave 0)
         if (wave == 0) {
-            CutBox *cur = boxes, *next = s_flip ? box_a : box_b;
-            uint32_t nb = nboxes, flip = s_flip, done = 0;
+            uint32_t nb = nboxes, cur = flip, done = 0;
             while (nb < (uint32_t)kMaxColors) {
+                // this lane's four list positions
+                uint32_t sm[4], cl[4], id[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = q * 64 + lane;
+                    const bool in    = i < nb;
+                    sm[q] = in ? l_sum[cur][i] : 0u;
+                    cl[q] = in ? l_col[cur][i] : 0u;
+                    id[q] = in ? l_id[cur][i] : 0u;
+                }
                 // first box (in sum-descending order) that still holds >= 2 colours
                 uint32_t bi = 0xffffffffu;
-                for (uint32_t i0 = 0; i0 < nb && bi == 0xffffffffu; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const unsigned long long m = __ballot(i < nb && cur[i].colors >= 2);
-                    if (m) bi = i0 + (uint32_t)__ffsll((long long)m) - 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long m = __ballot((cl[q] & ~kReady) >= 2);
+                    if (m && bi == 0xffffffffu) bi = q * 64 + (uint32_t)__ffsll((long long)m) - 1;
                 }
                 if (bi == 0xffffffffu) {
                     done = 1;
                     break;
                 }
-                const CutBox box = cur[bi];
-                if (!box.ready) break;  // its split has not been prepared yet: next round
+                if (!(l_col[cur][bi] & kReady)) break;  // its split has not been prepared yet: next round
+                const CutBox box      = pool[l_id[cur][bi]];
                 const uint32_t median = box.median, lowersum = box.lowersum;
                 // replace the box by its halves and restore the stable sum-descending order:
                 // the low half keeps the parent's place in the pre-sort sequence, the high
@@ -485,50 +533,68 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
                 const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 0};
                 const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u,
                                 0, 0, 0, 0};
+                const uint32_t lo_id = 2 * nb - 1, hi_id = 2 * nb;  // pool grows by two per split
                 uint32_t cnt_gt_lo = 0, cnt_ge_hi = 0;
-                for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
-                    const uint32_t i = i0 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = q * 64 + lane;
                     const bool other = i < nb && i != bi;
-                    const uint32_t sm = other ? cur[i].sum : 0u;
-                    cnt_gt_lo += (uint32_t)__popcll(__ballot(other && sm > lo.sum));
-                    cnt_ge_hi += (uint32_t)__popcll(__ballot(other && sm >= hi.sum));
+                    cnt_gt_lo += (uint32_t)__popcll(__ballot(other && sm[q] > lo.sum));
+                    cnt_ge_hi += (uint32_t)__popcll(__ballot(other && sm[q] >= hi.sum));
                 }
-                for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
-                    const uint32_t i = i0 + lane;
+                const uint32_t nxt = cur ^ 1u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = q * 64 + lane;
                     if (i < nb && i != bi) {
-                        const CutBox o = cur[i];
-                        const uint32_t pos = (i < bi ? i : i - 1) + (o.sum > lo.sum ? 0u : 1u) +
-                                             (o.sum >= hi.sum ? 0u : 1u);
-                        next[pos] = o;
+                        const uint32_t pos = (i < bi ? i : i - 1) + (sm[q] > lo.sum ? 0u : 1u) +
+                                             (sm[q] >= hi.sum ? 0u : 1u);
+                        l_sum[nxt][pos] = sm[q];
+                        l_col[nxt][pos] = cl[q];
+                        l_id[nxt][pos]  = id[q];
                     }
                 }
                 if (lane == 0) {
-                    next[cnt_gt_lo + (lo.sum < hi.sum ? 1u : 0u)]  = lo;
-                    next[cnt_ge_hi + (lo.sum >= hi.sum ? 1u : 0u)] = hi;
+                    const uint32_t plo = cnt_gt_lo + (lo.sum < hi.sum ? 1u : 0u);
+                    const uint32_t phi = cnt_ge_hi + (lo.sum >= hi.sum ? 1u : 0u);
+                    pool[lo_id]     = lo;
+                    pool[hi_id]     = hi;
+                    l_sum[nxt][plo] = lo.sum;
+                    l_col[nxt][plo] = lo.colors;
+                    l_id[nxt][plo]  = lo_id;
+                    l_sum[nxt][phi] = hi.sum;
+                    l_col[nxt][phi] = hi.colors;
+                    l_id[nxt][phi]  = hi_id;
                 }
                 ++nb;
-                CutBox *t = cur;
-                cur       = next;
-                next      = t;
-                flip ^= 1u;
+                cur = nxt;
                 TIMG_WAVE_SYNC();
             }
             if (nb >= (uint32_t)kMaxColors) done = 1;
             if (lane == 0) {
                 s_nboxes = nb;
-                s_flip   = flip;
+                s_flip   = cur;
                 s_done   = done;
             }
         }
         __threadfence_block();
         __syncthreads();
+#ifdef TIMG_CUT_TRACE
+        t_replay += wall_clock64() - t_mark;
+        if (tid == 0 && f == 0 && n_rounds <= 6)
+            printf("cut: round %d nboxes->%u split %lld replay-so-far %lld (100MHz ticks)\n", n_rounds, s_nboxes,
+                   t_split, t_replay);
+#endif
         if (s_done) break;
     }
-    const CutBox *boxes   = s_flip ? box_b : box_a;
+#ifdef TIMG_CUT_TRACE
+    if (tid == 0 && f == 0)
+        printf("cut: rounds %d split %lld replay %lld ticks(100MHz)\n", n_rounds, t_split, t_replay);
+#endif
     const uint32_t nboxes = s_nboxes;
     // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
     for (uint32_t bi = tid; bi < nboxes; bi += blockDim.x) {
-        const CutBox box    = boxes[bi];
+        const CutBox box    = pool[l_id[s_flip][bi]];
         const uint32_t *src = tab[box.buf] + box.ind;
         uint32_t sum[3]     = {0, 0, 0};
         for (uint32_t i = 0; i < box.colors; ++i) {
@@ -545,6 +611,10 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         s.meta[0] = (int)nboxes;
         s.meta[1] = 1;  // more colours than palette entries: diffuse
     }
+#ifdef TIMG_CUT_TRACE
+    __syncthreads();
+    if (tid == 0 && f == 0) printf("cut: total %lld ticks\n", wall_clock64() - t_kernel);
+#endif
 }
 
 // ---- K3: 15-bit cell -> nearest palette entry ----------------------------------------

@@ -79,6 +79,8 @@ struct SixelBatch {
     uint32_t *band_ent, *band_nkey, *band_pi, *band_pbase;
     uint16_t *band_nfirst, *band_xs;
     int *band_cnt;
+    unsigned long long *bridge;  // [frames][w][2] granules between the two halves of a frame (K4)
+    int *error;                  // [1] set when a device-side wait gives up
     char *out;
     size_t out_cap;
     unsigned long long *out_len;
@@ -698,7 +700,18 @@ __device__ __forceinline__ uint32_t FromLaneAbove(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
+//
+// With parts == 2 a frame is diffused by TWO workgroups on two CUs (upper and lower half
+// of the rows, single round): one wave per SIMD instead of two halves the time per step,
+// which is what bounds this kernel.  The lower half's first wave follows the upper half's
+// last wave through global memory: per column two self-validating 8-byte granules
+// {48 bits of terms, 16-bit tag}, written and read with relaxed agent-scope atomics (one
+// `sc1` store / load each: no fence, nothing to drain); the buffer is zeroed before every
+// launch.  The follower fetches up to 64 columns per poll into its LDS boundary row.
+constexpr unsigned long long kBridgeTag = 0x5a5aull;
+constexpr int kBridgeSpinLimit          = 1 << 20;
+
+__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b, int parts) {
     extern __shared__ uint32_t lds[];
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
@@ -706,14 +719,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);   // 32768 palette indices
     uint32_t *pal      = lds + 8192;                         // 256 x (idx | r<<8 | g<<16 | b<<24)
     uint32_t *padpix   = pal + 256;                          // [n_pad][W] pixels of the pad rows
-    uint32_t *boundary = padpix + (size_t)n_pad * W;         // [n_waves][3][W]: q1, q5, q3 of a wave's last row
+    uint32_t *boundary = padpix + (size_t)n_pad * W;         // [n_waves + 1][3][W]: q1, q5, q3 of a wave's last
+                                                             // row; the extra row receives the bridge
     // columns published by each wave's last row.  All hand-over traffic is LDS traffic of
     // the form "data, then counter" from ONE wave, which the LDS executes in order: no
     // fence is needed (a workgroup fence would also drain the wave's global prefetches and
     // stores, i.e. put a memory round trip into every step) -- only the compiler has to keep
     // the order, hence the relaxed atomics and the empty asm barriers below.
     __shared__ int progress[kDitherMaxWaves];
-    const int f               = blockIdx.x;
+    const int f               = blockIdx.x / parts;
+    const int part            = blockIdx.x % parts;
     const int tid             = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const SixelFrameScratch s = FrameScratch(b, g, f);
@@ -733,10 +748,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const bool dither = s.meta[1] != 0;
     __syncthreads();
 
-    const int rows_per_round = n_waves * 64;
+    const int rows_per_round = parts * n_waves * 64;  // (parts == 2: one round covers the frame)
+    const int part_row0      = part * n_waves * 64;
     const int steps          = W + 2 * 63;
-    for (int round = 0; round * rows_per_round + wave * 64 < H; ++round) {
-        const int row      = round * rows_per_round + wave * 64 + lane;
+    unsigned long long *bridge = b.bridge + (size_t)f * W * 2;
+    for (int round = 0; round * rows_per_round + part_row0 + wave * 64 < H; ++round) {
+        const int row      = round * rows_per_round + part_row0 + wave * 64 + lane;
         const bool has_row = row < H;
         // where this lane's pixels come from: a frame row in memory or a pad row in LDS
         const bool is_pad       = row >= g.h;
@@ -747,8 +764,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // whose last row lies directly above this wave's first row
         const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
         const int producer_round = wave == 0 ? round - 1 : round;
-        const bool follows       = producer_round >= 0;
-        const uint32_t *b_in     = boundary + (size_t)producer * 3 * W;
+        const bool from_bridge   = parts > 1 && part == 1 && wave == 0;  // follows the other workgroup
+        const bool to_bridge     = parts > 1 && part == 0 && wave == n_waves - 1;
+        const bool follows       = from_bridge || (producer_round >= 0 && !(parts > 1 && wave == 0));
+        uint32_t *b_in           = boundary + (size_t)(from_bridge ? n_waves : producer) * 3 * W;
         uint32_t *b_out          = boundary + (size_t)wave * 3 * W;
         const int in_base        = producer_round * W;   // progress value before the producer's round
         const int out_base       = round * W;
@@ -762,14 +781,44 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         uint32_t packed_idx = 0;
         // lane 0 of a following wave: boundary terms above x-1 (1/16), x (5/16), x+1 (3/16)
         uint32_t bl = 0, bc = 0, br = 0;
-        if (follows) {
-            int need = min(2, W);
+        // waits until `need` columns of the row above are available in b_in
+        int spins = 0;
+        auto wait_for = [&](int need) __attribute__((always_inline)) {
             while (avail < need) {
-                avail = __hip_atomic_load(&progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
-                        in_base;
-                if (avail < need) __builtin_amdgcn_s_sleep(1);
+                if (!from_bridge) {
+                    avail = __hip_atomic_load(&progress[producer], __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP) - in_base;
+                    if (avail < need) __builtin_amdgcn_s_sleep(1);
+                } else {
+                    // fetch the next (up to) 64 columns' granules, keep the valid prefix
+                    const int col = avail + lane;
+                    unsigned long long g0 = 0, g1 = 0;
+                    if (col < W) {
+                        g0 = __hip_atomic_load(&bridge[2 * col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        g1 = __hip_atomic_load(&bridge[2 * col + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const bool ok = col < W && (g0 >> 48) == kBridgeTag && (g1 >> 48) == kBridgeTag;
+                    const unsigned long long bad = ~__ballot(ok);
+                    const int c = bad ? __ffsll((long long)bad) - 1 : 64;
+                    if (lane < c) {
+                        b_in[col]         = (uint32_t)(g0 & 0xffffffull);
+                        b_in[W + col]     = (uint32_t)((g0 >> 24) & 0xffffffull);
+                        b_in[2 * W + col] = (uint32_t)(g1 & 0xffffffull);
+                    }
+                    avail += c;
+                    if (c == 0) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > kBridgeSpinLimit) {  // never on a healthy run: give up loudly
+                            if (lane == 0) atomicExch(b.error, 1);
+                            avail = W;
+                        }
+                    }
+                }
             }
             asm volatile("" ::: "memory");
+        };
+        if (follows) {
+            wait_for(min(2, W));
             bc = b_in[W + 0];                       // q5 above x = 0
             br = W > 1 ? b_in[2 * W + 1] : 0u;      // q3 above x + 1 = 1
         }
@@ -837,12 +886,21 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     packed_idx = 0;
                 }
                 if (lane == 63) {  // the row above the next wave's first row
-                    b_out[x]         = mine.q1;
-                    b_out[W + x]     = mine.q5;
-                    b_out[2 * W + x] = mine.q3;
-                    asm volatile("" ::: "memory");
-                    __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (to_bridge) {
+                        const unsigned long long g0 = (unsigned long long)(mine.q1 & 0xffffffu) |
+                                                      ((unsigned long long)(mine.q5 & 0xffffffu) << 24) |
+                                                      (kBridgeTag << 48);
+                        const unsigned long long g1 = (unsigned long long)(mine.q3 & 0xffffffu) | (kBridgeTag << 48);
+                        __hip_atomic_store(&bridge[2 * x], g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&bridge[2 * x + 1], g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        b_out[x]         = mine.q1;
+                        b_out[W + x]     = mine.q5;
+                        b_out[2 * W + x] = mine.q3;
+                        asm volatile("" ::: "memory");
+                        __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             own7 = mine.q7;
@@ -855,14 +913,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // lane 0's window over the boundary row moves one column to the right
             if (follows && t + 1 < W) {  // wave-uniform: lane 0 is at x = t
                 const int nx = t + 3;    // the step after this one needs column t + 2
-                if (nx <= W) {
-                    while (avail < nx) {
-                        avail = __hip_atomic_load(&progress[producer], __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP) - in_base;
-                        if (avail < nx) __builtin_amdgcn_s_sleep(1);
-                    }
-                    asm volatile("" ::: "memory");
-                }
+                if (nx <= W) wait_for(nx);
                 // next step lane 0 is at x = t + 1: 1/16 of column t, 5/16 of t + 1, 3/16 of t + 2
                 bl = b_in[t];
                 bc = b_in[W + t + 1];
@@ -1573,7 +1624,8 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_bxs   = carve(n_band * g.band_ne * 2);
     const size_t o_bpb   = carve(n_band * 256 * 4);
     const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
-    const size_t o_len   = carve(nf * sizeof(unsigned long long));
+    const size_t o_brdg  = carve(nf * (size_t)w * 2 * sizeof(unsigned long long));
+    const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
     char *base = (char *)ctx->dev[5].ptr;
     SixelBatch b;
@@ -1597,15 +1649,28 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.band_xs     = (uint16_t *)(base + o_bxs);
     b.band_pbase  = (uint32_t *)(base + o_bpb);
     b.band_cnt    = (int *)(base + o_bcnt);
+    b.bridge      = (unsigned long long *)(base + o_brdg);
+    b.error       = (int *)(base + o_len + nf * sizeof(unsigned long long));
     b.out        = dout;
     b.out_cap    = out_cap;
     b.out_len    = (unsigned long long *)(base + o_len);
 
-    // one wave per 64 rows, as many as the boundary rows leave room for next to the tables
-    int dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + 63) / 64));
+    // one wave per 64 rows, as many as the boundary rows leave room for next to the tables;
+    // frames of 4+ waves that fit one round are diffused by two workgroups (see K4)
+    const int rows64 = (g.h6 + 63) / 64;
+    int dither_parts = 1;
+    int dither_waves = std::max(1, std::min(kDitherMaxWaves, rows64));
     auto dither_bytes = [&](int waves) {
-        return (8192 + 256 + (size_t)(g.h6 - h) * w + (size_t)waves * 3 * w) * sizeof(uint32_t);
+        return (8192 + 256 + (size_t)(g.h6 - h) * w + (size_t)(waves + 1) * 3 * w) * sizeof(uint32_t);
     };
+    // MEASURED (MI355X, 800x450): two workgroups per frame are NOT faster (0.96 vs 0.94 ms): a
+    // wave issues in order, so a step costs its ~165 instructions plus two LDS round trips no
+    // matter how many waves share the SIMD.  Kept behind TIMG_HIP_DITHER_TWO_WG for experiments.
+    if (rows64 >= 4 && rows64 <= 2 * kDitherMaxWaves && dither_bytes((rows64 + 1) / 2) <= 160 * 1024 &&
+        getenv("TIMG_HIP_DITHER_TWO_WG")) {
+        dither_parts = 2;
+        dither_waves = (rows64 + 1) / 2;
+    }
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
     const size_t nodes_lds  = ((size_t)2 * g.band_ne + g.band_ne / 2 + 4096) * sizeof(uint32_t);
@@ -1627,6 +1692,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     // ~1.8 ms of cross-queue event hand-over per 64-frame batch (1 group 2.8 ms, 2 groups
     // 4.7 ms, 4 groups 6.3 ms), far more than the overlap wins -- so the default is ONE
     // group; TIMG_HIP_SIXEL_GROUPS keeps the experiment reproducible.
+    TIMG_HIP_TRY(ctx, hipMemsetAsync(b.error, 0, sizeof(unsigned long long), st));
     int n_groups = 1;
     if (const char *e = getenv("TIMG_HIP_SIXEL_GROUPS"))  // tuning
         n_groups = std::max(1, std::min(atoi(e), std::min(n_frames, (int)timg_hip_ctx::kSideStreams)));
@@ -1664,6 +1730,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.band_xs     = b.band_xs + o * g.bands * g.band_ne;
         gb.band_pbase  = b.band_pbase + o * g.bands * 256;
         gb.band_cnt    = b.band_cnt + o * g.bands * 4;
+        gb.bridge      = b.bridge + o * w * 2;
         gb.out         = b.out + o * b.out_cap;
         gb.out_len     = b.out_len + o;
 
@@ -1675,7 +1742,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(BuildLutKernel, dim3(128, nfr), dim3(256), 0, gs, g, gb);
-        hipLaunchKernelGGL(DitherKernel, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+        if (dither_parts > 1)
+            TIMG_HIP_TRY(ctx, hipMemsetAsync(gb.bridge, 0, (size_t)nfr * w * 2 * sizeof(unsigned long long), gs));
+        hipLaunchKernelGGL(DitherKernel, dim3(nfr * dither_parts), dim3(dither_waves * 64), dither_lds, gs, g,
+                           gb, dither_parts);
         hipLaunchKernelGGL(BandNodesKernel, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * nfr + 3) / 4), dim3(256), 0, gs, g, gb, nfr);
         hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, nfr), dim3(256), emit_lds, gs, g, gb);
@@ -1688,11 +1758,13 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     }
     TIMG_HIP_TRY(ctx, hipGetLastError());
 
-    TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * nf));
+    TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * (nf + 1)));
     unsigned long long *len_h = (unsigned long long *)ctx->pin[0].ptr;
-    TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * nf,
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * (nf + 1),
                                      hipMemcpyDeviceToHost, st));
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if ((int)len_h[nf] != 0)
+        return ctx->Fail(TIMG_HIP_ERR_DEVICE, "sixel diffusion: a workgroup gave up waiting for its neighbour");
     size_t worst = 0;
     for (int i = 0; i < n_frames; ++i) {
         out_len[i] = (size_t)len_h[i];

@@ -53,6 +53,10 @@ def cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, frames, target_seconds=12.
             orc.sixel_encode(fb, bg=bg, lookup_mode=0)
 
     work([0])  # warm-up
+    t1 = time.perf_counter()
+    work([0, 1])  # two frames on ONE thread: the per-core rate, for context
+    single = 2 * in_w * in_h / 1e6 / (time.perf_counter() - t1)
+
     def run(n):
         shards = [list(range(t, n, cores)) for t in range(cores)]
         threads = [threading.Thread(target=work, args=(s,)) for s in shards]
@@ -77,6 +81,7 @@ def cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, frames, target_seconds=12.
                    f"scale+blend = {'hzeller/timg sources (oracle/_ref)' if ref is not None else 'oracle port'}, "
                    "sixel = oracle restatement of libsixel (parity unpinned)"),
         "seconds": round(dt, 3),
+        "single_thread_value": round(single, 2),
     }
 
 

@@ -64,6 +64,7 @@ struct SixelFrameScratch {
     uint32_t *band_pi;     // per node: pass << 16 | index inside the pass
     uint16_t *band_xs;     // per node: pen position when it is put
     uint32_t *band_pbase;  // [bands * 256] output slot of the first node of every pass
+    uint2 *band_rec;       // per OUTPUT SLOT: {node key, first entry | pen << 13 | '$' << 24}
     int *band_cnt;         // [bands * 4]: entries, nodes
 };
 
@@ -78,6 +79,7 @@ struct SixelBatch {
     uint32_t *band_off;
     uint32_t *band_ent, *band_nkey, *band_pi, *band_pbase;
     uint16_t *band_nfirst, *band_xs;
+    uint2 *band_rec;
     int *band_cnt;
     unsigned long long *bridge;  // [frames][w][2] granules between the two halves of a frame (K4)
     int *error;                  // [1] set when a device-side wait gives up
@@ -108,6 +110,7 @@ __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, c
     s.band_pi     = b.band_pi + fb * g.band_ne;
     s.band_xs     = b.band_xs + fb * g.band_ne;
     s.band_pbase  = b.band_pbase + fb * 256;
+    s.band_rec    = b.band_rec + fb * g.band_ne;
     s.band_cnt    = b.band_cnt + fb * 4;
     return s;
 }
@@ -1302,9 +1305,10 @@ __global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b,
         }
     }
     // output slot of the first node of every pass: exclusive scan of the 256 counts
+    __shared__ uint32_t s_pbase[4][256];
+    uint32_t *pb  = s_pbase[threadIdx.x >> 6];
     uint32_t c[4] = {cnt0, cnt1, cnt2, cnt3};
     uint32_t carry = 0;
-    uint32_t *pbase = s.band_pbase + (size_t)band * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         uint32_t incl = c[q];
@@ -1313,51 +1317,49 @@ __global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b,
             const uint32_t o = __shfl_up(incl, d);
             if (lane >= d) incl += o;
         }
-        pbase[q * 64 + lane] = carry + incl - c[q];
+        pb[q * 64 + lane] = carry + incl - c[q];
         carry += __shfl(incl, 63);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's pi/xs stores and pb writes
+    // one record per OUTPUT SLOT (passes back to back, nodes of a pass in packing order): the
+    // emit kernel then reads its nodes with coalesced loads instead of chasing indices
+    const uint16_t *nfirst = s.band_nfirst + slot;
+    uint2 *rec             = s.band_rec + slot;
+    for (int i = lane; i < n_nodes; i += 64) {
+        const uint32_t v    = pi[i];
+        const uint32_t pass = v >> 16, idx = v & 0xffffu;
+        const uint32_t cr   = (idx == 0 && pass != 0) ? 1u : 0u;  // first node of a later pass: '$'
+        rec[pb[pass] + idx] = make_uint2(nkey[i], (uint32_t)nfirst[i] | ((uint32_t)xs[i] << 13) | (cr << 24));
     }
 }
 
 __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
-    const int NE       = g.band_ne;
-    uint32_t *node_off = lds;                                          // per output slot: size, then offset
-    uint16_t *order    = reinterpret_cast<uint16_t *>(lds + NE);       // output slot -> node
-    __shared__ uint32_t s_pbase[256];
+    uint32_t *node_off = lds;  // per output slot: size, then offset
     __shared__ uint32_t s_scan[5];
     __shared__ int s_overflow;
 
     const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    const size_t slot         = (size_t)band * NE;
+    const size_t slot         = (size_t)band * g.band_ne;
     const uint32_t *ent       = s.band_ent + slot;
-    const uint32_t *nkey      = s.band_nkey + slot;
-    const uint16_t *nfirst    = s.band_nfirst + slot;
-    const uint32_t *pi        = s.band_pi + slot;
-    const uint16_t *xs        = s.band_xs + slot;
+    const uint2 *rec          = s.band_rec + slot;
     const int n_nodes         = s.band_cnt[band * 4 + 1];
-    s_pbase[tid] = s.band_pbase[(size_t)band * 256 + tid];
     if (tid == 0) s_overflow = 0;
-    __syncthreads();
-    for (int i = tid; i < n_nodes; i += 256) {
-        const uint32_t v               = pi[i];
-        order[s_pbase[v >> 16] + (v & 0xffffu)] = (uint16_t)i;
-    }
     __syncthreads();
 
     auto describe = [&](int k, int *node_first, int *color, int *sx, int *mx, int *x_start, bool *tag,
                         bool *cr) {
-        const int node     = order[k];
-        const uint32_t key = nkey[node];
-        const uint32_t v   = pi[node];
-        *node_first        = nfirst[node];
+        const uint2 r      = rec[k];
+        const uint32_t key = r.x;
+        *node_first        = (int)(r.y & 0x1fffu);
+        *x_start           = (int)((r.y >> 13) & 0x7ffu);
+        *cr                = ((r.y >> 24) & 1u) != 0;
         *color             = (int)(key & 0xffu);
         *sx                = (int)(key >> 20);
         *mx                = 4095 - (int)((key >> 8) & 0xfffu);
-        *x_start           = xs[node];
-        *cr                = (v & 0xffffu) == 0 && (v >> 16) != 0;  // first node of a later pass: '$'
         // "#c" only when the active colour changes (first node: always, fixed up later)
-        *tag = k == 0 || (int)(nkey[order[k - 1]] & 0xffu) != *color;
+        *tag = k == 0 || (int)(rec[k - 1].x & 0xffu) != *color;
     };
     // phase 1: byte size of every output slot
     for (int k = tid; k < n_nodes; k += 256) {
@@ -1397,7 +1399,9 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         __syncthreads();
     }
     const uint32_t band_len = s_scan[4];
-    // phase 2: bytes into the band's scratch slot
+    // phase 2: bytes into the band's scratch slot.  (Staging the bytes in LDS and flushing them
+    // with 16-byte stores was measured slower: 345 vs 225 us per batch -- the staging buffer
+    // costs more in occupancy than the byte stores cost in memory instructions.)
     char *out_band = s.band_bytes + (size_t)band * g.band_cap;
     if (band_len > g.band_cap) {
         if (tid == 0) s_overflow = 1;
@@ -1414,8 +1418,8 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
     }
     __syncthreads();
     if (tid == 0) {
-        const int first_color = n_nodes ? (int)(nkey[order[0]] & 0xffu) : -1;
-        const int last_color  = n_nodes ? (int)(nkey[order[n_nodes - 1]] & 0xffu) : -1;
+        const int first_color = n_nodes ? (int)(rec[0].x & 0xffu) : -1;
+        const int last_color  = n_nodes ? (int)(rec[n_nodes - 1].x & 0xffu) : -1;
         // an overflowing band reports a length no caller buffer can hold
         s.band_meta[band * 4 + 0] = s_overflow ? 0x3fffffff : (int)band_len;
         s.band_meta[band * 4 + 1] = first_color;
@@ -1623,6 +1627,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_bpi   = carve(n_band * g.band_ne * 4);
     const size_t o_bxs   = carve(n_band * g.band_ne * 2);
     const size_t o_bpb   = carve(n_band * 256 * 4);
+    const size_t o_brec  = carve(n_band * g.band_ne * sizeof(uint2));
     const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
     const size_t o_brdg  = carve(nf * (size_t)w * 2 * sizeof(unsigned long long));
     const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
@@ -1648,6 +1653,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.band_pi     = (uint32_t *)(base + o_bpi);
     b.band_xs     = (uint16_t *)(base + o_bxs);
     b.band_pbase  = (uint32_t *)(base + o_bpb);
+    b.band_rec    = (uint2 *)(base + o_brec);
     b.band_cnt    = (int *)(base + o_bcnt);
     b.bridge      = (unsigned long long *)(base + o_brdg);
     b.error       = (int *)(base + o_len + nf * sizeof(unsigned long long));
@@ -1674,7 +1680,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
     const size_t nodes_lds  = ((size_t)2 * g.band_ne + g.band_ne / 2 + 4096) * sizeof(uint32_t);
-    const size_t emit_lds   = ((size_t)g.band_ne + g.band_ne / 2) * sizeof(uint32_t);
+    const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1729,6 +1735,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.band_pi     = b.band_pi + o * g.bands * g.band_ne;
         gb.band_xs     = b.band_xs + o * g.bands * g.band_ne;
         gb.band_pbase  = b.band_pbase + o * g.bands * 256;
+        gb.band_rec    = b.band_rec + o * g.bands * g.band_ne;
         gb.band_cnt    = b.band_cnt + o * g.bands * 4;
         gb.bridge      = b.bridge + o * w * 2;
         gb.out         = b.out + o * b.out_cap;

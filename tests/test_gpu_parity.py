@@ -303,6 +303,46 @@ def test_streaming_batch_with_blend_matches_generic(hip):
     sc.close()
 
 
+def test_baseline_config1_640x480_half_block(hip, oracle):
+    """BASELINE.json config 1: 640x480 RGBA -> -p half -g80x25 = 67x50 px -> 67 columns x 25 rows
+    (geometry C1), scale + alpha compose + half-block bytes end to end."""
+    src = synth.alpha(640, 480, seed=1)
+    blend = timg_amd.Blend.make(BG)
+    fb = hip.scale(src, 67, 50, blend=blend)
+    want_fb, _ = oracle.alpha_compose(oracle.scale(src, 67, 50), BG)
+    assert np.array_equal(fb, want_fb)
+    got = hip.block_encode(fb, 67, 50, flags=0)[0]
+    assert got == oracle.block_encode(want_fb)
+    assert got.count(b"\n") == 25
+
+
+def test_baseline_config3_grid_of_4k_frames_quarter_block(hip, oracle):
+    """BASELINE.json config 3 (a grid row of it): 4K frames -> 200x56 px -> -p quarter, 100x28 cells
+    each, placed side by side (Send's x = column * 202 px), device-resident batch, one launch
+    per stage; bit-exact bytes per frame."""
+    import torch
+    n = 4
+    frames = np.stack([synth.make(k, 3840, 2160, seed=30 + i) for i, k in enumerate(["photo", "alpha", "noise", "photo"])])
+    src = torch.from_numpy(frames).cuda()
+    sc = hip.scaler(3840, 2160, 200, 56)
+    blend = timg_amd.Blend.make(BG, PAT, 2, 2)
+    dst = torch.empty((n, 56, 200, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    hip.scale_blend(sc, src.data_ptr(), dst.data_ptr(), n, blend)
+    hip.sync()
+    scaled = dst.cpu().numpy()
+    for i in range(n):
+        want, _ = oracle.alpha_compose(oracle.scale(frames[i], 200, 56), BG, PAT, 2, 2)
+        assert np.array_equal(scaled[i], want), i
+        # every grid column has its own indent, so each is its own (single-frame) encode call
+        got = hip.block_encode(dst[i].data_ptr(), 200, 56, flags=timg_amd.TimgHip.QUARTER, x_indent=i * 202)[0]
+        assert got == oracle.block_encode(want, quarter=True, x=i * 202), i
+    outs = hip.block_encode(dst.data_ptr(), 200, 56, flags=timg_amd.TimgHip.QUARTER, n_frames=n)
+    for i in range(n):
+        assert outs[i] == oracle.block_encode(scaled[i], quarter=True), i
+    sc.close()
+
+
 def test_baseline_config5_8k_alpha_checkerboard_sixel(hip, oracle):
     """BASELINE.json config 5, one frame: 7680x4320 RGBA with alpha -> 800x450 with a
     checkerboard background (-b colour -B colour) -> sixel, against the oracle end to end."""

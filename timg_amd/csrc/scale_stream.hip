@@ -454,6 +454,224 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
     if (RunTile<M>(c) && threadIdx.x == 0) tile_state[tile] = 1;
 }
 
+
+// ===================================================================================
+// Horizontal-first plans (what stb picks e.g. for 8K -> 800x450 and 640x480 -> 67x50):
+// every source row is first gathered horizontally to the output width, the vertical
+// filter then runs over those rows in source-row order (stb's scatter / gather loops).
+//
+// One workgroup = one (strip of <= 256 output columns, band of output rows, frame), one
+// LANE PER OUTPUT COLUMN.  Per source row:
+//   * the lanes decode the strip's source window (raw RGBA8 rows are prefetched two rows
+//     ahead with 16-byte loads) into one of two LDS row buffers as float4 pixels;
+//   * one barrier; every lane gathers its TAPS taps from the row buffer (weights live in
+//     registers, taps past the column's own count have weight 0 and read finite data), in
+//     stb's even/odd chain order;
+//   * the row's value feeds the <= kSlots output rows whose vertical filter covers it
+//     (running sums in registers, RowSched as in the vertical-first kernel); a completed
+//     output pixel is un-weighted, composed and stored straight from registers.
+// No staging of results, one barrier per source row, and the expensive part -- taps x
+// channels multiply-adds -- is spread over all lanes with conflict-free-ish LDS reads.
+// Channel sets as above; the opaque set carries A == 1.0f as a fourth channel so that the
+// alpha chain is computed by the same packed arithmetic (three channels would cost the
+// same number of instructions).
+constexpr int kColsH   = 256;   // output columns per workgroup
+constexpr int kWinMaxH = 2560;  // source columns of a strip's window (multiple of 4)
+constexpr int kLoadsH  = (kWinMaxH / 4 + kColsH - 1) / kColsH;  // 16-byte loads per lane per row
+
+// One float4 per pixel in the row buffer: kOpaque (R, G, B, 1), kPremult (A, RA, GA, BA),
+// kFull (R, G, B, A) -- its weighted channels RA GA BA are formed while gathering, by the
+// same single multiplication the decoder would do.
+template <int M>
+__device__ __forceinline__ void DecodeToLds(uint32_t px, float *dst) {
+    constexpr int kCh = ModeTraits<M>::kCh;
+    float d[kCh];
+    DecodeMode<M>(px, d);
+    *reinterpret_cast<float4 *>(dst) =
+        make_float4(d[0], d[1], d[2], M == kOpaque ? 1.0f : d[kCh > 3 ? 3 : 0]);
+}
+
+template <int M, int TAPS>
+__global__ void __launch_bounds__(kColsH)
+ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
+                   int win) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (win + TAPS) pixels
+    __shared__ int fail;
+    constexpr int kStride = 4;  // floats per pixel in the row buffers
+    constexpr int kHc     = M == kFull ? 7 : 4;
+    const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tile_state[tile] != 0) return;  // uniform: whole workgroup leaves
+    const StripInfo si   = LoadConstant(tab.strips + blockIdx.x);
+    const BandInfo bi    = LoadConstant(tab.bands + blockIdx.y);
+    const RowSched *sched = tab.sched + bi.sched;
+    const int f          = blockIdx.z;
+    const int tid        = threadIdx.x;
+    const int row_px     = win + TAPS;  // pixels per LDS row buffer (zeroed tail: padded taps)
+    if (tid == 0) fail = 0;
+    for (int i = tid; i < TAPS * kStride; i += kColsH) {
+        lds[(size_t)win * kStride + i]            = 0.0f;
+        lds[(size_t)(row_px + win) * kStride + i] = 0.0f;
+    }
+
+    // this lane's output column: tap window and weights (in registers)
+    const int ox   = si.ox0 + tid;
+    const bool has = ox < si.ox1;
+    int2 ht        = make_int2(si.cx0, 0);
+    if (has) ht = plan.h_taps[ox];
+    const int n0l = ht.x - si.cx0;
+    float hw[TAPS];
+    {
+        const float *hc = plan.h_coeff + (size_t)ox * plan.h_width;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) hw[k] = (has && k < ht.y) ? hc[k] : 0.0f;
+    }
+    int *flag = batch.transparent_flags ? batch.transparent_flags + f : nullptr;
+    uint8_t *dst_frame = batch.dst + (size_t)f * batch.dst_frame_stride;
+
+    // raw source rows: lane t owns the 4-pixel chunks t, t + 256, ... of the window
+    const uint8_t *frame = batch.src + (size_t)f * batch.src_frame_stride;
+    const int r_last     = min(bi.r1, plan.in_h - 1);
+    uint32_t chunk_off[kLoadsH];
+    bool chunk_in[kLoadsH];
+#pragma unroll
+    for (int j = 0; j < kLoadsH; ++j) {
+        const int c  = tid + j * kColsH;  // chunk index inside the window
+        chunk_in[j]  = 4 * c < win;
+        chunk_off[j] = (uint32_t)min(si.cx0 + 4 * c, plan.in_w - 4) * 4u;
+    }
+    auto load_row = [&](int r, uint4 raw[kLoadsH]) {
+        const uint8_t *row = frame + (size_t)min(r, r_last) * batch.src_stride;  // uniform
+#pragma unroll
+        for (int j = 0; j < kLoadsH; ++j)
+            if (chunk_in[j]) raw[j] = *reinterpret_cast<const uint4 *>(row + chunk_off[j]);
+    };
+
+    float acc[kSlots][kHc];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s)
+#pragma unroll
+        for (int ch = 0; ch < kHc; ++ch) acc[s][ch] = 0.0f;
+    bool ok = true;
+
+    RowSched rs_next = LoadConstant(sched);
+    // one source row: decode -> LDS, barrier, gather, vertical update
+    auto row_step = [&](const uint4 raw[kLoadsH], int r) __attribute__((always_inline)) -> bool {
+        const RowSched rs = rs_next;
+        asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        rs_next = LoadConstant(sched + (r + 1 - bi.r0));
+        float *buf = lds + (size_t)((r - bi.r0) & 1) * row_px * kStride;
+#pragma unroll
+        for (int j = 0; j < kLoadsH; ++j) {
+            if (!chunk_in[j]) continue;
+            const uint4 q = raw[j];
+            if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
+            if (M == kPremult)
+                ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
+            float *dst = buf + (size_t)(tid + j * kColsH) * 4 * kStride;
+            DecodeToLds<M>(q.x, dst);
+            DecodeToLds<M>(q.y, dst + kStride);
+            DecodeToLds<M>(q.z, dst + 2 * kStride);
+            DecodeToLds<M>(q.w, dst + 3 * kStride);
+        }
+        if (M != kFull && __any(!ok) && (tid & 63) == 0) fail = 1;
+        __syncthreads();
+        if (M != kFull && fail) return false;
+
+        // horizontal gather of this row for my output column
+        const float *base = buf + (size_t)n0l * kStride;
+        float even[kHc], odd[kHc];
+#pragma unroll
+        for (int ch = 0; ch < kHc; ++ch) even[ch] = odd[ch] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            float v[kHc];
+            const float4 t0 = *reinterpret_cast<const float4 *>(base + (size_t)k * kStride);
+            v[0] = t0.x;
+            v[1] = t0.y;
+            v[2] = t0.z;
+            v[3] = t0.w;
+            if (kHc > 4) {  // kFull: R*A, G*A, B*A as the decoder forms them
+                v[kHc > 4 ? 4 : 0] = t0.x * t0.w;
+                v[kHc > 5 ? 5 : 0] = t0.y * t0.w;
+                v[kHc > 6 ? 6 : 0] = t0.z * t0.w;
+            }
+            if (plan.h_sequential || !(k & 1)) {  // (uniform; k is a compile-time constant)
+#pragma unroll
+                for (int ch = 0; ch < kHc; ++ch) even[ch] = even[ch] + v[ch] * hw[k];
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < kHc; ++ch) odd[ch] = odd[ch] + v[ch] * hw[k];
+            }
+        }
+        float h[kHc];
+#pragma unroll
+        for (int ch = 0; ch < kHc; ++ch) h[ch] = plan.h_sequential ? even[ch] : even[ch] + odd[ch];
+
+        // vertical: feed the active output rows, finish the one that completes
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int fl = rs.flags[s];
+            if (!(fl & 1)) continue;  // wave-uniform
+            const float w = rs.weight[s];
+#pragma unroll
+            for (int ch = 0; ch < kHc; ++ch) acc[s][ch] = acc[s][ch] + h[ch] * w;
+            if (fl & 4) {
+                Px7 px;
+                if (M == kOpaque) {  // with alpha == 1 the straight and the weighted sums coincide
+                    px.c[0] = acc[s][0];
+                    px.c[1] = acc[s][1];
+                    px.c[2] = acc[s][2];
+                    px.c[3] = acc[s][3];
+                    px.c[4] = acc[s][0];
+                    px.c[5] = acc[s][1];
+                    px.c[6] = acc[s][2];
+                } else if (M == kPremult) {
+                    px.c[0] = px.c[1] = px.c[2] = 0.0f;
+                    px.c[3] = acc[s][0];
+                    px.c[4] = acc[s][1];
+                    px.c[5] = acc[s][2];
+                    px.c[6] = acc[s][3];
+                    if (has && px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < 7; ++ch) px.c[ch] = acc[s][ch < kHc ? ch : 0];
+                }
+                const int y = fl >> 8;
+                if (has) {
+                    const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, blend, flag);
+                    *reinterpret_cast<uint32_t *>(dst_frame + (size_t)y * batch.dst_stride + (size_t)ox * 4) = out;
+                }
+#pragma unroll
+                for (int ch = 0; ch < kHc; ++ch) acc[s][ch] = 0.0f;
+            }
+        }
+        return true;
+    };
+
+    uint4 ra[kLoadsH], rb[kLoadsH];
+    load_row(bi.r0, ra);
+    load_row(bi.r0 + 1, rb);
+    __syncthreads();  // the zeroed tails and `fail`
+    bool good = true;
+    for (int r = bi.r0; r <= bi.r1 && good; r += 2) {
+        good = row_step(ra, r);
+        if (!good) break;
+        load_row(r + 2, ra);
+        if (r + 1 > bi.r1) break;
+        good = row_step(rb, r + 1);
+        if (!good) break;
+        load_row(r + 3, rb);
+    }
+    if (!good) return;
+    if (M != kFull) {
+        if (__any(!ok) && (tid & 63) == 0) fail = 1;
+        __syncthreads();
+        if (fail) return;
+    }
+    if (tid == 0) tile_state[tile] = 1;
+}
+
 }  // namespace
 
 // ---- host side: applicability + schedule ------------------------------------------
@@ -468,6 +686,8 @@ struct StreamSchedule {
     // [1]: short bands so that a single frame still yields ~500 workgroups
     StreamVariant v[2];
     int hrow        = 0;        // widest strip, in output columns
+    bool hfirst     = false;    // horizontal-first plan: ScaleStreamHKernel
+    int hwin        = 0;        // ... widest source window of a strip (multiple of 4)
     int *tile_state = nullptr;  // device, grown on demand
     size_t tile_cap = 0;
 };
@@ -562,7 +782,7 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
         return false;
     };
     if (p.identity) return no("identity plan");
-    if (!p.vertical_first) return no("horizontal-first plan");
+    if (!p.vertical_first && p.h_width > 80) return no("horizontal filter wider than 80 taps");
     if (p.max_active_rows > kSlots) return no("too many output rows per source row");
     if (p.in_w % kPix) return no("source width is not a multiple of 4");
     // slot = y % kSlots must be free again when row y + kSlots starts
@@ -587,28 +807,53 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     for (int y = 1; y < p.out_h; ++y)
         if (last[y] < last[y - 1] || first[y] < first[y - 1]) return no("non-monotonic rows");
 
-    // strips: as many output columns as fit with all their taps in kStripCols source columns
     std::vector<StripInfo> strips;
-    for (int ox = 0; ox < p.out_w;) {
-        StripInfo si;
-        si.ox0  = ox;
-        si.cx0  = p.h_taps[ox].n0 & ~(kPix - 1);
-        si.pad  = 0;
-        int end = ox;
-        // (LDS keeps {taps, weights} per output column: bound the strip's outputs too)
-        const int max_out = kLdsCoeffFloats / std::max(1, p.h_width);
-        if (max_out < 1) return no("horizontal filter too wide for the LDS weight table");
-        while (end < p.out_w && end - ox < max_out) {
-            const HTaps &t = p.h_taps[end];
-            if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kStripCols) break;
-            ++end;
+    int hwin = 0;
+    if (p.vertical_first) {
+        // strips: as many output columns as fit with all their taps in kStripCols source columns
+        for (int ox = 0; ox < p.out_w;) {
+            StripInfo si;
+            si.ox0  = ox;
+            si.cx0  = p.h_taps[ox].n0 & ~(kPix - 1);
+            si.pad  = 0;
+            int end = ox;
+            // (LDS keeps {taps, weights} per output column: bound the strip's outputs too)
+            const int max_out = kLdsCoeffFloats / std::max(1, p.h_width);
+            if (max_out < 1) return no("horizontal filter too wide for the LDS weight table");
+            while (end < p.out_w && end - ox < max_out) {
+                const HTaps &t = p.h_taps[end];
+                if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kStripCols) break;
+                ++end;
+            }
+            if (end == ox) return no("horizontal window wider than a strip");
+            si.ox1 = end;
+            strips.push_back(si);
+            ox = end;
         }
-        if (end == ox) return no("horizontal window wider than a strip");
-        si.ox1 = end;
-        strips.push_back(si);
-        ox = end;
+    } else {
+        // horizontal-first: one lane per output column, the strip's source window in LDS
+        for (int ox = 0; ox < p.out_w;) {
+            StripInfo si;
+            si.ox0  = ox;
+            si.cx0  = p.h_taps[ox].n0 & ~3;
+            si.pad  = 0;
+            int end = ox, reach = si.cx0;
+            while (end < p.out_w && end - ox < kColsH) {
+                const HTaps &t = p.h_taps[end];
+                if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kWinMaxH) break;
+                reach = std::max(reach, t.n0 + t.count);
+                ++end;
+            }
+            if (end == ox) return no("horizontal window wider than the row buffer");
+            si.ox1 = end;
+            hwin   = std::max(hwin, (reach - si.cx0 + 3) & ~3);
+            strips.push_back(si);
+            ox = end;
+        }
     }
     StreamSchedule *ss = new StreamSchedule();
+    ss->hfirst = !p.vertical_first;
+    ss->hwin   = hwin;
     for (const StripInfo &si : strips) ss->hrow = std::max(ss->hrow, si.ox1 - si.ox0);
     int tall = 45;
     if (const char *e = getenv("TIMG_HIP_BAND_ROWS")) tall = atoi(e) > 0 ? atoi(e) : tall;  // tuning
@@ -659,6 +904,33 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
     return hipGetLastError();
 }
 
+template <int M, int TAPS>
+static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (ss->hwin + TAPS) * 4 * sizeof(float);
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
+    hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kColsH), lds, stream, s->dev, v.t, blend,
+                       batch, ss->tile_state, ss->hwin);
+    return hipGetLastError();
+}
+
+template <int M>
+static hipError_t LaunchModeH(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                              const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    // the tap loop is unrolled with its weights in registers: smallest instantiation that fits
+    const int taps = s->plan.h_width;
+    if (taps <= 16) return LaunchModeHT<M, 16>(s, ss, v, blend, batch, stream);
+    if (taps <= 40) return LaunchModeHT<M, 40>(s, ss, v, blend, batch, stream);
+    return LaunchModeHT<M, 80>(s, ss, v, blend, batch, stream);
+}
+
 hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
@@ -683,6 +955,13 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
     // cheapest channel set first; tiles whose data breaks its assumption stay
     // open for the next kernel (stream_cfg[3] can skip the optimistic passes)
     const int first_mode = s->stream_cfg[3];
+    if (ss->hfirst) {
+        if (first_mode <= kOpaque && (e = LaunchModeH<kOpaque>(s, ss, v, blend, batch, stream)) != hipSuccess)
+            return e;
+        if (first_mode <= kPremult && (e = LaunchModeH<kPremult>(s, ss, v, blend, batch, stream)) != hipSuccess)
+            return e;
+        return LaunchModeH<kFull>(s, ss, v, blend, batch, stream);
+    }
     if (first_mode <= kOpaque && (e = LaunchMode<kOpaque>(s, ss, v, blend, batch, stream)) != hipSuccess)
         return e;
     if (first_mode <= kPremult && (e = LaunchMode<kPremult>(s, ss, v, blend, batch, stream)) != hipSuccess)

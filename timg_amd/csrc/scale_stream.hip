@@ -475,9 +475,10 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
 // Channel sets as above; the opaque set carries A == 1.0f as a fourth channel so that the
 // alpha chain is computed by the same packed arithmetic (three channels would cost the
 // same number of instructions).
-constexpr int kColsH   = 256;   // output columns per workgroup
-constexpr int kWinMaxH = 2560;  // source columns of a strip's window (multiple of 4)
-constexpr int kLoadsH  = (kWinMaxH / 4 + kColsH - 1) / kColsH;  // 16-byte loads per lane per row
+constexpr int kColsH    = 128;   // output columns per workgroup
+constexpr int kThreadsH = 256;   // ... two lanes per column: stb's even and odd tap chains
+constexpr int kWinMaxH  = 1536;  // source columns of a strip's window (multiple of 4)
+constexpr int kLoadsH   = (kWinMaxH / 4 + kThreadsH - 1) / kThreadsH;  // 16-byte loads per lane per row
 
 // One float4 per pixel in the row buffer: kOpaque (R, G, B, 1), kPremult (A, RA, GA, BA),
 // kFull (R, G, B, A) -- its weighted channels RA GA BA are formed while gathering, by the
@@ -491,40 +492,56 @@ __device__ __forceinline__ void DecodeToLds(uint32_t px, float *dst) {
         make_float4(d[0], d[1], d[2], M == kOpaque ? 1.0f : d[kCh > 3 ? 3 : 0]);
 }
 
+// value of the other lane of the pair (lanes 2i and 2i+1)
+__device__ __forceinline__ float FromPartner(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1 /* quad_perm [1,0,3,2] */,
+                                                      0xf, 0xf, false));
+}
+
+// TAPS = taps per LANE (the column's taps 2j + parity): the loop is unrolled with its
+// weights in registers.
 template <int M, int TAPS>
-__global__ void __launch_bounds__(kColsH)
+__global__ void __launch_bounds__(kThreadsH)
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
                    int win) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (win + TAPS) pixels
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (win + 2 * TAPS) pixels
     __shared__ int fail;
     constexpr int kStride = 4;  // floats per pixel in the row buffers
-    constexpr int kHc     = M == kFull ? 7 : 4;
+    constexpr int kHc     = M == kFull ? 7 : 4;   // channels of the horizontal gather
+    constexpr int kVc     = M == kFull ? 4 : 2;   // channels a lane carries through the vertical pass
     const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (tile_state[tile] != 0) return;  // uniform: whole workgroup leaves
-    const StripInfo si   = LoadConstant(tab.strips + blockIdx.x);
-    const BandInfo bi    = LoadConstant(tab.bands + blockIdx.y);
+    const StripInfo si    = LoadConstant(tab.strips + blockIdx.x);
+    const BandInfo bi     = LoadConstant(tab.bands + blockIdx.y);
     const RowSched *sched = tab.sched + bi.sched;
-    const int f          = blockIdx.z;
-    const int tid        = threadIdx.x;
-    const int row_px     = win + TAPS;  // pixels per LDS row buffer (zeroed tail: padded taps)
+    const int f           = blockIdx.z;
+    const int tid         = threadIdx.x;
+    const int par         = tid & 1;             // 0: even taps / low channels, 1: odd taps / high channels
+    const int row_px      = win + 2 * TAPS;      // pixels per LDS row buffer (zeroed tail: padded taps)
     if (tid == 0) fail = 0;
-    for (int i = tid; i < TAPS * kStride; i += kColsH) {
+    for (int i = tid; i < 2 * TAPS * kStride; i += kThreadsH) {
         lds[(size_t)win * kStride + i]            = 0.0f;
         lds[(size_t)(row_px + win) * kStride + i] = 0.0f;
     }
 
-    // this lane's output column: tap window and weights (in registers)
-    const int ox   = si.ox0 + tid;
+    // this lane's output column: tap window and its half of the weights (in registers)
+    const int ox   = si.ox0 + (tid >> 1);
     const bool has = ox < si.ox1;
     int2 ht        = make_int2(si.cx0, 0);
     if (has) ht = plan.h_taps[ox];
     const int n0l = ht.x - si.cx0;
     float hw[TAPS];
     {
+        // <= 3 taps: stb runs ONE chain over them -- lane 0 of the pair takes them all
         const float *hc = plan.h_coeff + (size_t)ox * plan.h_width;
 #pragma unroll
-        for (int k = 0; k < TAPS; ++k) hw[k] = (has && k < ht.y) ? hc[k] : 0.0f;
+        for (int j = 0; j < TAPS; ++j) {
+            const int k = plan.h_sequential ? j : 2 * j + par;
+            hw[j]       = (has && k < ht.y && !(plan.h_sequential && par)) ? hc[k] : 0.0f;
+        }
     }
+    const int tap_step = plan.h_sequential ? 1 : 2;
+    const int tap_0    = plan.h_sequential ? 0 : par;
     int *flag = batch.transparent_flags ? batch.transparent_flags + f : nullptr;
     uint8_t *dst_frame = batch.dst + (size_t)f * batch.dst_frame_stride;
 
@@ -535,7 +552,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     bool chunk_in[kLoadsH];
 #pragma unroll
     for (int j = 0; j < kLoadsH; ++j) {
-        const int c  = tid + j * kColsH;  // chunk index inside the window
+        const int c  = tid + j * kThreadsH;  // chunk index inside the window
         chunk_in[j]  = 4 * c < win;
         chunk_off[j] = (uint32_t)min(si.cx0 + 4 * c, plan.in_w - 4) * 4u;
     }
@@ -546,11 +563,12 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
             if (chunk_in[j]) raw[j] = *reinterpret_cast<const uint4 *>(row + chunk_off[j]);
     };
 
-    float acc[kSlots][kHc];
+    // vertical sums of this lane's channels: gather channels par * kVc ... (kFull: 0-3 / 4-6)
+    float acc[kSlots][kVc];
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
-        for (int ch = 0; ch < kHc; ++ch) acc[s][ch] = 0.0f;
+        for (int ch = 0; ch < kVc; ++ch) acc[s][ch] = 0.0f;
     bool ok = true;
 
     RowSched rs_next = LoadConstant(sched);
@@ -568,7 +586,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
             if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
             if (M == kPremult)
                 ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
-            float *dst = buf + (size_t)(tid + j * kColsH) * 4 * kStride;
+            float *dst = buf + (size_t)(tid + j * kThreadsH) * 4 * kStride;
             DecodeToLds<M>(q.x, dst);
             DecodeToLds<M>(q.y, dst + kStride);
             DecodeToLds<M>(q.z, dst + 2 * kStride);
@@ -578,15 +596,15 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         __syncthreads();
         if (M != kFull && fail) return false;
 
-        // horizontal gather of this row for my output column
-        const float *base = buf + (size_t)n0l * kStride;
-        float even[kHc], odd[kHc];
+        // this lane's chain of the horizontal gather
+        const float *base = buf + (size_t)(n0l + tap_0) * kStride;
+        float sum[kHc];
 #pragma unroll
-        for (int ch = 0; ch < kHc; ++ch) even[ch] = odd[ch] = 0.0f;
+        for (int ch = 0; ch < kHc; ++ch) sum[ch] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < TAPS; ++k) {
+        for (int j = 0; j < TAPS; ++j) {
             float v[kHc];
-            const float4 t0 = *reinterpret_cast<const float4 *>(base + (size_t)k * kStride);
+            const float4 t0 = *reinterpret_cast<const float4 *>(base + (size_t)(j * tap_step) * kStride);
             v[0] = t0.x;
             v[1] = t0.y;
             v[2] = t0.z;
@@ -596,17 +614,21 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
                 v[kHc > 5 ? 5 : 0] = t0.y * t0.w;
                 v[kHc > 6 ? 6 : 0] = t0.z * t0.w;
             }
-            if (plan.h_sequential || !(k & 1)) {  // (uniform; k is a compile-time constant)
 #pragma unroll
-                for (int ch = 0; ch < kHc; ++ch) even[ch] = even[ch] + v[ch] * hw[k];
-            } else {
-#pragma unroll
-                for (int ch = 0; ch < kHc; ++ch) odd[ch] = odd[ch] + v[ch] * hw[k];
-            }
+            for (int ch = 0; ch < kHc; ++ch) sum[ch] = sum[ch] + v[ch] * hw[j];
         }
-        float h[kHc];
+        // even chain + odd chain (one of them is all zeros for <= 3 taps); every lane keeps
+        // only the channels it carries through the vertical pass
+        float h[kVc];
 #pragma unroll
-        for (int ch = 0; ch < kHc; ++ch) h[ch] = plan.h_sequential ? even[ch] : even[ch] + odd[ch];
+        for (int ch = 0; ch < kVc; ++ch) {
+            // channel index in the gather: lane 0 carries 0..kVc-1, lane 1 the rest
+            const int lo = ch, hi = kVc + ch;
+            const float mine_lo = sum[lo], mine_hi = sum[hi < kHc ? hi : 0];
+            const float oth_lo = FromPartner(mine_lo), oth_hi = FromPartner(mine_hi);
+            // (sum of the even-tap lane's chain and the odd-tap lane's chain: commutative)
+            h[ch] = par ? (hi < kHc ? mine_hi + oth_hi : 0.0f) : mine_lo + oth_lo;
+        }
 
         // vertical: feed the active output rows, finish the one that completes
 #pragma unroll
@@ -615,35 +637,42 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
             if (!(fl & 1)) continue;  // wave-uniform
             const float w = rs.weight[s];
 #pragma unroll
-            for (int ch = 0; ch < kHc; ++ch) acc[s][ch] = acc[s][ch] + h[ch] * w;
+            for (int ch = 0; ch < kVc; ++ch) acc[s][ch] = acc[s][ch] + h[ch] * w;
             if (fl & 4) {
+                // lane 0 of the pair assembles the pixel: its own channels + the partner's
+                float all[2 * kVc];
+#pragma unroll
+                for (int ch = 0; ch < kVc; ++ch) {
+                    all[ch]       = acc[s][ch];
+                    all[kVc + ch] = FromPartner(acc[s][ch]);
+                }
                 Px7 px;
                 if (M == kOpaque) {  // with alpha == 1 the straight and the weighted sums coincide
-                    px.c[0] = acc[s][0];
-                    px.c[1] = acc[s][1];
-                    px.c[2] = acc[s][2];
-                    px.c[3] = acc[s][3];
-                    px.c[4] = acc[s][0];
-                    px.c[5] = acc[s][1];
-                    px.c[6] = acc[s][2];
+                    px.c[0] = all[0];
+                    px.c[1] = all[1];
+                    px.c[2] = all[2];
+                    px.c[3] = all[3];
+                    px.c[4] = all[0];
+                    px.c[5] = all[1];
+                    px.c[6] = all[2];
                 } else if (M == kPremult) {
                     px.c[0] = px.c[1] = px.c[2] = 0.0f;
-                    px.c[3] = acc[s][0];
-                    px.c[4] = acc[s][1];
-                    px.c[5] = acc[s][2];
-                    px.c[6] = acc[s][3];
-                    if (has && px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
+                    px.c[3] = all[0];
+                    px.c[4] = all[1];
+                    px.c[5] = all[2];
+                    px.c[6] = all[3];
+                    if (has && !par && px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
                 } else {
 #pragma unroll
-                    for (int ch = 0; ch < 7; ++ch) px.c[ch] = acc[s][ch < kHc ? ch : 0];
+                    for (int ch = 0; ch < 7; ++ch) px.c[ch] = all[ch];
                 }
                 const int y = fl >> 8;
-                if (has) {
+                if (has && !par) {
                     const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, blend, flag);
                     *reinterpret_cast<uint32_t *>(dst_frame + (size_t)y * batch.dst_stride + (size_t)ox * 4) = out;
                 }
 #pragma unroll
-                for (int ch = 0; ch < kHc; ++ch) acc[s][ch] = 0.0f;
+                for (int ch = 0; ch < kVc; ++ch) acc[s][ch] = 0.0f;
             }
         }
         return true;
@@ -831,14 +860,17 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
             ox = end;
         }
     } else {
-        // horizontal-first: one lane per output column, the strip's source window in LDS
+        // horizontal-first: a lane pair per output column, the strip's source window in LDS;
+        // equally wide strips (a narrow last strip would cost a full walk over the rows)
+        const int n_even = (p.out_w + kColsH - 1) / kColsH;
+        const int cols   = (p.out_w + n_even - 1) / n_even;
         for (int ox = 0; ox < p.out_w;) {
             StripInfo si;
             si.ox0  = ox;
             si.cx0  = p.h_taps[ox].n0 & ~3;
             si.pad  = 0;
             int end = ox, reach = si.cx0;
-            while (end < p.out_w && end - ox < kColsH) {
+            while (end < p.out_w && end - ox < cols) {
                 const HTaps &t = p.h_taps[end];
                 if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kWinMaxH) break;
                 reach = std::max(reach, t.n0 + t.count);
@@ -907,7 +939,7 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
 template <int M, int TAPS>
 static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                                const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
-    const size_t lds = (size_t)2 * (ss->hwin + TAPS) * 4 * sizeof(float);
+    const size_t lds = (size_t)2 * (ss->hwin + 2 * TAPS) * 4 * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>,
@@ -916,7 +948,7 @@ static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *s
         attr_done = true;
     }
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
-    hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kColsH), lds, stream, s->dev, v.t, blend,
+    hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
                        batch, ss->tile_state, ss->hwin);
     return hipGetLastError();
 }
@@ -925,10 +957,11 @@ template <int M>
 static hipError_t LaunchModeH(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
     // the tap loop is unrolled with its weights in registers: smallest instantiation that fits
+    // (a lane runs every second tap; <= 3 taps form one chain that lane 0 of the pair runs alone)
     const int taps = s->plan.h_width;
-    if (taps <= 16) return LaunchModeHT<M, 16>(s, ss, v, blend, batch, stream);
-    if (taps <= 40) return LaunchModeHT<M, 40>(s, ss, v, blend, batch, stream);
-    return LaunchModeHT<M, 80>(s, ss, v, blend, batch, stream);
+    if (taps <= 16) return LaunchModeHT<M, 8>(s, ss, v, blend, batch, stream);
+    if (taps <= 40) return LaunchModeHT<M, 20>(s, ss, v, blend, batch, stream);
+    return LaunchModeHT<M, 40>(s, ss, v, blend, batch, stream);
 }
 
 hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,

@@ -11,8 +11,8 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if "ScaleStreamKernel" not in n: continue
-    k = n.split("ScaleStreamKernel")[1][:4]
+    if "ScaleStream" not in n: continue
+    k = n.split("ScaleStream")[1][:22]
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(acc.items()):
     print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()})

@@ -503,8 +503,13 @@ __device__ __forceinline__ float FromPartner(float v) {
 template <int M, int TAPS>
 __global__ void __launch_bounds__(kThreadsH)
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
-                   int win) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (win + 2 * TAPS) pixels
+                   int win, int w4) {
+    // Two row buffers of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at
+    // index n >> 2.  The decoder's lanes hold 4 consecutive pixels each, so plane q is written
+    // by consecutive lanes at consecutive 16-byte slots (no bank conflicts; a linear layout
+    // made every write 4-way conflicted and the LDS the bottleneck); w4 = 4 mod 16 keeps the
+    // planes 16 banks apart for the gather's reads.  Pixels >= win stay zero (padded taps).
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int fail;
     constexpr int kStride = 4;  // floats per pixel in the row buffers
     constexpr int kHc     = M == kFull ? 7 : 4;   // channels of the horizontal gather
@@ -517,12 +522,11 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     const int f           = blockIdx.z;
     const int tid         = threadIdx.x;
     const int par         = tid & 1;             // 0: even taps / low channels, 1: odd taps / high channels
-    const int row_px      = win + 2 * TAPS;      // pixels per LDS row buffer (zeroed tail: padded taps)
+    const int buf_floats  = 4 * w4 * kStride;    // floats per row buffer
     if (tid == 0) fail = 0;
-    for (int i = tid; i < 2 * TAPS * kStride; i += kThreadsH) {
-        lds[(size_t)win * kStride + i]            = 0.0f;
-        lds[(size_t)(row_px + win) * kStride + i] = 0.0f;
-    }
+    for (int i = tid; i < 2 * buf_floats / 4; i += kThreadsH)
+        reinterpret_cast<float4 *>(lds)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto slot = [&](int n) -> int { return ((n & 3) * w4 + (n >> 2)) * kStride; };  // float index of pixel n
 
     // this lane's output column: tap window and its half of the weights (in registers)
     const int ox   = si.ox0 + (tid >> 1);
@@ -578,7 +582,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));
         __builtin_amdgcn_sched_barrier(0);
         rs_next = LoadConstant(sched + (r + 1 - bi.r0));
-        float *buf = lds + (size_t)((r - bi.r0) & 1) * row_px * kStride;
+        float *buf = lds + (size_t)((r - bi.r0) & 1) * buf_floats;
 #pragma unroll
         for (int j = 0; j < kLoadsH; ++j) {
             if (!chunk_in[j]) continue;
@@ -586,25 +590,29 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
             if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
             if (M == kPremult)
                 ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
-            float *dst = buf + (size_t)(tid + j * kThreadsH) * 4 * kStride;
+            float *dst = buf + (size_t)(tid + j * kThreadsH) * kStride;  // index (chunk) in plane 0
             DecodeToLds<M>(q.x, dst);
-            DecodeToLds<M>(q.y, dst + kStride);
-            DecodeToLds<M>(q.z, dst + 2 * kStride);
-            DecodeToLds<M>(q.w, dst + 3 * kStride);
+            DecodeToLds<M>(q.y, dst + (size_t)w4 * kStride);
+            DecodeToLds<M>(q.z, dst + (size_t)2 * w4 * kStride);
+            DecodeToLds<M>(q.w, dst + (size_t)3 * w4 * kStride);
         }
         if (M != kFull && __any(!ok) && (tid & 63) == 0) fail = 1;
         __syncthreads();
         if (M != kFull && fail) return false;
 
-        // this lane's chain of the horizontal gather
-        const float *base = buf + (size_t)(n0l + tap_0) * kStride;
+        // this lane's chain of the horizontal gather: taps n = nb + 2j alternate between two
+        // planes, each advancing one slot every second tap
+        const int nb      = n0l + tap_0;
+        const float *b_ev = buf + slot(nb), *b_od = buf + slot(nb + 2);
         float sum[kHc];
 #pragma unroll
         for (int ch = 0; ch < kHc; ++ch) sum[ch] = 0.0f;
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) {
             float v[kHc];
-            const float4 t0 = *reinterpret_cast<const float4 *>(base + (size_t)(j * tap_step) * kStride);
+            const float *src = tap_step == 2 ? ((j & 1) ? b_od : b_ev) + (size_t)(j >> 1) * kStride
+                                             : buf + slot(nb + j);  // (<= 3 taps: one chain)
+            const float4 t0 = *reinterpret_cast<const float4 *>(src);
             v[0] = t0.x;
             v[1] = t0.y;
             v[2] = t0.z;
@@ -939,7 +947,10 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
 template <int M, int TAPS>
 static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                                const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
-    const size_t lds = (size_t)2 * (ss->hwin + 2 * TAPS) * 4 * sizeof(float);
+    // pixels per plane: a quarter of (window + padded taps), rounded up to 4 mod 16
+    int w4 = (ss->hwin + 2 * TAPS + 3) / 4 + 1;
+    while ((w4 & 15) != 4) ++w4;
+    const size_t lds = (size_t)2 * 4 * w4 * 4 * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>,
@@ -949,7 +960,7 @@ static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *s
     }
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
-                       batch, ss->tile_state, ss->hwin);
+                       batch, ss->tile_state, ss->hwin, w4);
     return hipGetLastError();
 }
 

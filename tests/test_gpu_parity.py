@@ -281,6 +281,46 @@ def test_full_size_4k_frames(hip, oracle, kind, dw, dh):
     sc.close()
 
 
+@pytest.mark.parametrize("kind", ["photo", "alpha", "noise"])
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 67, 50), (1000, 1000, 100, 100), (2048, 1536, 200, 150),
+                                         (1600, 1200, 133, 100)])
+def test_horizontal_first_streaming_kernel(hip, oracle, kind, sw, sh, dw, dh):
+    """Plans for which stb resamples horizontally first (BASELINE configs 1 and 5 are of that
+    kind) have their own streaming kernel: every channel set (opaque / premultiplied / full)
+    against the oracle, plus the generic kernel."""
+    src = synth.make(kind, sw, sh, seed=sw + dh)
+    sc = hip.scaler(sw, sh, dw, dh)
+    info = sc.info()
+    assert info["vertical_first"] == 0 and info["streaming_ok"] == 1
+    want = oracle.scale(src, dw, dh)
+    for kernel in (2, 3, 4, 1):
+        sc.set_kernel(kernel)
+        got = np.empty((dh, dw, 4), np.uint8)
+        hip.scale_blend(sc, src, got)
+        assert np.array_equal(got, want), (kernel, int(np.count_nonzero(got != want)))
+    sc.close()
+
+
+def test_horizontal_first_batch_with_bgra_and_blend(hip, oracle):
+    n, sw, sh, dw, dh = 3, 1280, 960, 120, 90
+    frames = np.stack([synth.alpha(sw, sh, seed=70 + i) for i in range(n)])
+    sc = hip.scaler(sw, sh, dw, dh, in_fmt=1)
+    assert sc.info()["vertical_first"] == 0 and sc.info()["streaming_ok"] == 1
+    blend = timg_amd.Blend.make(BG, PAT, 7, 5, start_row=3)
+    d_src = hip.upload(frames)
+    d_dst = hip.malloc(n * dw * dh * 4)
+    flags = hip.scale_blend(sc, d_src, d_dst, n, blend, want_transparent=True)
+    hip.sync()
+    out = hip.download(d_dst, n * dw * dh * 4).reshape(n, dh, dw, 4)
+    assert flags == [1] * n
+    for i in range(n):
+        want, _ = oracle.alpha_compose(oracle.scale(frames[i], dw, dh, 1), BG, PAT, 7, 5, 3)
+        assert np.array_equal(out[i], want), i
+    hip.free(d_src)
+    hip.free(d_dst)
+    sc.close()
+
+
 def test_streaming_batch_with_blend_matches_generic(hip):
     """Size-independent property at full batch shape: both kernel families give
     identical bytes on device-resident frames (the generic one is pinned to the

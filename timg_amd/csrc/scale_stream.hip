@@ -460,24 +460,25 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
 // every source row is first gathered horizontally to the output width, the vertical
 // filter then runs over those rows in source-row order (stb's scatter / gather loops).
 //
-// One workgroup = one (strip of <= 256 output columns, band of output rows, frame), one
-// LANE PER OUTPUT COLUMN.  Per source row:
+// One workgroup = ONE WAVE = one (strip of <= 32 output columns, band of output rows, frame),
+// a lane pair per output column.  Per source row:
 //   * the lanes decode the strip's source window (raw RGBA8 rows are prefetched two rows
-//     ahead with 16-byte loads) into one of two LDS row buffers as float4 pixels;
-//   * one barrier; every lane gathers its TAPS taps from the row buffer (weights live in
-//     registers, taps past the column's own count have weight 0 and read finite data), in
-//     stb's even/odd chain order;
+//     ahead with 16-byte loads) into the wave's LDS row buffer as float4 pixels;
+//   * no barrier (a wave's LDS operations execute in order: the gather's reads see the
+//     decoder's writes, and the next row's writes land behind this row's reads); the two
+//     lanes of a pair gather stb's even and odd tap chains (weights live in registers, taps
+//     past the column's own count have weight 0 and read finite data);
 //   * the row's value feeds the <= kSlots output rows whose vertical filter covers it
 //     (running sums in registers, RowSched as in the vertical-first kernel); a completed
 //     output pixel is un-weighted, composed and stored straight from registers.
-// No staging of results, one barrier per source row, and the expensive part -- taps x
-// channels multiply-adds -- is spread over all lanes with conflict-free-ish LDS reads.
+// No staging of results, no barriers -- waves never wait for each other, only for their own
+// loads -- and the expensive part, taps x channels multiply-adds, is spread over all lanes.
 // Channel sets as above; the opaque set carries A == 1.0f as a fourth channel so that the
 // alpha chain is computed by the same packed arithmetic (three channels would cost the
 // same number of instructions).
-constexpr int kColsH    = 128;   // output columns per workgroup
-constexpr int kThreadsH = 256;   // ... two lanes per column: stb's even and odd tap chains
-constexpr int kWinMaxH  = 1536;  // source columns of a strip's window (multiple of 4)
+constexpr int kColsH    = 32;    // output columns per workgroup = ONE WAVE
+constexpr int kThreadsH = 64;    // ... two lanes per column: stb's even and odd tap chains
+constexpr int kWinMaxH  = 1024;  // source columns of a strip's window (multiple of 4)
 constexpr int kLoadsH   = (kWinMaxH / 4 + kThreadsH - 1) / kThreadsH;  // 16-byte loads per lane per row
 
 // One float4 per pixel in the row buffer: kOpaque (R, G, B, 1), kPremult (A, RA, GA, BA),
@@ -504,14 +505,13 @@ template <int M, int TAPS>
 __global__ void __launch_bounds__(kThreadsH)
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
                    int win, int w4) {
-    // Two row buffers of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at
+    // One row buffer of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at
     // index n >> 2.  The decoder's lanes hold 4 consecutive pixels each, so plane q is written
     // by consecutive lanes at consecutive 16-byte slots (no bank conflicts; a linear layout
     // made every write 4-way conflicted and the LDS the bottleneck); w4 = 4 mod 16 keeps the
     // planes 16 banks apart for the gather's reads.  Pixels >= win stay zero (padded taps).
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int fail;
-    constexpr int kStride = 4;  // floats per pixel in the row buffers
+    constexpr int kStride = 4;  // floats per pixel in the row buffer
     constexpr int kHc     = M == kFull ? 7 : 4;   // channels of the horizontal gather
     constexpr int kVc     = M == kFull ? 4 : 2;   // channels a lane carries through the vertical pass
     const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -522,9 +522,8 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     const int f           = blockIdx.z;
     const int tid         = threadIdx.x;
     const int par         = tid & 1;             // 0: even taps / low channels, 1: odd taps / high channels
-    const int buf_floats  = 4 * w4 * kStride;    // floats per row buffer
-    if (tid == 0) fail = 0;
-    for (int i = tid; i < 2 * buf_floats / 4; i += kThreadsH)
+    const int buf_floats  = 4 * w4 * kStride;    // floats of the row buffer
+    for (int i = tid; i < buf_floats / 4; i += kThreadsH)
         reinterpret_cast<float4 *>(lds)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto slot = [&](int n) -> int { return ((n & 3) * w4 + (n >> 2)) * kStride; };  // float index of pixel n
 
@@ -582,7 +581,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));
         __builtin_amdgcn_sched_barrier(0);
         rs_next = LoadConstant(sched + (r + 1 - bi.r0));
-        float *buf = lds + (size_t)((r - bi.r0) & 1) * buf_floats;
+        float *buf = lds;
 #pragma unroll
         for (int j = 0; j < kLoadsH; ++j) {
             if (!chunk_in[j]) continue;
@@ -596,9 +595,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
             DecodeToLds<M>(q.z, dst + (size_t)2 * w4 * kStride);
             DecodeToLds<M>(q.w, dst + (size_t)3 * w4 * kStride);
         }
-        if (M != kFull && __any(!ok) && (tid & 63) == 0) fail = 1;
-        __syncthreads();
-        if (M != kFull && fail) return false;
+        if (M != kFull && __any(!ok)) return false;  // (the workgroup is this one wave)
 
         // this lane's chain of the horizontal gather: taps n = nb + 2j alternate between two
         // planes, each advancing one slot every second tap
@@ -689,7 +686,6 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     uint4 ra[kLoadsH], rb[kLoadsH];
     load_row(bi.r0, ra);
     load_row(bi.r0 + 1, rb);
-    __syncthreads();  // the zeroed tails and `fail`
     bool good = true;
     for (int r = bi.r0; r <= bi.r1 && good; r += 2) {
         good = row_step(ra, r);
@@ -701,11 +697,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         load_row(r + 3, rb);
     }
     if (!good) return;
-    if (M != kFull) {
-        if (__any(!ok) && (tid & 63) == 0) fail = 1;
-        __syncthreads();
-        if (fail) return;
-    }
+    if (M != kFull && __any(!ok)) return;
     if (tid == 0) tile_state[tile] = 1;
 }
 
@@ -950,7 +942,7 @@ static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *s
     // pixels per plane: a quarter of (window + padded taps), rounded up to 4 mod 16
     int w4 = (ss->hwin + 2 * TAPS + 3) / 4 + 1;
     while ((w4 & 15) != 4) ++w4;
-    const size_t lds = (size_t)2 * 4 * w4 * 4 * sizeof(float);
+    const size_t lds = (size_t)4 * w4 * 4 * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>,

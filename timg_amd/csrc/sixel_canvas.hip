@@ -63,7 +63,6 @@ struct SixelFrameScratch {
     uint16_t *band_nfirst; // first entry of each node
     uint32_t *band_pi;     // per node: pass << 16 | index inside the pass
     uint16_t *band_xs;     // per node: pen position when it is put
-    uint32_t *band_pbase;  // [bands * 256] output slot of the first node of every pass
     uint2 *band_rec;       // per OUTPUT SLOT: {node key, first entry | pen << 13 | '$' << 24}
     int *band_cnt;         // [bands * 4]: entries, nodes
 };
@@ -77,7 +76,7 @@ struct SixelBatch {
     char *band_bytes;
     int *band_meta;
     uint32_t *band_off;
-    uint32_t *band_ent, *band_nkey, *band_pi, *band_pbase;
+    uint32_t *band_ent, *band_nkey, *band_pi;
     uint16_t *band_nfirst, *band_xs;
     uint2 *band_rec;
     int *band_cnt;
@@ -109,7 +108,6 @@ __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, c
     s.band_nfirst = b.band_nfirst + fb * g.band_ne;
     s.band_pi     = b.band_pi + fb * g.band_ne;
     s.band_xs     = b.band_xs + fb * g.band_ne;
-    s.band_pbase  = b.band_pbase + fb * 256;
     s.band_rec    = b.band_rec + fb * g.band_ne;
     s.band_cnt    = b.band_cnt + fb * 4;
     return s;
@@ -1626,7 +1624,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_bfst  = carve(n_band * g.band_ne * 2);
     const size_t o_bpi   = carve(n_band * g.band_ne * 4);
     const size_t o_bxs   = carve(n_band * g.band_ne * 2);
-    const size_t o_bpb   = carve(n_band * 256 * 4);
     const size_t o_brec  = carve(n_band * g.band_ne * sizeof(uint2));
     const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
     const size_t o_brdg  = carve(nf * (size_t)w * 2 * sizeof(unsigned long long));
@@ -1652,7 +1649,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.band_nfirst = (uint16_t *)(base + o_bfst);
     b.band_pi     = (uint32_t *)(base + o_bpi);
     b.band_xs     = (uint16_t *)(base + o_bxs);
-    b.band_pbase  = (uint32_t *)(base + o_bpb);
     b.band_rec    = (uint2 *)(base + o_brec);
     b.band_cnt    = (int *)(base + o_bcnt);
     b.bridge      = (unsigned long long *)(base + o_brdg);
@@ -1734,7 +1730,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.band_nfirst = b.band_nfirst + o * g.bands * g.band_ne;
         gb.band_pi     = b.band_pi + o * g.bands * g.band_ne;
         gb.band_xs     = b.band_xs + o * g.bands * g.band_ne;
-        gb.band_pbase  = b.band_pbase + o * g.bands * 256;
         gb.band_rec    = b.band_rec + o * g.bands * g.band_ne;
         gb.band_cnt    = b.band_cnt + o * g.bands * 4;
         gb.bridge      = b.bridge + o * w * 2;

@@ -301,6 +301,26 @@ def test_horizontal_first_streaming_kernel(hip, oracle, kind, sw, sh, dw, dh):
     sc.close()
 
 
+@pytest.mark.parametrize("sw,sh,dw,dh", [(1366, 768, 200, 112), (1366, 768, 455, 256), (999, 1333, 333, 444),
+                                         (1023, 767, 341, 255), (6, 1000, 3, 100), (5, 500, 2, 100),  # vertical-first
+                                         (1001, 999, 100, 100), (1275, 1650, 150, 194), (2561, 1441, 320, 180),
+                                         (1365, 767, 91, 51)])                                        # horizontal-first
+def test_streaming_kernels_take_any_source_width(hip, oracle, sw, sh, dw, dh):
+    """Source widths that are not a multiple of 4: rows are only 4-byte aligned and one lane's
+    16-byte load straddles the end of the row."""
+    for kind in ("alpha", "photo"):
+        src = synth.make(kind, sw, sh, seed=sw)
+        sc = hip.scaler(sw, sh, dw, dh)
+        assert sc.info()["streaming_ok"] == 1, (sw, sh, dw, dh)
+        want = oracle.scale(src, dw, dh)
+        for kernel in (2, 4, 1):
+            sc.set_kernel(kernel)
+            got = np.empty((dh, dw, 4), np.uint8)
+            hip.scale_blend(sc, src, got)
+            assert np.array_equal(got, want), (kind, kernel, int(np.count_nonzero(got != want)))
+        sc.close()
+
+
 def test_horizontal_first_batch_with_bgra_and_blend(hip, oracle):
     n, sw, sh, dw, dh = 3, 1280, 960, 120, 90
     frames = np.stack([synth.alpha(sw, sh, seed=70 + i) for i in range(n)])

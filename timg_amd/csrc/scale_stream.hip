@@ -278,9 +278,12 @@ __device__ bool RunTile(const TileCtx &c) {
     const FrameBatch &batch = *c.batch;
     const int tid           = threadIdx.x;
     const int col0          = c.si.cx0 + tid * kPix;
-    // in_w is a multiple of kPix (PrepareStreamSchedule): a lane is either fully
-    // inside the row or fully past its end; the latter re-read the last pixels
-    // (never consumed: no tap reaches past in_w) so that loads need no predicate
+    // A lane whose four columns straddle the end of the row (in_w not a multiple of 4) loads
+    // the LAST four pixels of the row instead and shifts them into place when they are used;
+    // lanes entirely past the end re-read those pixels too (never consumed: no tap reaches
+    // past in_w).  So loads need no predicate (16-byte loads need only 4-byte alignment).
+    const int over  = col0 + kPix - plan.in_w;
+    const int shift = (col0 < plan.in_w && over > 0) ? over : 0;
     const uint32_t lane_off = (uint32_t)min(col0, plan.in_w - kPix) * 4u;
     const uint8_t *frame    = batch.src + (size_t)c.f * batch.src_frame_stride;
     int *flag               = batch.transparent_flags ? batch.transparent_flags + c.f : nullptr;
@@ -310,7 +313,13 @@ __device__ bool RunTile(const TileCtx &c) {
     // table carries one blank entry past the last band): a scalar load issued and
     // consumed in the same step would expose the scalar-cache latency every row.
     RowSched rs_next = LoadConstant(c.sched);
-    auto row_step = [&](const uint4 &q, int r) __attribute__((always_inline)) -> bool {
+    auto row_step = [&](const uint4 &q_in, int r) __attribute__((always_inline)) -> bool {
+        uint4 q = q_in;
+        if (shift) {  // (one lane of the last strip at most)
+            if (shift == 1) q = make_uint4(q.y, q.z, q.w, q.w);
+            else if (shift == 2) q = make_uint4(q.z, q.w, q.w, q.w);
+            else q = make_uint4(q.w, q.w, q.w, q.w);
+        }
         const RowSched rs = rs_next;
         asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));  // rs is complete here ...
         __builtin_amdgcn_sched_barrier(0);
@@ -553,11 +562,14 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     const int r_last     = min(bi.r1, plan.in_h - 1);
     uint32_t chunk_off[kLoadsH];
     bool chunk_in[kLoadsH];
+    int chunk_shift[kLoadsH];  // a chunk straddling the end of the row: see the vertical-first kernel
 #pragma unroll
     for (int j = 0; j < kLoadsH; ++j) {
-        const int c  = tid + j * kThreadsH;  // chunk index inside the window
-        chunk_in[j]  = 4 * c < win;
-        chunk_off[j] = (uint32_t)min(si.cx0 + 4 * c, plan.in_w - 4) * 4u;
+        const int c    = tid + j * kThreadsH;  // chunk index inside the window
+        const int col  = si.cx0 + 4 * c;
+        chunk_in[j]    = 4 * c < win;
+        chunk_off[j]   = (uint32_t)min(col, plan.in_w - 4) * 4u;
+        chunk_shift[j] = (col < plan.in_w && col + 4 > plan.in_w) ? col + 4 - plan.in_w : 0;
     }
     auto load_row = [&](int r, uint4 raw[kLoadsH]) {
         const uint8_t *row = frame + (size_t)min(r, r_last) * batch.src_stride;  // uniform
@@ -585,7 +597,12 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
 #pragma unroll
         for (int j = 0; j < kLoadsH; ++j) {
             if (!chunk_in[j]) continue;
-            const uint4 q = raw[j];
+            uint4 q = raw[j];
+            if (chunk_shift[j]) {
+                if (chunk_shift[j] == 1) q = make_uint4(q.y, q.z, q.w, q.w);
+                else if (chunk_shift[j] == 2) q = make_uint4(q.z, q.w, q.w, q.w);
+                else q = make_uint4(q.w, q.w, q.w, q.w);
+            }
             if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
             if (M == kPremult)
                 ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
@@ -813,7 +830,7 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     if (p.identity) return no("identity plan");
     if (!p.vertical_first && p.h_width > 80) return no("horizontal filter wider than 80 taps");
     if (p.max_active_rows > kSlots) return no("too many output rows per source row");
-    if (p.in_w % kPix) return no("source width is not a multiple of 4");
+    if (p.in_w < kPix) return no("source narrower than one load");
     // slot = y % kSlots must be free again when row y + kSlots starts
     std::vector<int> first(p.out_h), last(p.out_h);
     for (int y = 0; y < p.out_h; ++y) {
@@ -971,8 +988,9 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
     if (!ss) return hipErrorNotSupported;
-    // 16-byte loads need 16-byte aligned rows; otherwise the generic kernel runs
-    if (((uintptr_t)batch.src & 15) || (batch.src_stride & 15) || (batch.src_frame_stride & 15))
+    // rows of whole pixels (the 16-byte loads only need 4-byte alignment); otherwise the
+    // generic kernel runs
+    if (((uintptr_t)batch.src & 3) || (batch.src_stride & 3) || (batch.src_frame_stride & 3))
         return LaunchScaleGeneric(s->dev, blend, batch, stream);
     const StreamVariant &tall = ss->v[0];
     const bool enough = (size_t)tall.t.n_strips * tall.t.n_bands * batch.n_frames >= 512;

@@ -191,6 +191,8 @@ int timg_hip_block_canvas_send(timg_hip_block_canvas *c, int x, int dy, const ui
 #define TIMG_HIP_SIXEL_BROKEN_CURSOR 1 /* SixelOptions::known_broken_cursor_placement */
 
 size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
+/* Frames up to 4095 pixels wide (columns travel in 12-bit fields); wider ones are refused
+ * with TIMG_HIP_ERR_UNSUPP. */
 
 int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
                           int stride, size_t frame_stride, int fb_on_device,

@@ -258,10 +258,21 @@ def test_sixel_round_trip_decodes_to_the_palette_image(hip, oracle):
     assert err.mean() < 12.0 and np.percentile(err, 99) < 80
 
 
+@pytest.mark.parametrize("kind,w,h", [("photo", 1366, 40), ("noise", 1920, 27), ("alpha", 3840, 20),
+                                      ("photo", 4095, 11)])
+def test_sixel_wide_frames(hip, oracle, kind, w, h):
+    """Frames wider than 1365 px (8192 band entries): the band kernels sort in global scratch."""
+    fb = synth.make(kind, w, h, seed=23)
+    got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 16, 4),
+                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 16, 4, lookup_mode=1)
+    assert len(got) == len(want) and got == want, (len(got), len(want))
+
+
 def test_sixel_too_wide_is_refused(hip):
-    fb = np.zeros((6, 1400, 4), np.uint8)
+    fb = np.zeros((6, 4096, 4), np.uint8)
     with pytest.raises(timg_amd.TimgHipError) as e:
-        hip.sixel_encode(fb, 1400, 6)
+        hip.sixel_encode(fb, 4096, 6)
     assert e.value.code == -5
 
 

@@ -27,8 +27,11 @@ namespace timg_amd {
 namespace {
 
 constexpr int kMaxColors     = 256;
-constexpr int kMaxEntries    = 8192;  // 6 * width entries per band -> width <= 1365
-constexpr int kMaxSixelWidth = kMaxEntries / 6;
+// A band has at most 6 * width (colour, column) entries.  Up to kLdsEntries of them the band
+// kernels sort in LDS; wider frames (up to kMaxSixelWidth: columns travel in 12-bit fields)
+// use the same code on global-memory scratch.
+constexpr int kLdsEntries    = 8192;
+constexpr int kMaxSixelWidth = 4095;
 
 struct SixelGeom {
     int w, h, h6;        // frame, padded height
@@ -63,7 +66,7 @@ struct SixelFrameScratch {
     uint16_t *band_nfirst; // first entry of each node
     uint32_t *band_pi;     // per node: pass << 16 | index inside the pass
     uint16_t *band_xs;     // per node: pen position when it is put
-    uint2 *band_rec;       // per OUTPUT SLOT: {node key, first entry | pen << 13 | '$' << 24}
+    uint2 *band_rec;       // per OUTPUT SLOT: {node key, first entry | pen << 15 | '$' << 27}
     int *band_cnt;         // [bands * 4]: entries, nodes
 };
 
@@ -719,8 +722,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const int n_pad    = H - g.h;                            // rows SixelCanvas::Send appends
     uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);   // 32768 palette indices
     uint32_t *pal      = lds + 8192;                         // 256 x (idx | r<<8 | g<<16 | b<<24)
-    uint32_t *padpix   = pal + 256;                          // [n_pad][W] pixels of the pad rows
-    uint32_t *boundary = padpix + (size_t)n_pad * W;         // [n_waves + 1][3][W]: q1, q5, q3 of a wave's last
+    uint8_t *padflag   = reinterpret_cast<uint8_t *>(pal + 256);  // [n_pad][W]: which of the two pad colours
+    const int pad_words = (n_pad * W + 3) / 4;
+    uint32_t *boundary = pal + 256 + pad_words;              // [n_waves + 1][3][W]: q1, q5, q3 of a wave's last
                                                              // row; the extra row receives the bridge
     // columns published by each wave's last row.  All hand-over traffic is LDS traffic of
     // the form "data, then counter" from ONE wave, which the LDS executes in order: no
@@ -744,7 +748,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                           ((uint32_t)s.palette[i * 3 + 1] << 16) | ((uint32_t)s.palette[i * 3 + 2] << 24))
                        : 0u;
     }
-    for (int i = tid; i < n_pad * W; i += blockDim.x) padpix[i] = PaddedPixel(frame, g, i % W, g.h + i / W);
+    for (int i = tid; i < n_pad * W; i += blockDim.x)
+        padflag[i] = PaddedPixel(frame, g, i % W, g.h + i / W) == g.pad[1] ? 1 : 0;
     if (tid < n_waves) progress[tid] = 0;
     const bool dither = s.meta[1] != 0;
     __syncthreads();
@@ -759,7 +764,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // where this lane's pixels come from: a frame row in memory or a pad row in LDS
         const bool is_pad       = row >= g.h;
         const uint8_t *src_row  = frame + (size_t)min(row, g.h - 1) * g.stride;
-        const uint32_t *pad_row = padpix + (size_t)(is_pad && has_row ? row - g.h : 0) * W;
+        const uint8_t *pad_row  = padflag + (size_t)(is_pad && has_row ? row - g.h : 0) * W;
         uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
         const bool diffuses     = dither && row < H - 1;
         // whose last row lies directly above this wave's first row
@@ -839,7 +844,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         auto fetch_pad = [&](int t) -> uint32_t {
             const int x = t - 2 * lane;
             uint32_t v  = 0u;
-            if (wave_has_pad && has_row && is_pad && x >= 0 && x < W) v = pad_row[x];
+            if (wave_has_pad && has_row && is_pad && x >= 0 && x < W) v = pad_row[x] ? g.pad[1] : g.pad[0];
             return v;
         };
         auto step = [&](int t, uint32_t px_frame, uint32_t px_pad) __attribute__((always_inline)) {
@@ -1077,13 +1082,30 @@ __device__ __forceinline__ int ColumnEntries(const uint8_t *rows, int stride, in
     return n;
 }
 
+template <bool kWide>
 __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
-    const int NE       = g.band_ne;
-    uint32_t *ent_a    = lds;            // sorted entries end up here
-    uint32_t *ent_b    = lds + NE;       // radix partner, then the unsorted node keys
-    uint16_t *nfirst_u = reinterpret_cast<uint16_t *>(lds + 2 * NE);  // first entry of node k
-    uint32_t *aux      = lds + 2 * NE + NE / 2;  // 4096 words: radix histogram / column buckets
+    const int NE = g.band_ne;
+    // aux: 4096 words of radix histogram, later two column-indexed bucket arrays
+    // (kBucket apart).  The sort buffers live in LDS, or -- for frames too wide for that --
+    // in this band's global scratch slots, which later kernels overwrite with their outputs
+    // (ent_a is the final home of the sorted entries anyway).
+    constexpr int kBucket = kWide ? 4096 : 2048;  // columns (<= kMaxSixelWidth resp. kLdsEntries / 6)
+    uint32_t *aux      = lds;
+    uint32_t *ent_a, *ent_b;
+    uint16_t *nfirst_u;
+    {
+        const size_t fslot = ((size_t)blockIdx.y * g.bands + blockIdx.x) * NE;
+        if (kWide) {
+            ent_a    = b.band_ent + fslot;
+            ent_b    = b.band_pi + fslot;
+            nfirst_u = reinterpret_cast<uint16_t *>(b.band_rec + fslot);
+        } else {
+            ent_a    = lds + 2 * kBucket;  // sorted entries end up here
+            ent_b    = ent_a + NE;         // radix partner, then the unsorted node keys
+            nfirst_u = reinterpret_cast<uint16_t *>(ent_b + NE);  // first entry of node k
+        }
+    }
     __shared__ uint32_t s_tmp[5];
 
     const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -1106,6 +1128,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
         at += (uint32_t)n;
     }
+    if (kWide) __threadfence_block();
     __syncthreads();
 
     // ---- stable LSD radix sort by colour: two 4-bit passes, a contiguous chunk per lane
@@ -1117,6 +1140,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         uint32_t *dst       = pass ? ent_a : ent_b;
         for (int d = 0; d < 16; ++d) aux[d * 256 + tid] = 0;
         for (int i = e0; i < e1; ++i) aux[((src[i] >> shift) & 15u) * 256 + tid] += 1;
+        if (kWide) __threadfence_block();
         __syncthreads();
         // exclusive scan over the 4096 counters in (digit, lane) order
         uint32_t sum = 0;
@@ -1127,12 +1151,14 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             aux[tid * 16 + j] = run;
             run += t;
         }
+        if (kWide) __threadfence_block();
         __syncthreads();
         for (int i = e0; i < e1; ++i) {
             const uint32_t e = src[i];
             const uint32_t d = (e >> shift) & 15u;
             dst[aux[d * 256 + tid]++] = e;
         }
+        if (kWide) __threadfence_block();
         __syncthreads();
     }
 
@@ -1150,9 +1176,10 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     for (int i = e0; i < e1; ++i)
         if (i == 0 || breaks(i)) nfirst_u[k++] = (uint16_t)i;
     for (int x = tid; x <= W; x += 256) {
-        aux[x]         = 0;  // nodes starting in column x
-        aux[2048 + x]  = 0;  // fill counter
+        aux[x]           = 0;  // nodes starting in column x
+        aux[kBucket + x] = 0;  // fill counter
     }
+    if (kWide) __threadfence_block();
     __syncthreads();
     uint32_t *key_u = ent_b;
     for (int n = tid; n < n_nodes; n += 256) {
@@ -1163,6 +1190,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         key_u[n]          = (sx << 20) | ((4095u - mx) << 8) | (e >> 22);
         atomicAdd(&aux[sx], 1u);
     }
+    if (kWide) __threadfence_block();
     __syncthreads();
     // bucket bases: exclusive scan over the columns
     {
@@ -1177,21 +1205,23 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             run += t;
         }
     }
+    if (kWide) __threadfence_block();
     __syncthreads();
     uint32_t *nkey   = s.band_nkey + slot;
     uint16_t *nfirst = s.band_nfirst + slot;
     for (int n = tid; n < n_nodes; n += 256) {
         const uint32_t key = key_u[n];
         const uint32_t sx  = key >> 20;
-        const uint32_t pos = aux[sx] + atomicAdd(&aux[2048 + sx], 1u);
+        const uint32_t pos = aux[sx] + atomicAdd(&aux[kBucket + sx], 1u);
         nkey[pos]          = key;
         nfirst[pos]        = nfirst_u[n];
     }
+    if (kWide) __threadfence_block();
     __syncthreads();  // (also orders the global writes above inside the workgroup)
     // nodes starting in the same column (at most 6: one per colour of the column):
     // order them by end desc, colour asc = ascending key
     for (int x = tid; x < W; x += 256) {
-        const int c = (int)aux[2048 + x];
+        const int c = (int)aux[kBucket + x];
         if (c < 2) continue;
         const uint32_t base = aux[x];
         uint32_t kk[6];
@@ -1217,8 +1247,10 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             nfirst[base + j] = ff[j];
         }
     }
-    uint32_t *ent_g = s.band_ent + slot;
-    for (int i = tid; i < n_ent; i += 256) ent_g[i] = ent_a[i];
+    if (!kWide) {
+        uint32_t *ent_g = s.band_ent + slot;
+        for (int i = tid; i < n_ent; i += 256) ent_g[i] = ent_a[i];
+    }
     if (tid == 0) {
         s.band_cnt[band * 4 + 0] = n_ent;
         s.band_cnt[band * 4 + 1] = n_nodes;
@@ -1327,7 +1359,7 @@ __global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b,
         const uint32_t v    = pi[i];
         const uint32_t pass = v >> 16, idx = v & 0xffffu;
         const uint32_t cr   = (idx == 0 && pass != 0) ? 1u : 0u;  // first node of a later pass: '$'
-        rec[pb[pass] + idx] = make_uint2(nkey[i], (uint32_t)nfirst[i] | ((uint32_t)xs[i] << 13) | (cr << 24));
+        rec[pb[pass] + idx] = make_uint2(nkey[i], (uint32_t)nfirst[i] | ((uint32_t)xs[i] << 15) | (cr << 27));
     }
 }
 
@@ -1350,9 +1382,9 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
                         bool *cr) {
         const uint2 r      = rec[k];
         const uint32_t key = r.x;
-        *node_first        = (int)(r.y & 0x1fffu);
-        *x_start           = (int)((r.y >> 13) & 0x7ffu);
-        *cr                = ((r.y >> 24) & 1u) != 0;
+        *node_first        = (int)(r.y & 0x7fffu);
+        *x_start           = (int)((r.y >> 15) & 0xfffu);
+        *cr                = ((r.y >> 27) & 1u) != 0;
         *color             = (int)(key & 0xffu);
         *sx                = (int)(key >> 20);
         *mx                = 4095 - (int)((key >> 8) & 0xfffu);
@@ -1663,7 +1695,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     int dither_parts = 1;
     int dither_waves = std::max(1, std::min(kDitherMaxWaves, rows64));
     auto dither_bytes = [&](int waves) {
-        return (8192 + 256 + (size_t)(g.h6 - h) * w + (size_t)(waves + 1) * 3 * w) * sizeof(uint32_t);
+        return (8192 + 256 + ((size_t)(g.h6 - h) * w + 3) / 4 + (size_t)(waves + 1) * 3 * w) * sizeof(uint32_t);
     };
     // MEASURED (MI355X, 800x450): two workgroups per frame are NOT faster (0.96 vs 0.94 ms): a
     // wave issues in order, so a step costs its ~165 instructions plus two LDS round trips no
@@ -1675,15 +1707,20 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     }
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
-    const size_t nodes_lds  = ((size_t)2 * g.band_ne + g.band_ne / 2 + 4096) * sizeof(uint32_t);
+    const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
+    const size_t nodes_lds  = wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
+                                         : ((size_t)2 * 2048 + 2 * g.band_ne + g.band_ne / 2 + 16) * sizeof(uint32_t);
     const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dither_lds));
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)BandNodesKernel,
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true>
+                                                     : (const void *)BandNodesKernel<false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)nodes_lds));
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)BandEmitKernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kCutLdsBytes));
@@ -1748,7 +1785,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
             TIMG_HIP_TRY(ctx, hipMemsetAsync(gb.bridge, 0, (size_t)nfr * w * 2 * sizeof(unsigned long long), gs));
         hipLaunchKernelGGL(DitherKernel, dim3(nfr * dither_parts), dim3(dither_waves * 64), dither_lds, gs, g,
                            gb, dither_parts);
-        hipLaunchKernelGGL(BandNodesKernel, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
+        if (wide_bands)
+            hipLaunchKernelGGL(BandNodesKernel<true>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
+        else
+            hipLaunchKernelGGL(BandNodesKernel<false>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * nfr + 3) / 4), dim3(256), 0, gs, g, gb, nfr);
         hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, nfr), dim3(256), emit_lds, gs, g, gb);
         hipLaunchKernelGGL(AssembleFrameKernel, dim3(nfr), dim3(256), 0, gs, g, gb);

@@ -14,7 +14,7 @@
  *   dropped, default Floyd-Steinberg diffusion, RGB palette in percent.
  * What can be and is verified independently: the emitted stream is valid
  * sixel (oracle_sixel_decode round trip), uses <=256 colours, and reproduces
- * the input within a Delta-E bound (tests/test_sixel.py).
+ * the input within a Delta-E bound (tests/test_sixel_oracle.py).
  *
  * lookup_mode 0: libsixel's lossy nearest-colour cache -- the first pixel that
  *   lands in a 15-bit (5:5:5) cell decides the palette entry of every later

@@ -245,6 +245,20 @@ def test_sixel_geometry_corner_cases(hip, oracle, kind, w, h):
     assert len(got) == len(want) and got == want, (len(got), len(want))
 
 
+def test_sixel_within_stated_delta_e_of_the_libsixel_like_lookup(hip, oracle):
+    """north_star: sixel palette selection within a stated dE.  The HIP path (exact nearest
+    colour per 15-bit cell) against the restatement's libsixel-like lossy lookup cache
+    (lookup_mode 0), both decoded by the independent decoder: mean CIE76 dE to the source below
+    4.0 for both, and within 0.5 of each other (the tolerances of tests/test_sixel_oracle.py)."""
+    from test_sixel_oracle import DE_PHOTO, mean_delta_e
+    fb = synth.photo(800, 450, seed=3)
+    got = hip.sixel_encode(fb, 800, 450, pad_blend=timg_amd.Blend.make(BG))[0]
+    like_libsixel = oracle.sixel_encode(fb, BG, lookup_mode=0)
+    de_hip = mean_delta_e(oracle.sixel_decode(got)[0][:450, :, :3], fb[..., :3])
+    de_ref = mean_delta_e(oracle.sixel_decode(like_libsixel)[0][:450, :, :3], fb[..., :3])
+    assert de_hip < DE_PHOTO and de_ref < DE_PHOTO and abs(de_hip - de_ref) < 0.5, (de_hip, de_ref)
+
+
 def test_sixel_round_trip_decodes_to_the_palette_image(hip, oracle):
     """Size-independent property at the BASELINE frame size: the stream decodes (independent
     decoder) to a full 800x450 raster whose every pixel is a palette colour close to the

@@ -1063,10 +1063,7 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_t
 
 // distinct colours of one column of a band: up to 6 (colour, row mask) pairs in
 // order of first occurrence
-__device__ __forceinline__ int ColumnEntries(const uint8_t *rows, int stride, int x, uint32_t ent[6]) {
-    uint32_t c[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) c[r] = rows[(size_t)r * stride + x];
+__device__ __forceinline__ int ColumnEntries(const uint32_t c[6], int x, uint32_t ent[6]) {
     uint32_t done = 0;
     int n         = 0;
 #pragma unroll
@@ -1114,20 +1111,46 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     const uint8_t *rows       = s.index + (size_t)band * 6 * g.idx_stride;
     const size_t slot         = (size_t)band * NE;
 
-    // ---- entries, column-major: count, scan, write
-    const int per_c = (W + 255) / 256;
-    const int x0 = min(W, tid * per_c), x1 = min(W, x0 + per_c);
-    uint32_t mine = 0;
+    // ---- entries, column-major: count, scan, write.  A lane takes kGroups x 4 adjacent
+    // columns; the six index rows of a group arrive as six 4-byte loads (the rows of the
+    // index image are padded to 4) that are issued together and kept for both passes.
+    constexpr int kGroups = 4;  // 256 lanes x 4 groups x 4 columns >= kMaxSixelWidth
+    const int n_groups    = (W + 3) / 4;
+    const int per_g       = (n_groups + 255) / 256;
+    const int g0 = min(n_groups, tid * per_g), g1 = min(n_groups, g0 + per_g);
+    uint32_t cw[kGroups][6];
+#pragma unroll
+    for (int gi = 0; gi < kGroups; ++gi)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            cw[gi][r] = g0 + gi < g1 ? *reinterpret_cast<const uint32_t *>(rows + (size_t)r * g.idx_stride +
+                                                                         4 * (g0 + gi))
+                                     : 0u;
     uint32_t e6[6];
-    for (int x = x0; x < x1; ++x) mine += (uint32_t)ColumnEntries(rows, g.idx_stride, x, e6);
+    auto for_columns = [&](auto &&visit) {
+#pragma unroll
+        for (int gi = 0; gi < kGroups; ++gi) {
+            if (g0 + gi >= g1) break;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int x = 4 * (g0 + gi) + q;
+                if (x >= W) break;
+                uint32_t c[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) c[r] = (cw[gi][r] >> (8 * q)) & 0xffu;
+                visit(ColumnEntries(c, x, e6));
+            }
+        }
+    };
+    uint32_t mine = 0;
+    for_columns([&](int n) { mine += (uint32_t)n; });
     uint32_t n_ent_u;
     uint32_t at = BlockExclusiveScan(mine, s_tmp, &n_ent_u);
     const int n_ent = (int)n_ent_u;
-    for (int x = x0; x < x1; ++x) {
-        const int n = ColumnEntries(rows, g.idx_stride, x, e6);
+    for_columns([&](int n) {
         for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
         at += (uint32_t)n;
-    }
+    });
     if (kWide) __threadfence_block();
     __syncthreads();
 

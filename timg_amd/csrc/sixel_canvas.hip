@@ -627,27 +627,31 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b) {
     const int f               = blockIdx.y;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    __shared__ uint32_t pal[kMaxColors];  // r | g << 8 | b << 16: one broadcast read per entry
+    // |cell - entry|^2 = |cell|^2 + |entry|^2 - 2 <cell, entry>: the byte dot product is one
+    // instruction (v_dot4_u32_u8); all integer, the same numbers as the direct form.
+    __shared__ uint2 pal[kMaxColors];  // {r | g << 8 | b << 16, r^2 + g^2 + b^2}: broadcast reads
     const int ncolors = s.meta[0];
-    for (int i = threadIdx.x; i < ncolors; i += 256)
-        pal[i] = (uint32_t)s.palette[i * 3] | ((uint32_t)s.palette[i * 3 + 1] << 8) |
-                 ((uint32_t)s.palette[i * 3 + 2] << 16);
+    for (int i = threadIdx.x; i < ncolors; i += 256) {
+        const uint32_t pr = s.palette[i * 3], pg = s.palette[i * 3 + 1], pb = s.palette[i * 3 + 2];
+        pal[i] = make_uint2(pr | (pg << 8) | (pb << 16), pr * pr + pg * pg + pb * pb);
+    }
     __syncthreads();
     const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
-    const int r = (int)(((cell >> 10) & 0x1f) << 3 | 4), gg = (int)(((cell >> 5) & 0x1f) << 3 | 4),
-              bl = (int)((cell & 0x1f) << 3 | 4);
+    const uint32_t r = ((cell >> 10) & 0x1f) << 3 | 4, gg = ((cell >> 5) & 0x1f) << 3 | 4,
+                   bl = (cell & 0x1f) << 3 | 4;
+    const uint32_t me = r | (gg << 8) | (bl << 16);
+    const int me2     = (int)(r * r + gg * gg + bl * bl);
     int best = 0, diff = 0x7fffffff;
 #pragma unroll 4
     for (int i = 0; i < ncolors; ++i) {
-        const uint32_t c = pal[i];
-        const int dr = r - (int)(c & 0xffu), dg = gg - (int)((c >> 8) & 0xffu), db = bl - (int)((c >> 16) & 0xffu);
-        const int d  = dr * dr + dg * dg + db * db;
+        const uint2 c = pal[i];
+        const int d   = me2 + (int)c.y - 2 * (int)__builtin_amdgcn_udot4(me, c.x, 0u, false);
         if (d < diff) {  // strict: the first of equally near entries wins
             diff = d;
             best = i;
         }
     }
-    s.lut[cell] = (uint32_t)best | (pal[best] << 8);
+    s.lut[cell] = (uint32_t)best | (pal[best].x << 8);
 }
 
 // ---- K4: lookup + Floyd-Steinberg -----------------------------------------------------

@@ -519,19 +519,26 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
                     cl[q] = in ? l_col[cur][i] : 0u;
                     id[q] = in ? l_id[cur][i] : 0u;
                 }
-                // first box (in sum-descending order) that still holds >= 2 colours
-                uint32_t bi = 0xffffffffu;
+                // first box (in sum-descending order) that still holds >= 2 colours; whether its
+                // split is prepared and which box it is come out of the same registers
+                uint32_t bi = 0xffffffffu, bi_id = 0;
+                bool bi_ready = false;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const unsigned long long m = __ballot((cl[q] & ~kReady) >= 2);
-                    if (m && bi == 0xffffffffu) bi = q * 64 + (uint32_t)__ffsll((long long)m) - 1;
+                    if (m && bi == 0xffffffffu) {
+                        const int l = __ffsll((long long)m) - 1;
+                        bi          = q * 64 + (uint32_t)l;
+                        bi_ready    = ((uint32_t)__builtin_amdgcn_readlane((int)cl[q], l) & kReady) != 0;
+                        bi_id       = (uint32_t)__builtin_amdgcn_readlane((int)id[q], l);
+                    }
                 }
                 if (bi == 0xffffffffu) {
                     done = 1;
                     break;
                 }
-                if (!(l_col[cur][bi] & kReady)) break;  // its split has not been prepared yet: next round
-                const CutBox box      = pool[l_id[cur][bi]];
+                if (!bi_ready) break;  // its split has not been prepared yet: next round
+                const CutBox box      = pool[bi_id];
                 const uint32_t median = box.median, lowersum = box.lowersum;
                 // replace the box by its halves and restore the stable sum-descending order:
                 // the low half keeps the parent's place in the pre-sort sequence, the high

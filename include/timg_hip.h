@@ -161,6 +161,15 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
                           size_t out_cap, int out_on_device, size_t *out_len,
                           void *stream);
 
+/* The same for one row of a --grid: frame i is the image of grid column i, Sent at
+ * x = x_indents[i] pixels (MultiColumnRenderer, src/renderer.cc:81-189, calls Send once per
+ * image with its column's x).  x_indents: host int[n_frames]. */
+int timg_hip_block_encode_grid(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
+                               int stride, size_t frame_stride, int fb_on_device,
+                               int n_frames, int flags, const int *x_indents, char *out,
+                               size_t out_cap, int out_on_device, size_t *out_len,
+                               void *stream);
+
 /* Stateful canvas = one UnicodeBlockCanvas object: keeps what the reference
  * keeps between Sends (last height / indent and the backing store of the
  * previous frame, src/unicode-block-canvas.h:66-79) on the device, so that

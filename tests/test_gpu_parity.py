@@ -425,6 +425,11 @@ def test_baseline_config3_grid_of_4k_frames_quarter_block(hip, oracle):
     outs = hip.block_encode(dst.data_ptr(), 200, 56, flags=timg_amd.TimgHip.QUARTER, n_frames=n)
     for i in range(n):
         assert outs[i] == oracle.block_encode(scaled[i], quarter=True), i
+    # the whole grid row in ONE launch, every frame with its own column offset
+    xs = [i * 202 for i in range(n)]
+    outs = hip.block_encode(dst.data_ptr(), 200, 56, flags=timg_amd.TimgHip.QUARTER, n_frames=n, x_indents=xs)
+    for i in range(n):
+        assert outs[i] == oracle.block_encode(scaled[i], quarter=True, x=xs[i]), i
     sc.close()
 
 

@@ -42,6 +42,7 @@ struct BlockGeom {
     int rows;            // text rows: (h + 1) / 2
     int row_offset;      // -1 when an odd height shifts everything down (:356-358)
     int indent;          // Send's x in character cells
+    const int *indents;  // per frame (a grid row's images side by side), or null: `indent` for all
     int emit_diff;       // compare against the previous frame
     size_t stride, frame_stride;
 };
@@ -310,7 +311,7 @@ ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
         // cursor-right in front of an emitted cell: cells skipped since the last
         // emitted one; the row starts with x_skip = indent (:240)
         const int prev_present = prev_p >= 0 ? c0 + prev_p : last_present;
-        const uint32_t skip    = present ? (uint32_t)(i - prev_present - 1 + (prev_present < 0 ? g.indent : 0)) : 0u;
+        const uint32_t skip    = present ? (uint32_t)(i - prev_present - 1 + (prev_present < 0 ? (g.indents ? g.indents[f] : g.indent) : 0)) : 0u;
 
         const uint32_t bg_from_lane = __shfl(rec.bg, prev_p < 0 ? 0 : prev_p);
         const bool left_known       = prev_p >= 0 || last_present >= 0;
@@ -592,6 +593,7 @@ BlockGeom MakeGeom(int w, int h, int stride, size_t frame_stride, int flags, int
     g.rows         = (h + 1) / 2;
     g.row_offset   = ((h & 1) && !g.upper) ? -1 : 0;
     g.indent       = g.quarter ? x_indent / 2 : x_indent;
+    g.indents      = nullptr;
     g.emit_diff    = 0;
     g.stride       = (size_t)stride;
     g.frame_stride = frame_stride;
@@ -625,12 +627,15 @@ size_t timg_hip_block_max_bytes(int w, int h) {
     return 8 + rows * (8 + (size_t)w * max_pixel + 5);
 }
 
-int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
-                          size_t frame_stride, int fb_on_device, int n_frames, int flags,
-                          int x_indent, char *out, size_t out_cap, int out_on_device,
-                          size_t *out_len, void *stream) {
+static int BlockEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                           size_t frame_stride, int fb_on_device, int n_frames, int flags, int x_indent,
+                           const int *x_indents, char *out, size_t out_cap, int out_on_device,
+                           size_t *out_len, void *stream) {
     if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0 || x_indent < 0)
         return TIMG_HIP_ERR_ARG;
+    if (x_indents)
+        for (int i = 0; i < n_frames; ++i)
+            if (x_indents[i] < 0) return TIMG_HIP_ERR_ARG;
     if (stride == 0) stride = w * 4;
     if (stride < w * 4 || (stride & 3) || ((uintptr_t)fb & 3))
         return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride/alignment");
@@ -639,7 +644,15 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, in
     hipStream_t st = ctx->Stream(stream);
     std::lock_guard<std::mutex> lock(ctx->mu);
 
-    const BlockGeom g = MakeGeom(w, h, stride, frame_stride, flags, x_indent);
+    BlockGeom g = MakeGeom(w, h, stride, frame_stride, flags, x_indent);
+    if (x_indents) {  // per-frame Send x (in cells), uploaded next to the other scratch
+        TIMG_HIP_TRY(ctx, ctx->dev[6].Reserve(sizeof(int) * n_frames));
+        TIMG_HIP_TRY(ctx, ctx->pin[1].Reserve(sizeof(int) * n_frames));
+        int *host = (int *)ctx->pin[1].ptr;
+        for (int i = 0; i < n_frames; ++i) host[i] = g.quarter ? x_indents[i] / 2 : x_indents[i];
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[6].ptr, host, sizeof(int) * n_frames, hipMemcpyHostToDevice, st));
+        g.indents = (const int *)ctx->dev[6].ptr;
+    }
     const size_t fb_bytes = frame_stride * (size_t)(n_frames - 1) + (size_t)stride * h;
     const uint8_t *dfb    = fb;
     if (!fb_on_device) {
@@ -683,6 +696,23 @@ int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, in
         TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     return TIMG_HIP_OK;
+}
+
+int timg_hip_block_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                          size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                          int x_indent, char *out, size_t out_cap, int out_on_device,
+                          size_t *out_len, void *stream) {
+    return BlockEncodeImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, x_indent,
+                           nullptr, out, out_cap, out_on_device, out_len, stream);
+}
+
+int timg_hip_block_encode_grid(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                               size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                               const int *x_indents, char *out, size_t out_cap, int out_on_device,
+                               size_t *out_len, void *stream) {
+    if (!x_indents) return TIMG_HIP_ERR_ARG;
+    return BlockEncodeImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, 0,
+                           x_indents, out, out_cap, out_on_device, out_len, stream);
 }
 
 int timg_hip_block_canvas_create(timg_hip_ctx *ctx, int flags, timg_hip_block_canvas **out) {

@@ -86,6 +86,9 @@ def load_library():
     L.timg_hip_block_max_bytes.restype = c_size_t
     L.timg_hip_block_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
                                         c_int, c_int, vp, c_size_t, c_int, POINTER(c_size_t), vp]
+    L.timg_hip_block_encode_grid.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
+                                             c_int, POINTER(c_int), vp, c_size_t, c_int,
+                                             POINTER(c_size_t), vp]
     L.timg_hip_block_canvas_create.argtypes = [vp, c_int, POINTER(vp)]
     L.timg_hip_block_canvas_destroy.argtypes = [vp]
     L.timg_hip_block_canvas_destroy.restype = None
@@ -260,8 +263,9 @@ class TimgHip:
         return int(self.L.timg_hip_block_max_bytes(w, h))
 
     def block_encode(self, fb, w, h, flags=0, x_indent=0, n_frames=1, out=None, out_cap=None,
-                     stride=0, frame_stride=0, stream=None):
-        """Returns list[bytes] (host out) or the lengths (device out)."""
+                     stride=0, frame_stride=0, stream=None, x_indents=None):
+        """Returns list[bytes] (host out) or the lengths (device out).  x_indents: one Send x
+        per frame (a grid row) instead of the common x_indent."""
         p, dev = _ptr(fb)
         if out_cap is None:
             out_cap = self.block_max_bytes(w, h)
@@ -270,10 +274,16 @@ class TimgHip:
             out = np.empty(out_cap * n_frames, np.uint8)
         op, o_dev = _ptr(out)
         lens = (c_size_t * n_frames)()
-        self._check(self.L.timg_hip_block_encode(self.ctx, p, w, h, stride, frame_stride, int(dev),
-                                                 n_frames, flags, x_indent, op, out_cap,
-                                                 int(o_dev), lens,
-                                                 c_void_p(stream) if stream else None))
+        if x_indents is not None:
+            xs = (c_int * n_frames)(*[int(v) for v in x_indents])
+            self._check(self.L.timg_hip_block_encode_grid(self.ctx, p, w, h, stride, frame_stride, int(dev),
+                                                          n_frames, flags, xs, op, out_cap, int(o_dev), lens,
+                                                          c_void_p(stream) if stream else None))
+        else:
+            self._check(self.L.timg_hip_block_encode(self.ctx, p, w, h, stride, frame_stride, int(dev),
+                                                     n_frames, flags, x_indent, op, out_cap,
+                                                     int(o_dev), lens,
+                                                     c_void_p(stream) if stream else None))
         if host_out:
             return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
         return list(lens)

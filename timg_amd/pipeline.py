@@ -49,9 +49,12 @@ class GridPipeline:
                                          out=self.out.data_ptr(), out_cap=self.cap, stream=st)
         else:
             flags = {"half": 0, "quarter": TimgHip.QUARTER}[self.mode]
+            # --grid=8x8: frame i sits in grid column i % 8, i.e. is Sent at that column's x
+            # (the renderer leaves two pixel columns between images)
+            xs = [(i % 8) * (self.out_w + 2) for i in range(self.n)]
             lens = self.hip.block_encode(self.scaled.data_ptr(), self.out_w, self.out_h, flags=flags,
                                          n_frames=self.n, out=self.out.data_ptr(), out_cap=self.cap,
-                                         stream=st)
+                                         stream=st, x_indents=xs)
         self.lengths = lens
         return lens
 

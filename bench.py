@@ -109,7 +109,7 @@ def main():
     import torch.distributed as dist
     import timg_amd
     from timg_amd.gather import gather_frames_to_root
-    from timg_amd.pipeline import GridPipeline, synth_frames_on_device
+    from timg_amd.pipeline import GridPipeline, run_batched_streams, synth_frames_on_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -143,49 +143,16 @@ def main():
     for p in pipes:
         p.stream.wait_stream(torch.cuda.current_stream())
 
+    def record(stream):
+        # HIP events on the stream the kernels are launched on
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
     def run_steps(n_steps, timed_events=None, n_pipes=n_pipes):
         """n_steps passes of the hot path, step k on stream k % P; with several ranks the
         outputs are gathered to rank 0 in step order by this (the main) thread."""
-        done = [threading.Event() for _ in range(n_steps)]
-        consumed = [threading.Event() for _ in range(n_steps)]
-        errors = []
-
-        def worker(i):
-            try:
-                p = pipes[i]
-                for k in range(i, n_steps, n_pipes):
-                    if world > 1 and k >= n_pipes:
-                        consumed[k - n_pipes].wait()  # this stream's previous output has been gathered
-                    # HIP events on the stream the kernels are launched on
-                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                    e0.record(p.stream)
-                    p.scale(src)
-                    e1.record(p.stream)
-                    p.encode()
-                    e2.record(p.stream)
-                    if timed_events is not None:
-                        timed_events.append((e0, e1, e2))
-                    done[k].set()
-            except Exception as exc:  # surface worker failures instead of hanging the gather loop
-                errors.append(exc)
-                for ev in done:
-                    ev.set()
-
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(min(n_pipes, n_steps))]
-        for t in threads:
-            t.start()
-        if world > 1:
-            for k in range(n_steps):
-                done[k].wait()
-                if errors:
-                    break
-                payload, lens = pipes[k % n_pipes].packed_output()
-                gather_frames_to_root(payload, lens)
-                consumed[k].set()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+        run_batched_streams(pipes, src, n_steps, n_pipes, world, gather_frames_to_root, timed_events, record)
 
     def timed(n_steps, n_pipes, timed_events=None):
         torch.cuda.synchronize()

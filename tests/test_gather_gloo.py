@@ -78,3 +78,78 @@ def test_shard_frames_partitions_exactly():
                     assert all(o == list(range(r, n, world)) for r, o in enumerate(owned))
                 else:
                     assert all(o == sorted(o) and (not o or o[-1] - o[0] == len(o) - 1) for o in owned)
+
+
+# ---- the multi-pipeline step runner of bench.py on CPU (fake pipelines, gloo) -----------------
+class _FakePipe:
+    """Stands in for GridPipeline: 'encodes' a batch of 4 frames whose bytes depend on
+    (rank, call number) so that ordering mistakes show."""
+
+    def __init__(self, rank, pipe_id):
+        self.rank, self.pipe_id, self.calls, self.stream = rank, pipe_id, 0, None
+        self._out = None
+
+    def scale(self, src):
+        pass
+
+    def encode(self):
+        import time
+        time.sleep(0.002 * ((self.pipe_id + self.calls) % 3))  # uneven speeds
+        step = self.pipe_id + 3 * self.calls  # the global step this pipeline is running (3 pipelines)
+        self.calls += 1
+        frames = [np.full(1 + (step + i + self.rank) % 7, (step * 4 + i + 50 * self.rank) % 251, np.uint8)
+                  for i in range(4)]
+        self._out = frames
+
+    def packed_output(self):
+        lens = torch.tensor([len(f) for f in self._out], dtype=torch.int64)
+        return torch.from_numpy(np.concatenate(self._out)), lens
+
+
+def _runner_worker(rank, world, port, n_steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from timg_amd.pipeline import run_batched_streams
+        pipes = [_FakePipe(rank, i) for i in range(3)]
+        seen = []
+
+        def gather(payload, lens):
+            got = gather_frames_to_root(payload, lens)
+            if rank == 0:
+                seen.append([[t.numpy().copy() for t in frames] for frames in got])
+
+        run_batched_streams(pipes, None, n_steps, 3, world, gather)
+        if rank == 0:
+            ok = len(seen) == n_steps
+            for step, per_rank in enumerate(seen):
+                for r in range(world):
+                    for i in range(4):
+                        want = np.full(1 + (step + i + r) % 7, (step * 4 + i + 50 * r) % 251, np.uint8)
+                        ok = ok and np.array_equal(per_rank[r][i], want)
+            q.put(bool(ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_steps", [(2, 7), (2, 2)])
+def test_batched_streams_gather_in_step_order(world, n_steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_runner_worker, args=(r, world, port, n_steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() is True
+
+
+def test_batched_streams_single_rank_runs_every_step():
+    from timg_amd.pipeline import run_batched_streams
+    pipes = [_FakePipe(0, i) for i in range(3)]
+    run_batched_streams(pipes, None, 8, 3)
+    assert sorted(p.calls for p in pipes) == [2, 3, 3]

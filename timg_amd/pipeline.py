@@ -75,6 +75,59 @@ class GridPipeline:
         self.scaler.close()
 
 
+def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, timed_events=None,
+                        record_event=None):
+    """n_steps passes of the hot path over `src`, step k on pipeline k % n_pipes, every pipeline
+    driven by its own host thread (one batch in flight per pipeline).  With several ranks the
+    variable-length outputs are handed to `gather(payload, lengths)` by the CALLING thread in
+    step order -- collectives must be issued in the same order on every rank -- and a pipeline
+    starts its next step only after its previous output has been gathered.
+
+    pipes: objects with scale(src), encode(), packed_output() (and .stream when record_event is
+    given); record_event(stream) -> event, used to bracket the two stages of each step."""
+    import threading
+    done = [threading.Event() for _ in range(n_steps)]
+    consumed = [threading.Event() for _ in range(n_steps)]
+    errors = []
+
+    def worker(i):
+        try:
+            p = pipes[i]
+            for k in range(i, n_steps, n_pipes):
+                if world > 1 and k >= n_pipes:
+                    consumed[k - n_pipes].wait()
+                e0 = record_event(p.stream) if record_event else None
+                p.scale(src)
+                e1 = record_event(p.stream) if record_event else None
+                p.encode()
+                e2 = record_event(p.stream) if record_event else None
+                if timed_events is not None and record_event:
+                    timed_events.append((e0, e1, e2))
+                done[k].set()
+        except Exception as exc:  # surface worker failures instead of hanging the gather loop
+            errors.append(exc)
+            for ev in done:
+                ev.set()
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(min(n_pipes, n_steps))]
+    for t in threads:
+        t.start()
+    if world > 1:
+        for k in range(n_steps):
+            done[k].wait()
+            if errors:
+                break
+            payload, lens = pipes[k % n_pipes].packed_output()
+            gather(payload, lens)
+            consumed[k].set()
+    for t in threads:
+        t.join()
+    if errors:
+        for ev in consumed:  # (nobody is left waiting)
+            ev.set()
+        raise errors[0]
+
+
 def synth_frames_on_device(n: int, w: int, h: int, kind: str = "photo", seed: int = 0,
                            device: str = "cuda") -> torch.Tensor:
     """Seeded synthetic RGBA8 frames generated on the device (nothing crosses

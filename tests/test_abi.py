@@ -62,3 +62,28 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".cc", ".h")):
                 body = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "libtimg_oracle" not in body and "oracle_lib" not in body, f
+
+
+def test_header_is_valid_c99():
+    """The drop-in boundary is a C header: it must compile as C, not only as C++."""
+    import subprocess
+    src = '#include "timg_hip.h"\nint main(void) { return timg_hip_version() ? 0 : 1; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I",
+                        os.path.join(ROOT, "include"), "-x", "c", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs_and_matches_the_python_binding(oracle):
+    """examples/abi_demo.c (plain C against the C-ABI): its sixel stream decodes to the 320x200
+    picture, its quarter-block output is what the oracle produces for the same pixels."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "abi_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/abi_demo not built")
+    six = subprocess.run([exe], capture_output=True, timeout=120)
+    assert six.returncode == 0, six.stderr.decode()
+    img, ncolors = oracle.sixel_decode(six.stdout[six.stdout.index(b"\x1bP"):])
+    assert img.shape[:2] == (204, 320) and 2 <= ncolors <= 256
+    q = subprocess.run([exe, "quarter"], capture_output=True, timeout=120)
+    assert q.returncode == 0 and q.stdout.count(b"\n") == 100 and b"\xe2\x96" in q.stdout

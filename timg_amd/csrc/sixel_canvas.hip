@@ -48,8 +48,6 @@ struct SixelGeom {
 
 // per-frame device scratch
 struct SixelFrameScratch {
-    uint32_t *hist_cnt;    // [32768]
-    uint32_t *hist_first;  // [32768]
     uint32_t *entries;     // [n_samples]  cnt<<15 | hash for first-seen samples, else 0
     uint32_t *tab_a;       // [32768]
     uint32_t *tab_b;       // [32768]
@@ -72,7 +70,7 @@ struct SixelFrameScratch {
 
 struct SixelBatch {
     const uint8_t *fb;
-    uint32_t *hist_cnt, *hist_first, *entries, *tab_a, *tab_b, *lut;
+    uint32_t *entries, *tab_a, *tab_b, *lut;
     uint8_t *palette;
     int *meta;
     uint8_t *index;
@@ -93,8 +91,6 @@ struct SixelBatch {
 __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, const SixelGeom &g,
                                                           int f) {
     SixelFrameScratch s;
-    s.hist_cnt   = b.hist_cnt + (size_t)f * 32768;
-    s.hist_first = b.hist_first + (size_t)f * 32768;
     s.entries    = b.entries + (size_t)f * g.n_samples;
     s.tab_a      = b.tab_a + (size_t)f * 32768;
     s.tab_b      = b.tab_b + (size_t)f * 32768;
@@ -129,34 +125,73 @@ __device__ __forceinline__ uint32_t Hash555(uint32_t px) {  // r,g,b in the low 
     return ((px & 0xf8u) << 7) | (((px >> 8) & 0xf8u) << 2) | ((px >> 19) & 0x1fu);
 }
 
-// ---- K1 ------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) HistSampleKernel(SixelGeom g, SixelBatch b) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f      = blockIdx.y;
-    if (k >= g.n_samples) return;
-    const SixelFrameScratch s = FrameScratch(b, g, f);
-    const uint32_t p          = k * g.sample_stride_px;
-    const uint32_t px = PaddedPixel(b.fb + (size_t)f * g.frame_stride, g, p % g.w, p / g.w);
-    const uint32_t h  = Hash555(px);
-    atomicAdd(&s.hist_cnt[h], 1u);
-    atomicMin(&s.hist_first[h], k);
-}
+// ---- K1: sampled 15-bit histogram, one workgroup per frame --------------------------------
+// libsixel's computeHistogram walks the samples in order, counts every 5:5:5 colour and
+// lists the colours in first-seen order.  Both tables (first sample index, count) live in
+// LDS, one after the other in the same 128 KB; the result is entries[k] = count<<15 | hash
+// for the sample that saw its colour first, 0 for every other sample -- the global 32768-bin
+// tables of the first version (and their 16 MB memset per batch) are gone.
+constexpr int kHistThreads = 1024;
+constexpr size_t kHistLdsBytes = 32768 * sizeof(uint32_t);
 
-__global__ void __launch_bounds__(256) MarkFirstKernel(SixelGeom g, SixelBatch b) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f      = blockIdx.y;
-    if (k >= g.n_samples) return;
+constexpr int kHistPerThread = 36;  // n_samples <= 2 * 18383 (libsixel's sampling budget)
+
+__global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t hist_lds[];
+    const int f   = blockIdx.x;
+    const int tid = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    const uint32_t p          = k * g.sample_stride_px;
-    const uint32_t px = PaddedPixel(b.fb + (size_t)f * g.frame_stride, g, p % g.w, p / g.w);
-    const uint32_t h  = Hash555(px);
-    uint32_t e        = 0;
-    if (s.hist_first[h] == k) {
-        uint32_t c = s.hist_cnt[h];
-        if (c > 65535u) c = 65535u;  // libsixel's histogram is unsigned short, saturating
-        e = (c << 15) | h;
+    const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
+
+    for (int i = tid; i < 32768; i += kHistThreads) hist_lds[i] = 0xffffffffu;
+    // the thread's samples k = tid, tid + 1024, ...: all loads in flight together, hashes
+    // kept in registers for the passes below; (x, y) advance without divisions
+    uint32_t hash[kHistPerThread];
+    {
+        const uint32_t step = kHistThreads * g.sample_stride_px;
+        const int dx = (int)(step % g.w), dy = (int)(step / g.w);
+        const uint32_t p0 = (uint32_t)tid * g.sample_stride_px;
+        int x = (int)(p0 % g.w), y = (int)(p0 / g.w);
+#pragma unroll
+        for (int j = 0; j < kHistPerThread; ++j) {
+            const bool in = (uint32_t)(tid + j * kHistThreads) < g.n_samples;
+            hash[j]       = in ? Hash555(PaddedPixel(frame, g, x, y)) : 0xffffffffu;
+            x += dx;
+            y += dy;
+            if (x >= g.w) {
+                x -= g.w;
+                ++y;
+            }
+        }
     }
-    s.entries[k] = e;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kHistPerThread; ++j)
+        if (hash[j] != 0xffffffffu) atomicMin(&hist_lds[hash[j]], (uint32_t)(tid + j * kHistThreads));
+    __syncthreads();
+    unsigned long long is_first = 0;
+#pragma unroll
+    for (int j = 0; j < kHistPerThread; ++j)
+        if (hash[j] != 0xffffffffu && hist_lds[hash[j]] == (uint32_t)(tid + j * kHistThreads))
+            is_first |= 1ull << j;
+    __syncthreads();
+    for (int i = tid; i < 32768; i += kHistThreads) hist_lds[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kHistPerThread; ++j)
+        if (hash[j] != 0xffffffffu) atomicAdd(&hist_lds[hash[j]], 1u);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kHistPerThread; ++j) {
+        if (hash[j] == 0xffffffffu) continue;
+        uint32_t e = 0;
+        if ((is_first >> j) & 1ull) {
+            uint32_t c = hist_lds[hash[j]];
+            if (c > 65535u) c = 65535u;  // libsixel's histogram is unsigned short, saturating
+            e = (c << 15) | hash[j];
+        }
+        s.entries[tid + j * kHistThreads] = e;
+    }
 }
 
 // ---- K2: median cut, one workgroup per frame -------------------------------------------
@@ -1578,14 +1613,6 @@ __global__ void __launch_bounds__(256) CopyBandsKernel(SixelGeom g, SixelBatch b
     }
 }
 
-__global__ void InitHistKernel(uint32_t *cnt, uint32_t *first, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        cnt[i]   = 0u;
-        first[i] = 0xffffffffu;
-    }
-}
-
 }  // namespace
 }  // namespace timg_amd
 
@@ -1647,6 +1674,8 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     if (sp == 0) sp = 1;
     g.sample_stride_px = sp;
     g.n_samples        = (npix + sp - 1) / sp;
+    if (g.n_samples > (uint32_t)(kHistPerThread * kHistThreads))
+        return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "sixel: %u samples", g.n_samples);
     g.band_cap         = (size_t)w * 6 * 16 + 1024;  // >= 16 bytes per (column, colour) entry
 
     const size_t fb_bytes = frame_stride * (size_t)(n_frames - 1) + (size_t)stride * h;
@@ -1670,8 +1699,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         off             = align(off + bytes);
         return at;
     };
-    const size_t o_cnt   = carve(nf * 32768 * 4);
-    const size_t o_first = carve(nf * 32768 * 4);
     const size_t o_ent   = carve(nf * g.n_samples * 4);
     const size_t o_ta    = carve(nf * 32768 * 4);
     const size_t o_tb    = carve(nf * 32768 * 4);
@@ -1698,8 +1725,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     char *base = (char *)ctx->dev[5].ptr;
     SixelBatch b;
     b.fb         = dfb;
-    b.hist_cnt   = (uint32_t *)(base + o_cnt);
-    b.hist_first = (uint32_t *)(base + o_first);
     b.entries    = (uint32_t *)(base + o_ent);
     b.tab_a      = (uint32_t *)(base + o_ta);
     b.tab_b      = (uint32_t *)(base + o_tb);
@@ -1755,6 +1780,8 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
                                           (int)nodes_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)BandEmitKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds));
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)HistKernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLdsBytes));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kCutLdsBytes));
@@ -1784,8 +1811,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         SixelBatch gb = b;
         const size_t o = (size_t)f0;
         gb.fb          = b.fb + o * g.frame_stride;
-        gb.hist_cnt    = b.hist_cnt + o * 32768;
-        gb.hist_first  = b.hist_first + o * 32768;
         gb.entries     = b.entries + o * g.n_samples;
         gb.tab_a       = b.tab_a + o * 32768;
         gb.tab_b       = b.tab_b + o * 32768;
@@ -1807,12 +1832,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.out         = b.out + o * b.out_cap;
         gb.out_len     = b.out_len + o;
 
-        const size_t nbins = (size_t)nfr * 32768;
-        hipLaunchKernelGGL(InitHistKernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, gs,
-                           gb.hist_cnt, gb.hist_first, nbins);
-        const dim3 sgrid((g.n_samples + 255) / 256, nfr);
-        hipLaunchKernelGGL(HistSampleKernel, sgrid, dim3(256), 0, gs, g, gb);
-        hipLaunchKernelGGL(MarkFirstKernel, sgrid, dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(HistKernel, dim3(nfr), dim3(kHistThreads), kHistLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(BuildLutKernel, dim3(128, nfr), dim3(256), 0, gs, g, gb);
         if (dither_parts > 1)

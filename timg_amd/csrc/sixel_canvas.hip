@@ -669,31 +669,35 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b) {
     const int f               = blockIdx.y;
     const SixelFrameScratch s = FrameScratch(b, g, f);
-    // |cell - entry|^2 = |cell|^2 + |entry|^2 - 2 <cell, entry>: the byte dot product is one
-    // instruction (v_dot4_u32_u8); all integer, the same numbers as the direct form.
-    __shared__ uint2 pal[kMaxColors];  // {r | g << 8 | b << 16, r^2 + g^2 + b^2}: broadcast reads
+    // |cell - entry|^2 = |cell|^2 + |entry|^2 - 2 <cell, entry>.  |cell|^2 is the same for
+    // every entry, the byte dot product is one instruction (v_dot4_u32_u8), and with the
+    // entry's number in the low 8 bits of the key
+    //     key = (|entry|^2 << 8 | i) - 512 * <cell, entry>
+    // "smallest distance, first of equally near entries" (strict < in libsixel's loop) is a
+    // plain signed minimum.  All integer: the same ordering as the direct form.
+    __shared__ uint2 pal[kMaxColors];  // {r | g << 8 | b << 16, |entry|^2 << 8 | i}: broadcast reads
     const int ncolors = s.meta[0];
     for (int i = threadIdx.x; i < ncolors; i += 256) {
         const uint32_t pr = s.palette[i * 3], pg = s.palette[i * 3 + 1], pb = s.palette[i * 3 + 2];
-        pal[i] = make_uint2(pr | (pg << 8) | (pb << 16), pr * pr + pg * pg + pb * pb);
+        pal[i] = make_uint2(pr | (pg << 8) | (pb << 16), ((pr * pr + pg * pg + pb * pb) << 8) | (uint32_t)i);
     }
     __syncthreads();
-    const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t r = ((cell >> 10) & 0x1f) << 3 | 4, gg = ((cell >> 5) & 0x1f) << 3 | 4,
-                   bl = (cell & 0x1f) << 3 | 4;
-    const uint32_t me = r | (gg << 8) | (bl << 16);
-    const int me2     = (int)(r * r + gg * gg + bl * bl);
-    int best = 0, diff = 0x7fffffff;
-#pragma unroll 4
+    // two cells per thread share every palette read
+    const uint32_t cell0 = blockIdx.x * 512 + threadIdx.x, cell1 = cell0 + 256;
+    const uint32_t me0 = (((cell0 >> 10) & 0x1f) << 3 | 4) | (((cell0 >> 5) & 0x1f) << 3 | 4) << 8 |
+                         ((cell0 & 0x1f) << 3 | 4) << 16;
+    const uint32_t me1 = (((cell1 >> 10) & 0x1f) << 3 | 4) | (((cell1 >> 5) & 0x1f) << 3 | 4) << 8 |
+                         ((cell1 & 0x1f) << 3 | 4) << 16;
+    int k0 = 0x7fffffff, k1 = 0x7fffffff;
+#pragma unroll 8
     for (int i = 0; i < ncolors; ++i) {
         const uint2 c = pal[i];
-        const int d   = me2 + (int)c.y - 2 * (int)__builtin_amdgcn_udot4(me, c.x, 0u, false);
-        if (d < diff) {  // strict: the first of equally near entries wins
-            diff = d;
-            best = i;
-        }
+        k0 = min(k0, (int)c.y - 512 * (int)__builtin_amdgcn_udot4(me0, c.x, 0u, false));
+        k1 = min(k1, (int)c.y - 512 * (int)__builtin_amdgcn_udot4(me1, c.x, 0u, false));
     }
-    s.lut[cell] = (uint32_t)best | (pal[best].x << 8);
+    const int b0 = k0 & 255, b1 = k1 & 255;
+    s.lut[cell0] = (uint32_t)b0 | (pal[b0].x << 8);
+    s.lut[cell1] = (uint32_t)b1 | (pal[b1].x << 8);
 }
 
 // ---- K4: lookup + Floyd-Steinberg -----------------------------------------------------
@@ -1834,7 +1838,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
 
         hipLaunchKernelGGL(HistKernel, dim3(nfr), dim3(kHistThreads), kHistLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
-        hipLaunchKernelGGL(BuildLutKernel, dim3(128, nfr), dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
         if (dither_parts > 1)
             TIMG_HIP_TRY(ctx, hipMemsetAsync(gb.bridge, 0, (size_t)nfr * w * 2 * sizeof(unsigned long long), gs));
         hipLaunchKernelGGL(DitherKernel, dim3(nfr * dither_parts), dim3(dither_waves * 64), dither_lds, gs, g,

@@ -1001,6 +1001,245 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     }
 }
 
+// ---- K4, second form: two lanes per row ----------------------------------------------------
+// A wave issues in order, and with one wave per SIMD the diffusion above is bound by the
+// instructions of one step, not by throughput.  Here a row is handled by a PAIR of lanes:
+// the even lane carries (r, g), the odd lane (b, -) as packed 16-bit values, so add / clamp /
+// the four error terms are v_pk_*_i16 instructions that serve two channels at once and the
+// two lanes together do in one instruction stream what a lane did in three.  A wave covers
+// 32 rows (row y still two columns behind row y-1), the hand-down from the row above is two
+// wave_shr:1 moves, boundary rows and progress counters between waves are those of the first
+// form (same byte layout: r | g << 8 | b << 16 per term).
+typedef short PairI16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ PairI16 AsPair(uint32_t u) { return __builtin_bit_cast(PairI16, u); }
+__device__ __forceinline__ uint32_t AsBits(PairI16 v) { return __builtin_bit_cast(uint32_t, v); }
+
+__device__ __forceinline__ uint32_t FromRowAbove(uint32_t v) {  // the same half of the pair one row up
+    return FromLaneAbove(FromLaneAbove(v));
+}
+__device__ __forceinline__ uint32_t FromPairPartner(uint32_t v) {  // quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ PairI16 ApplyPair(PairI16 v, uint32_t q) {
+    const PairI16 lo = {0, 0}, hi = {255, 255};
+    return __builtin_elementwise_min(__builtin_elementwise_max(v + AsPair(q), lo), hi);
+}
+
+constexpr int kPairRows = 32;  // rows per wave
+
+__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t lds[];
+    const int W = g.w, H = g.h6;
+    const int n_waves  = blockDim.x >> 6;
+    const int n_pad    = H - g.h;
+    uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);
+    uint32_t *pal      = lds + 8192;
+    uint8_t *padflag   = reinterpret_cast<uint8_t *>(pal + 256);
+    const int pad_words = (n_pad * W + 3) / 4;
+    // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it
+    // reads): slot c + 1 holds, for the CONSUMER at column c, the three terms it needs as three
+    // consecutive words {1/16 of e(c-1), 5/16 of e(c), 3/16 of e(c+1)} -- the producer at column x
+    // writes into slots x + 2, x + 1 and x.  Slots nobody writes (1/16 left of column 0, 3/16
+    // right of column W-1) keep the zero they are initialised with.
+    const int brow     = (W + 2) * 3;
+    uint32_t *boundary = pal + 256 + pad_words;  // [n_waves + 1][W + 2][3]
+    __shared__ int progress[kDitherMaxWaves];
+    const int f   = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rl   = lane >> 1;        // row inside the wave
+    const bool odd = (lane & 1) != 0;  // the (b, -) half
+    // v_perm_b32 selectors of this lane's half (0x0c = zero byte)
+    const uint32_t sel_px   = odd ? 0x0c0c0c02u : 0x0c010c00u;  // RGBA pixel     -> (r, g) / (b, 0)
+    const uint32_t sel_pal  = odd ? 0x0c0c0c03u : 0x0c020c01u;  // idx|r|g|b word -> (r, g) / (b, 0)
+    const uint32_t sel_term = odd ? 0x0c0c020cu : 0x010c000cu;  // term bytes -> HIGH byte of each half
+    const int cell_shift    = odd ? 0 : 10;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
+    for (int i = tid; i < 8192; i += blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i];
+        lds[i]        = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
+    }
+    for (int i = tid; i < 256; i += blockDim.x) {
+        const int n = s.meta[0];
+        pal[i]      = i < n ? ((uint32_t)i | ((uint32_t)s.palette[i * 3] << 8) |
+                          ((uint32_t)s.palette[i * 3 + 1] << 16) | ((uint32_t)s.palette[i * 3 + 2] << 24))
+                       : 0u;
+    }
+    for (int i = tid; i < n_pad * W; i += blockDim.x)
+        padflag[i] = PaddedPixel(frame, g, i % W, g.h + i / W) == g.pad[1] ? 1 : 0;
+    for (int i = tid; i < (n_waves + 1) * brow; i += blockDim.x) boundary[i] = 0u;
+    if (tid < n_waves) progress[tid] = 0;
+    const bool dither = s.meta[1] != 0;
+    const uint32_t pad0 = g.pad[0], pad_xor = g.pad[0] ^ g.pad[1];
+    __syncthreads();
+
+    // sign-extends the term bytes of a boundary word into this half's 16-bit pair
+    auto unpack_term = [&](uint32_t q) -> uint32_t {
+        return AsBits(AsPair(__builtin_amdgcn_perm(q, q, sel_term)) >> 8);
+    };
+
+    const int rows_per_round = n_waves * kPairRows;
+    const int steps          = W + 2 * (kPairRows - 1);
+    for (int round = 0; round * rows_per_round + wave * kPairRows < H; ++round) {
+        const int row      = round * rows_per_round + wave * kPairRows + rl;
+        const bool has_row = row < H;
+        const bool is_pad       = row >= g.h;
+        const uint8_t *src_row  = frame + (size_t)min(row, g.h - 1) * g.stride;
+        const uint8_t *pad_row  = padflag + (size_t)(is_pad && has_row ? row - g.h : 0) * W;
+        uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
+        const bool diffuses     = dither && row < H - 1;
+        const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
+        const int producer_round = wave == 0 ? round - 1 : round;
+        const bool follows       = producer_round >= 0;
+        const uint32_t *b_in     = boundary + (size_t)(follows ? producer : n_waves) * brow;
+        uint8_t *b_out           = reinterpret_cast<uint8_t *>(boundary + (size_t)wave * brow) + (odd ? 2 : 0);
+        const int in_base        = producer_round * W;
+        const int out_base       = round * W;
+        int avail = follows ? 0 : W;  // columns of the row above known to be published
+
+        uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;  // 16-bit pairs, see the first form
+        uint32_t first_q3 = 0;
+        uint32_t packed_idx = 0;
+        uint32_t bl = 0, bc = 0, br = 0;        // terms from above for the wave's first row, this step
+        uint32_t n_bl = 0, n_bc = 0, n_br = 0;  // ... and, still packed, for the next step
+        // A poll is an LDS round trip in the middle of a step: when the producer is not far
+        // enough ahead, wait until it is kPollBatch columns further than needed, so that a wave
+        // that runs right behind its producer polls every kPollBatch steps, not every step.
+        constexpr int kPollBatch = 4;
+        auto wait_for = [&](int need) __attribute__((always_inline)) {
+            if (avail < need) {
+                const int target = min(W, need + kPollBatch - 1);
+                while (avail < target) {
+                    avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                &progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - in_base;
+                    if (avail < target) __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            asm volatile("" ::: "memory");
+        };
+        // the first row's terms for column c are complete once the producer has finished column
+        // c + 1; they are requested one step before they are unpacked
+        auto request = [&](int c) __attribute__((always_inline)) {
+            c = min(c, W - 1);
+            wait_for(min(W, c + 2));
+            const uint32_t *slot = b_in + (c + 1) * 3;
+            n_bl = slot[0];
+            n_bc = slot[1];
+            n_br = slot[2];
+        };
+        request(0);
+        bl = unpack_term(n_bl);
+        bc = unpack_term(n_bc);
+        br = unpack_term(n_br);
+        request(1);
+
+        const bool wave_has_pad = __any(is_pad && has_row);
+        // UNCONDITIONAL loads from clamped addresses: a load inside a branch makes the compiler
+        // lose count of what is in flight and wait for vmcnt(0) -- the prefetch issued one step
+        // earlier -- in every step, which bounds the step by a memory round trip
+        auto fetch_frame = [&](int t) -> uint32_t {
+            const int x = min(max(t - 2 * rl, 0), W - 1);
+            return *reinterpret_cast<const uint32_t *>(src_row + (size_t)x * 4);
+        };
+        auto fetch_pad = [&](int t) -> uint32_t {
+            if (!wave_has_pad) return 0u;  // wave-uniform
+            const int x = min(max(t - 2 * rl, 0), W - 1);
+            return (uint32_t)pad_row[x];  // which of the two pad colours: turned into the colour when consumed
+        };
+        // One step.  Everything is computed by every lane, in range or not (the loads are
+        // clamped, the tables indexed with clamped values): straight-line code the compiler can
+        // schedule across the two dependent LDS reads; only the stores are predicated, and a
+        // lane outside its row produces zero terms.
+        auto step = [&](int t, uint32_t px_frame, uint32_t px_pad) __attribute__((always_inline)) {
+            uint32_t px = px_frame;
+            if (wave_has_pad) px = is_pad ? pad0 ^ ((0u - px_pad) & pad_xor) : px_frame;  // wave-uniform
+            uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
+            const int x       = t - 2 * rl;
+            const bool active = has_row && (unsigned)x < (unsigned)W;
+            if (rl == 0) {
+                up_l = bl;
+                up_c = bc;
+                up_r = br;
+            }
+            PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_px));
+            v = ApplyPair(v, up_l);
+            v = ApplyPair(v, up_c);
+            v = ApplyPair(v, up_r);
+            const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
+            v = ApplyPair(v, wrap);  // (W > 2: the narrower frames, where the order differs, use the first form)
+            v = ApplyPair(v, own7);
+            const uint32_t c5   = AsBits(v >> 3);  // 5 bits per channel
+            const uint32_t part = ((c5 & 0xffffu) << cell_shift) | ((c5 >> 16) << 5);
+            const uint32_t cell = part | FromPairPartner(part);
+            const uint32_t i8   = lut8[cell];
+            // the first row's terms for the next step (requested a step ago), and the request for
+            // the step after it, while the table lookups are in flight
+            bl = unpack_term(n_bl);
+            bc = unpack_term(n_bc);
+            br = unpack_term(n_br);
+            request(t + 2);
+            const uint32_t e    = pal[i8];
+            const bool spread   = active && diffuses && x < W - 1;
+            const PairI16 zero  = {0, 0};
+            const PairI16 err   = spread ? v - AsPair(__builtin_amdgcn_perm(e, e, sel_pal)) : zero;
+            // trunc(e * n / 16) == (e * n + (e < 0 ? 15 : 0)) >> 4, two channels at a time
+            const PairI16 fifteen = {15, 15}, k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
+            const PairI16 sgn = (err >> 15) & fifteen;
+            const uint32_t m7 = AsBits((err * k7 + sgn) >> 4);
+            const uint32_t m5 = AsBits((err * k5 + sgn) >> 4);
+            const uint32_t m3 = AsBits((err * k3 + sgn) >> 4);
+            const uint32_t m1 = AsBits((err + sgn) >> 4);
+            first_q3 = x == 0 ? m3 : first_q3;
+            // four indices per 32-bit store: the newest enters at the top byte
+            packed_idx = __builtin_amdgcn_alignbyte(e, packed_idx, 1);
+            if (active && ((x & 3) == 3 || x == W - 1) && !odd)
+                *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx >> (8 * (3 - (x & 3)));
+            if (active && rl == kPairRows - 1) {  // the row above the next wave's first row
+                // term word r | g << 8 | b << 16: the even lane writes its low half (r, g), the
+                // odd lane the high half (b, 0), each the low bytes of its two 16-bit values
+                uint8_t *o = b_out + x * 12;
+                *reinterpret_cast<uint16_t *>(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0200u);
+                *reinterpret_cast<uint16_t *>(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0200u);
+                *reinterpret_cast<uint16_t *>(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0200u);
+                asm volatile("" ::: "memory");
+                if (!odd)
+                    __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            own7 = m7;
+            c3   = c2;
+            c2   = c1;
+            c1   = m1;
+            b2   = b1;
+            b1   = m5;
+            a1   = m3;
+        };
+
+        uint32_t p0 = fetch_frame(0), p1 = fetch_frame(1), p2 = fetch_frame(2), p3 = fetch_frame(3),
+                 p4 = fetch_frame(4), p5 = fetch_frame(5), p6 = fetch_frame(6), p7 = fetch_frame(7);
+        uint32_t q0 = fetch_pad(0), q1 = fetch_pad(1), q2 = fetch_pad(2), q3 = fetch_pad(3),
+                 q4 = fetch_pad(4), q5 = fetch_pad(5), q6 = fetch_pad(6), q7 = fetch_pad(7);
+        // (no early exit inside the unrolled body: with one the compiler loses count of the
+        // loads in flight; the up to 7 extra steps find every lane out of range)
+#define TIMG_DITHER_STEP(k, P, Q)           \
+    step(t + k, P, Q);                      \
+    P = fetch_frame(t + k + kDitherAhead);  \
+    Q = fetch_pad(t + k + kDitherAhead);
+        for (int t = 0; t < steps; t += 8) {
+            TIMG_DITHER_STEP(0, p0, q0)
+            TIMG_DITHER_STEP(1, p1, q1)
+            TIMG_DITHER_STEP(2, p2, q2)
+            TIMG_DITHER_STEP(3, p3, q3)
+            TIMG_DITHER_STEP(4, p4, q4)
+            TIMG_DITHER_STEP(5, p5, q5)
+            TIMG_DITHER_STEP(6, p6, q6)
+            TIMG_DITHER_STEP(7, p7, q7)
+        }
+#undef TIMG_DITHER_STEP
+    }
+}
+
 // ---- K5: band encode, three kernels --------------------------------------------------------
 // libsixel encodes a 6-row band as "nodes" (a colour's run of columns, gaps of < 10
 // empty columns merged), sorts them by (start asc, end desc, colour asc) and packs them
@@ -1758,7 +1997,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     int dither_parts = 1;
     int dither_waves = std::max(1, std::min(kDitherMaxWaves, rows64));
     auto dither_bytes = [&](int waves) {
-        return (8192 + 256 + ((size_t)(g.h6 - h) * w + 3) / 4 + (size_t)(waves + 1) * 3 * w) * sizeof(uint32_t);
+        return (8192 + 256 + ((size_t)(g.h6 - h) * w + 3) / 4 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
     };
     // MEASURED (MI355X, 800x450): two workgroups per frame are NOT faster (0.96 vs 0.94 ms): a
     // wave issues in order, so a step costs its ~165 instructions plus two LDS round trips no
@@ -1768,6 +2007,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         dither_parts = 2;
         dither_waves = (rows64 + 1) / 2;
     }
+    // default: the two-lanes-per-row form, one wave per 32 rows (TIMG_HIP_DITHER_V1 selects the first form)
+    const bool dither_pairs = dither_parts == 1 && w > 2 && !getenv("TIMG_HIP_DITHER_V1");
+    if (dither_pairs) dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + kPairRows - 1) / kPairRows));
+    if (const char *cap = getenv("TIMG_HIP_DITHER_WAVES")) dither_waves = std::max(1, std::min(dither_waves, atoi(cap)));
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
     const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
@@ -1775,7 +2018,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
                                          : ((size_t)2 * 2048 + 2 * g.band_ne + g.band_ne / 2 + 16) * sizeof(uint32_t);
     const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel,
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(dither_pairs ? (const void *)DitherPairKernel : (const void *)DitherKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dither_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true>
@@ -1841,8 +2084,11 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
         if (dither_parts > 1)
             TIMG_HIP_TRY(ctx, hipMemsetAsync(gb.bridge, 0, (size_t)nfr * w * 2 * sizeof(unsigned long long), gs));
-        hipLaunchKernelGGL(DitherKernel, dim3(nfr * dither_parts), dim3(dither_waves * 64), dither_lds, gs, g,
-                           gb, dither_parts);
+        if (dither_pairs)
+            hipLaunchKernelGGL(DitherPairKernel, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+        else
+            hipLaunchKernelGGL(DitherKernel, dim3(nfr * dither_parts), dim3(dither_waves * 64), dither_lds, gs, g,
+                               gb, dither_parts);
         if (wide_bands)
             hipLaunchKernelGGL(BandNodesKernel<true>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         else

@@ -1020,9 +1020,11 @@ __device__ __forceinline__ uint32_t FromRowAbove(uint32_t v) {  // the same half
 __device__ __forceinline__ uint32_t FromPairPartner(uint32_t v) {  // quad_perm [1,0,3,2]
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);
 }
+typedef unsigned short PairU16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t AsBits(PairU16 v) { return __builtin_bit_cast(uint32_t, v); }
+// add one contribution and clamp: see "Number format" in the kernel
 __device__ __forceinline__ PairI16 ApplyPair(PairI16 v, uint32_t q) {
-    const PairI16 lo = {0, 0}, hi = {255, 255};
-    return __builtin_elementwise_min(__builtin_elementwise_max(v + AsPair(q), lo), hi);
+    return __builtin_elementwise_add_sat(v, AsPair(q));
 }
 
 constexpr int kPairRows = 32;  // rows per wave
@@ -1032,9 +1034,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
     const int n_pad    = H - g.h;
-    uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);
-    uint32_t *pal      = lds + 8192;
-    uint8_t *padflag   = reinterpret_cast<uint8_t *>(pal + 256);
+    uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);  // [cell ^ kCellBias] -> palette index
+    uint32_t *pal      = lds + 8192;                        // [2][256]: 16 * (colour - 128) as (r, g) / (b, 0)
+    uint8_t *padflag   = reinterpret_cast<uint8_t *>(pal + 512);
     const int pad_words = (n_pad * W + 3) / 4;
     // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it
     // reads): slot c + 1 holds, for the CONSUMER at column c, the three terms it needs as three
@@ -1042,29 +1044,35 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
     // writes into slots x + 2, x + 1 and x.  Slots nobody writes (1/16 left of column 0, 3/16
     // right of column W-1) keep the zero they are initialised with.
     const int brow     = (W + 2) * 3;
-    uint32_t *boundary = pal + 256 + pad_words;  // [n_waves + 1][W + 2][3]
+    uint32_t *boundary = pal + 512 + pad_words;  // [n_waves + 1][W + 2][3]
     __shared__ int progress[kDitherMaxWaves];
     const int f   = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int rl   = lane >> 1;        // row inside the wave
     const bool odd = (lane & 1) != 0;  // the (b, -) half
-    // v_perm_b32 selectors of this lane's half (0x0c = zero byte)
-    const uint32_t sel_px   = odd ? 0x0c0c0c02u : 0x0c010c00u;  // RGBA pixel     -> (r, g) / (b, 0)
-    const uint32_t sel_pal  = odd ? 0x0c0c0c03u : 0x0c020c01u;  // idx|r|g|b word -> (r, g) / (b, 0)
-    const uint32_t sel_term = odd ? 0x0c0c020cu : 0x010c000cu;  // term bytes -> HIGH byte of each half
+    // Number format.  A channel value c (0..255) is held as the signed 16-bit number
+    // (c - 128) << 8 | junk, an error term q as q << 8: then "add, clamp to 0..255" -- what
+    // libsixel does for every single contribution -- is ONE saturating 16-bit add (a sum
+    // above 255 hits 0x7fff, below 0 hits 0x8000, anything else leaves the junk byte alone).
+    // v_perm_b32 selector of this lane's half (0x0c = zero byte): bytes (r, g) / (b) of a pixel
+    // or of a term word -> HIGH byte of each 16-bit half
+    const uint32_t sel_hi   = odd ? 0x0c0c020cu : 0x010c000cu;
+    const uint32_t px_bias  = odd ? 0x00008000u : 0x80008000u;  // c -> c - 128 (the unused half stays 0)
     const int cell_shift    = odd ? 0 : 10;
+    constexpr uint32_t kCellBias = 0x4210u;  // (c - 128) >> 3 as an unsigned field is (c >> 3) ^ 16
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
-    for (int i = tid; i < 8192; i += blockDim.x) {
-        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i];
+    for (int i = tid; i < 8192; i += blockDim.x) {  // four cells per word; the bias leaves the low 2 bits alone
+        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i ^ (kCellBias >> 2)];
         lds[i]        = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
     }
     for (int i = tid; i < 256; i += blockDim.x) {
-        const int n = s.meta[0];
-        pal[i]      = i < n ? ((uint32_t)i | ((uint32_t)s.palette[i * 3] << 8) |
-                          ((uint32_t)s.palette[i * 3 + 1] << 16) | ((uint32_t)s.palette[i * 3 + 2] << 24))
-                       : 0u;
+        const bool in = i < s.meta[0];
+        const int pr = in ? s.palette[i * 3] : 128, pg = in ? s.palette[i * 3 + 1] : 128,
+                  pb = in ? s.palette[i * 3 + 2] : 128;
+        pal[i]       = ((uint32_t)((pr - 128) * 16) & 0xffffu) | ((uint32_t)((pg - 128) * 16) << 16);
+        pal[256 + i] = (uint32_t)((pb - 128) * 16) & 0xffffu;
     }
     for (int i = tid; i < n_pad * W; i += blockDim.x)
         padflag[i] = PaddedPixel(frame, g, i % W, g.h + i / W) == g.pad[1] ? 1 : 0;
@@ -1074,10 +1082,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
     const uint32_t pad0 = g.pad[0], pad_xor = g.pad[0] ^ g.pad[1];
     __syncthreads();
 
-    // sign-extends the term bytes of a boundary word into this half's 16-bit pair
-    auto unpack_term = [&](uint32_t q) -> uint32_t {
-        return AsBits(AsPair(__builtin_amdgcn_perm(q, q, sel_term)) >> 8);
-    };
+    const uint32_t *pal_half = pal + (odd ? 256 : 0);
+    // the term bytes of a boundary word as this half's pair of q << 8
+    auto unpack_term = [&](uint32_t q) -> uint32_t { return __builtin_amdgcn_perm(q, q, sel_hi); };
 
     const int rows_per_round = n_waves * kPairRows;
     const int steps          = W + 2 * (kPairRows - 1);
@@ -1162,14 +1169,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
                 up_c = bc;
                 up_r = br;
             }
-            PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_px));
+            PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_hi) ^ px_bias);
             v = ApplyPair(v, up_l);
             v = ApplyPair(v, up_c);
             v = ApplyPair(v, up_r);
             const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
             v = ApplyPair(v, wrap);  // (W > 2: the narrower frames, where the order differs, use the first form)
             v = ApplyPair(v, own7);
-            const uint32_t c5   = AsBits(v >> 3);  // 5 bits per channel
+            const uint32_t c5   = AsBits(__builtin_bit_cast(PairU16, v) >> 11);  // 5 bits per channel, biased
             const uint32_t part = ((c5 & 0xffffu) << cell_shift) | ((c5 >> 16) << 5);
             const uint32_t cell = part | FromPairPartner(part);
             const uint32_t i8   = lut8[cell];
@@ -1179,29 +1186,31 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
             bc = unpack_term(n_bc);
             br = unpack_term(n_br);
             request(t + 2);
-            const uint32_t e    = pal[i8];
+            const uint32_t e    = pal_half[i8];  // 16 * (palette colour - 128)
             const bool spread   = active && diffuses && x < W - 1;
             const PairI16 zero  = {0, 0};
-            const PairI16 err   = spread ? v - AsPair(__builtin_amdgcn_perm(e, e, sel_pal)) : zero;
-            // trunc(e * n / 16) == (e * n + (e < 0 ? 15 : 0)) >> 4, two channels at a time
-            const PairI16 fifteen = {15, 15}, k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
-            const PairI16 sgn = (err >> 15) & fifteen;
-            const uint32_t m7 = AsBits((err * k7 + sgn) >> 4);
-            const uint32_t m5 = AsBits((err * k5 + sgn) >> 4);
-            const uint32_t m3 = AsBits((err * k3 + sgn) >> 4);
-            const uint32_t m1 = AsBits((err + sgn) >> 4);
+            // 16 * err = 16 * (c - 128) - 16 * (p - 128); |16 * err * 7 + 240| fits 16 bits
+            const PairI16 c16   = AsPair(AsBits(v >> 4) & 0xfff0fff0u);
+            const PairI16 err   = spread ? c16 - AsPair(e) : zero;
+            // trunc(err * n / 16) << 8 == (16 * err * n + (err < 0 ? 240 : 0)) & 0xff00: two channels at a time
+            const PairI16 k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
+            const PairI16 sgn = AsPair(AsBits(err >> 15) & 0x00f000f0u);
+            const uint32_t m7 = AsBits(err * k7 + sgn) & 0xff00ff00u;
+            const uint32_t m5 = AsBits(err * k5 + sgn) & 0xff00ff00u;
+            const uint32_t m3 = AsBits(err * k3 + sgn) & 0xff00ff00u;
+            const uint32_t m1 = AsBits(err + sgn) & 0xff00ff00u;
             first_q3 = x == 0 ? m3 : first_q3;
             // four indices per 32-bit store: the newest enters at the top byte
-            packed_idx = __builtin_amdgcn_alignbyte(e, packed_idx, 1);
+            packed_idx = __builtin_amdgcn_alignbyte(i8, packed_idx, 1);
             if (active && ((x & 3) == 3 || x == W - 1) && !odd)
                 *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx >> (8 * (3 - (x & 3)));
             if (active && rl == kPairRows - 1) {  // the row above the next wave's first row
                 // term word r | g << 8 | b << 16: the even lane writes its low half (r, g), the
                 // odd lane the high half (b, 0), each the low bytes of its two 16-bit values
                 uint8_t *o = b_out + x * 12;
-                *reinterpret_cast<uint16_t *>(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0200u);
-                *reinterpret_cast<uint16_t *>(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0200u);
-                *reinterpret_cast<uint16_t *>(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0200u);
+                *reinterpret_cast<uint16_t *>(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0301u);
+                *reinterpret_cast<uint16_t *>(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0301u);
+                *reinterpret_cast<uint16_t *>(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0301u);
                 asm volatile("" ::: "memory");
                 if (!odd)
                     __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
@@ -1997,7 +2006,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     int dither_parts = 1;
     int dither_waves = std::max(1, std::min(kDitherMaxWaves, rows64));
     auto dither_bytes = [&](int waves) {
-        return (8192 + 256 + ((size_t)(g.h6 - h) * w + 3) / 4 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
+        return (8192 + 512 + ((size_t)(g.h6 - h) * w + 3) / 4 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
     };
     // MEASURED (MI355X, 800x450): two workgroups per frame are NOT faster (0.96 vs 0.94 ms): a
     // wave issues in order, so a step costs its ~165 instructions plus two LDS round trips no

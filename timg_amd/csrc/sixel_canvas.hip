@@ -81,7 +81,7 @@ struct SixelBatch {
     uint16_t *band_nfirst, *band_xs;
     uint2 *band_rec;
     int *band_cnt;
-    unsigned long long *bridge;  // [frames][w][2] granules between the two halves of a frame (K4)
+    uint32_t *pad_rows;          // [frames][5][w] the rows appended below the frame, as pixels (K4)
     int *error;                  // [1] set when a device-side wait gives up
     char *out;
     size_t out_cap;
@@ -705,311 +705,42 @@ __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b)
 // C integer division (err * num / 16, truncating toward zero) and clamped to
 // 0..255 before the next one arrives, so order and rounding of each term matter.
 // The pixel that PRODUCES an error computes its four terms once (7/16 right,
-// 3/16 below-left, 5/16 below, 1/16 below-right), each packed as three signed
-// bytes (r, g, b); consumers only add and clamp.
-struct ErrTerms {
-    uint32_t q7, q5, q3, q1;
-};
-
-__device__ __forceinline__ uint32_t PackBytes(int r, int g, int b) {
-    return ((uint32_t)r & 0xffu) | (((uint32_t)g & 0xffu) << 8) | (((uint32_t)b & 0xffu) << 16);
-}
-
-__device__ __forceinline__ ErrTerms MakeTerms(int er, int eg, int eb) {
-    // trunc(e * n / 16) == (e * n + (e < 0 ? 15 : 0)) >> 4   (arithmetic shift)
-    const int sr = (er >> 31) & 15, sg = (eg >> 31) & 15, sb = (eb >> 31) & 15;
-    ErrTerms t;
-    t.q7 = PackBytes((er * 7 + sr) >> 4, (eg * 7 + sg) >> 4, (eb * 7 + sb) >> 4);
-    t.q5 = PackBytes((er * 5 + sr) >> 4, (eg * 5 + sg) >> 4, (eb * 5 + sb) >> 4);
-    t.q3 = PackBytes((er * 3 + sr) >> 4, (eg * 3 + sg) >> 4, (eb * 3 + sb) >> 4);
-    t.q1 = PackBytes((er + sr) >> 4, (eg + sg) >> 4, (eb + sb) >> 4);
-    return t;
-}
-
-__device__ __forceinline__ int Clamp255(int c) { return c < 0 ? 0 : (c > 255 ? 255 : c); }
-
-__device__ __forceinline__ void ApplyTerm(int v[3], uint32_t q) {
-    v[0] = Clamp255(v[0] + (int)(int8_t)(q & 0xffu));
-    v[1] = Clamp255(v[1] + (int)(int8_t)((q >> 8) & 0xffu));
-    v[2] = Clamp255(v[2] + (int)(int8_t)((q >> 16) & 0xffu));
-}
-
-// One workgroup per frame, one wave per 64 consecutive rows, one lane per row.
-// Inside a wave row y runs two columns behind row y-1 (the minimum Floyd-
-// Steinberg allows: pixel (x,y) needs e(x+1,y-1)), the lane above hands its
-// terms down through DPP shuffles.  Between waves the last row of wave k
-// publishes its terms in LDS boundary rows plus a progress counter, and the
-// first row of wave k+1 follows it as closely as the data allows: the waves of a
-// frame form a pipeline, so a frame costs W + 2*(H-1) steps instead of
-// ceil(H/64) * (W + 2*63).  Frames taller than kDitherMaxWaves*64 rows go round
-// again (wave 0 then follows the last wave of the previous round).
-// LDS: the cell -> palette index table as bytes (32 KiB), the palette, and three
-// boundary rows per wave.
+// 3/16 below-left, 5/16 below, 1/16 below-right); consumers only add and clamp.
+//
+// One workgroup per frame, one wave per 32 consecutive rows.  Inside a wave row y
+// runs two columns behind row y-1 (the minimum Floyd-Steinberg allows: pixel (x,y)
+// needs e(x+1,y-1)) and receives the terms of the row above through DPP moves.
+// Between waves the last row of wave k publishes its terms in an LDS boundary row
+// plus a progress counter, and the first row of wave k+1 follows it as closely as
+// the data allows: the waves of a frame form a pipeline, so a frame costs about
+// W + 2*(H-1) steps.  Frames with more rows than the waves cover go round again
+// (wave 0 then follows the last wave of the previous round).
+//
+// A wave issues in order and the chain of steps is serial, so the kernel is bound by
+// the INSTRUCTIONS OF ONE STEP (measured: ~7 cycles per instruction for a wave alone on
+// its SIMD), not by bandwidth.  Hence:
+//  * a row is handled by a PAIR of lanes, the even lane carrying (r, g), the odd lane
+//    (b, -), as packed 16-bit values: every v_pk_*_i16 instruction serves two channels
+//    and the pair does in one instruction stream what a single lane did in three;
+//  * a number format in which "add, clamp to 0..255" is one saturating add (below);
+//  * straight-line steps: every lane computes, in range or not (loads clamped, tables
+//    indexed with clamped values), only stores are predicated -- the compiler can then
+//    schedule across the two dependent LDS lookups;
+//  * UNCONDITIONAL source-pixel prefetch 8 steps ahead: a load inside a branch makes the
+//    compiler lose count of what is in flight and wait for vmcnt(0) -- the prefetch issued
+//    a step earlier -- in every step, a memory round trip per step (that, not the
+//    arithmetic, bounded the first version of this kernel);
+//  * all hand-over traffic is LDS traffic of the form "data, then counter" from ONE wave,
+//    which the LDS executes in order: no fence (a workgroup fence would drain the wave's
+//    global prefetches), only relaxed atomics and compiler barriers.
 constexpr int kDitherMaxWaves = 16;
 constexpr int kDitherAhead    = 8;  // source pixels are requested this many steps early
 
-// wave_shr:1 -- every lane receives the value of the lane below it in index (lane 0 keeps
-// its own): the hand-down of error terms from row y-1 to row y costs one VALU move
+// wave_shr:1 -- every lane receives the value of the lane below it in index
 __device__ __forceinline__ uint32_t FromLaneAbove(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-//
-// With parts == 2 a frame is diffused by TWO workgroups on two CUs (upper and lower half
-// of the rows, single round): one wave per SIMD instead of two halves the time per step,
-// which is what bounds this kernel.  The lower half's first wave follows the upper half's
-// last wave through global memory: per column two self-validating 8-byte granules
-// {48 bits of terms, 16-bit tag}, written and read with relaxed agent-scope atomics (one
-// `sc1` store / load each: no fence, nothing to drain); the buffer is zeroed before every
-// launch.  The follower fetches up to 64 columns per poll into its LDS boundary row.
-constexpr unsigned long long kBridgeTag = 0x5a5aull;
-constexpr int kBridgeSpinLimit          = 1 << 20;
-
-__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b, int parts) {
-    extern __shared__ uint32_t lds[];
-    const int W = g.w, H = g.h6;
-    const int n_waves  = blockDim.x >> 6;
-    const int n_pad    = H - g.h;                            // rows SixelCanvas::Send appends
-    uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);   // 32768 palette indices
-    uint32_t *pal      = lds + 8192;                         // 256 x (idx | r<<8 | g<<16 | b<<24)
-    uint8_t *padflag   = reinterpret_cast<uint8_t *>(pal + 256);  // [n_pad][W]: which of the two pad colours
-    const int pad_words = (n_pad * W + 3) / 4;
-    uint32_t *boundary = pal + 256 + pad_words;              // [n_waves + 1][3][W]: q1, q5, q3 of a wave's last
-                                                             // row; the extra row receives the bridge
-    // columns published by each wave's last row.  All hand-over traffic is LDS traffic of
-    // the form "data, then counter" from ONE wave, which the LDS executes in order: no
-    // fence is needed (a workgroup fence would also drain the wave's global prefetches and
-    // stores, i.e. put a memory round trip into every step) -- only the compiler has to keep
-    // the order, hence the relaxed atomics and the empty asm barriers below.
-    __shared__ int progress[kDitherMaxWaves];
-    const int f               = blockIdx.x / parts;
-    const int part            = blockIdx.x % parts;
-    const int tid             = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const SixelFrameScratch s = FrameScratch(b, g, f);
-    const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
-    for (int i = tid; i < 8192; i += blockDim.x) {  // four cells per word
-        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i];
-        lds[i]        = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
-    }
-    for (int i = tid; i < 256; i += blockDim.x) {
-        const int n = s.meta[0];
-        pal[i]      = i < n ? ((uint32_t)i | ((uint32_t)s.palette[i * 3] << 8) |
-                          ((uint32_t)s.palette[i * 3 + 1] << 16) | ((uint32_t)s.palette[i * 3 + 2] << 24))
-                       : 0u;
-    }
-    for (int i = tid; i < n_pad * W; i += blockDim.x)
-        padflag[i] = PaddedPixel(frame, g, i % W, g.h + i / W) == g.pad[1] ? 1 : 0;
-    if (tid < n_waves) progress[tid] = 0;
-    const bool dither = s.meta[1] != 0;
-    __syncthreads();
-
-    const int rows_per_round = parts * n_waves * 64;  // (parts == 2: one round covers the frame)
-    const int part_row0      = part * n_waves * 64;
-    const int steps          = W + 2 * 63;
-    unsigned long long *bridge = b.bridge + (size_t)f * W * 2;
-    for (int round = 0; round * rows_per_round + part_row0 + wave * 64 < H; ++round) {
-        const int row      = round * rows_per_round + part_row0 + wave * 64 + lane;
-        const bool has_row = row < H;
-        // where this lane's pixels come from: a frame row in memory or a pad row in LDS
-        const bool is_pad       = row >= g.h;
-        const uint8_t *src_row  = frame + (size_t)min(row, g.h - 1) * g.stride;
-        const uint8_t *pad_row  = padflag + (size_t)(is_pad && has_row ? row - g.h : 0) * W;
-        uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
-        const bool diffuses     = dither && row < H - 1;
-        // whose last row lies directly above this wave's first row
-        const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
-        const int producer_round = wave == 0 ? round - 1 : round;
-        const bool from_bridge   = parts > 1 && part == 1 && wave == 0;  // follows the other workgroup
-        const bool to_bridge     = parts > 1 && part == 0 && wave == n_waves - 1;
-        const bool follows       = from_bridge || (producer_round >= 0 && !(parts > 1 && wave == 0));
-        uint32_t *b_in           = boundary + (size_t)(from_bridge ? n_waves : producer) * 3 * W;
-        uint32_t *b_out          = boundary + (size_t)wave * 3 * W;
-        const int in_base        = producer_round * W;   // progress value before the producer's round
-        const int out_base       = round * W;
-        int avail = 0;                                   // boundary entries known to be published
-
-        // terms of this lane's own recent errors:
-        //   own7 = 7/16 of e(x-1)  -> this row's next pixel
-        //   a1   = 3/16 of e(x-1), b2 = 5/16 of e(x-2), c3 = 1/16 of e(x-3) -> the row below
-        uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;
-        uint32_t first_q3 = 0;  // 3/16 of e(0,row) for the x == W-1 quirk
-        uint32_t packed_idx = 0;
-        // lane 0 of a following wave: boundary terms above x-1 (1/16), x (5/16), x+1 (3/16)
-        uint32_t bl = 0, bc = 0, br = 0;
-        // waits until `need` columns of the row above are available in b_in
-        int spins = 0;
-        auto wait_for = [&](int need) __attribute__((always_inline)) {
-            while (avail < need) {
-                if (!from_bridge) {
-                    avail = __hip_atomic_load(&progress[producer], __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP) - in_base;
-                    if (avail < need) __builtin_amdgcn_s_sleep(1);
-                } else {
-                    // fetch the next (up to) 64 columns' granules, keep the valid prefix
-                    const int col = avail + lane;
-                    unsigned long long g0 = 0, g1 = 0;
-                    if (col < W) {
-                        g0 = __hip_atomic_load(&bridge[2 * col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        g1 = __hip_atomic_load(&bridge[2 * col + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    const bool ok = col < W && (g0 >> 48) == kBridgeTag && (g1 >> 48) == kBridgeTag;
-                    const unsigned long long bad = ~__ballot(ok);
-                    const int c = bad ? __ffsll((long long)bad) - 1 : 64;
-                    if (lane < c) {
-                        b_in[col]         = (uint32_t)(g0 & 0xffffffull);
-                        b_in[W + col]     = (uint32_t)((g0 >> 24) & 0xffffffull);
-                        b_in[2 * W + col] = (uint32_t)(g1 & 0xffffffull);
-                    }
-                    avail += c;
-                    if (c == 0) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > kBridgeSpinLimit) {  // never on a healthy run: give up loudly
-                            if (lane == 0) atomicExch(b.error, 1);
-                            avail = W;
-                        }
-                    }
-                }
-            }
-            asm volatile("" ::: "memory");
-        };
-        if (follows) {
-            wait_for(min(2, W));
-            bc = b_in[W + 0];                       // q5 above x = 0
-            br = W > 1 ? b_in[2 * W + 1] : 0u;      // q3 above x + 1 = 1
-        }
-
-        // Source pixels come from the frame in memory or, for the rows SixelCanvas::Send
-        // appends, from the pad table in LDS.  The two are requested into SEPARATE registers
-        // and merged only when consumed: a merged register would make the LDS read wait for
-        // the global load (write-after-write), i.e. a memory round trip per step.
-        const bool wave_has_pad = __any(is_pad && has_row);
-        auto fetch_frame = [&](int t) -> uint32_t {
-            const int x = t - 2 * lane;
-            uint32_t v  = 0u;
-            if (has_row && !is_pad && x >= 0 && x < W)
-                v = *reinterpret_cast<const uint32_t *>(src_row + (size_t)x * 4);
-            return v;
-        };
-        auto fetch_pad = [&](int t) -> uint32_t {
-            const int x = t - 2 * lane;
-            uint32_t v  = 0u;
-            if (wave_has_pad && has_row && is_pad && x >= 0 && x < W) v = pad_row[x] ? g.pad[1] : g.pad[0];
-            return v;
-        };
-        auto step = [&](int t, uint32_t px_frame, uint32_t px_pad) __attribute__((always_inline)) {
-            const uint32_t px = is_pad ? px_pad : px_frame;
-            // the lane above is 2 columns ahead: its a1/b2/c3 belong to e(x+1), e(x), e(x-1)
-            uint32_t up_r = FromLaneAbove(a1), up_c = FromLaneAbove(b2), up_l = FromLaneAbove(c3);
-            const int x = t - 2 * lane;
-            if (lane == 0) {
-                up_l = bl;
-                up_c = bc;
-                up_r = br;
-            }
-            ErrTerms mine = {0, 0, 0, 0};
-            if (has_row && x >= 0 && x < W) {
-                int v[3] = {(int)(px & 0xffu), (int)((px >> 8) & 0xffu), (int)((px >> 16) & 0xffu)};
-                // arrival order of the contributions in raster order:
-                // (x-1,y-1) 1/16, (x,y-1) 5/16, (x+1,y-1) 3/16, [(0,y) 3/16], (x-1,y) 7/16
-                ApplyTerm(v, up_l);
-                ApplyTerm(v, up_c);
-                ApplyTerm(v, up_r);
-                // the last pixel of a row also receives 3/16 of the row's FIRST error (its
-                // "below-left" neighbour in libsixel's linear addressing); for W == 2 that is
-                // the same source pixel as the 7/16 term, which then arrives first
-                const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
-                if (W > 2) {
-                    ApplyTerm(v, wrap);
-                    ApplyTerm(v, own7);
-                } else {
-                    ApplyTerm(v, own7);
-                    ApplyTerm(v, wrap);
-                }
-                const uint32_t cell = ((uint32_t)(v[0] >> 3) << 10) | ((uint32_t)(v[1] >> 3) << 5) |
-                                      (uint32_t)(v[2] >> 3);
-                const uint32_t e = pal[lut8[cell]];
-                const bool spread = diffuses && x < W - 1;
-                const int er = spread ? v[0] - (int)((e >> 8) & 0xffu) : 0;
-                const int eg = spread ? v[1] - (int)((e >> 16) & 0xffu) : 0;
-                const int eb = spread ? v[2] - (int)(e >> 24) : 0;
-                mine         = MakeTerms(er, eg, eb);
-                first_q3     = x == 0 ? mine.q3 : first_q3;
-                // four indices per 32-bit store (rows of the index image are padded to 4)
-                packed_idx |= (e & 0xffu) << (8 * (x & 3));
-                if ((x & 3) == 3 || x == W - 1) {
-                    *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx;
-                    packed_idx = 0;
-                }
-                if (lane == 63) {  // the row above the next wave's first row
-                    if (to_bridge) {
-                        const unsigned long long g0 = (unsigned long long)(mine.q1 & 0xffffffu) |
-                                                      ((unsigned long long)(mine.q5 & 0xffffffu) << 24) |
-                                                      (kBridgeTag << 48);
-                        const unsigned long long g1 = (unsigned long long)(mine.q3 & 0xffffffu) | (kBridgeTag << 48);
-                        __hip_atomic_store(&bridge[2 * x], g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&bridge[2 * x + 1], g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        b_out[x]         = mine.q1;
-                        b_out[W + x]     = mine.q5;
-                        b_out[2 * W + x] = mine.q3;
-                        asm volatile("" ::: "memory");
-                        __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-            }
-            own7 = mine.q7;
-            c3   = c2;
-            c2   = c1;
-            c1   = mine.q1;
-            b2   = b1;
-            b1   = mine.q5;
-            a1   = mine.q3;
-            // lane 0's window over the boundary row moves one column to the right
-            if (follows && t + 1 < W) {  // wave-uniform: lane 0 is at x = t
-                const int nx = t + 3;    // the step after this one needs column t + 2
-                if (nx <= W) wait_for(nx);
-                // next step lane 0 is at x = t + 1: 1/16 of column t, 5/16 of t + 1, 3/16 of t + 2
-                bl = b_in[t];
-                bc = b_in[W + t + 1];
-                br = t + 2 < W ? b_in[2 * W + t + 2] : 0u;
-            }
-        };
-
-        static_assert(kDitherAhead == 8, "the pixel ring below is written out for 8 steps");
-        uint32_t p0 = fetch_frame(0), p1 = fetch_frame(1), p2 = fetch_frame(2), p3 = fetch_frame(3),
-                 p4 = fetch_frame(4), p5 = fetch_frame(5), p6 = fetch_frame(6), p7 = fetch_frame(7);
-        uint32_t q0 = fetch_pad(0), q1 = fetch_pad(1), q2 = fetch_pad(2), q3 = fetch_pad(3),
-                 q4 = fetch_pad(4), q5 = fetch_pad(5), q6 = fetch_pad(6), q7 = fetch_pad(7);
-#define TIMG_DITHER_STEP(k, P, Q)           \
-    if (t + k >= steps) break;              \
-    step(t + k, P, Q);                      \
-    P = fetch_frame(t + k + kDitherAhead);  \
-    Q = fetch_pad(t + k + kDitherAhead);
-        for (int t = 0; t < steps; t += 8) {
-            TIMG_DITHER_STEP(0, p0, q0)
-            TIMG_DITHER_STEP(1, p1, q1)
-            TIMG_DITHER_STEP(2, p2, q2)
-            TIMG_DITHER_STEP(3, p3, q3)
-            TIMG_DITHER_STEP(4, p4, q4)
-            TIMG_DITHER_STEP(5, p5, q5)
-            TIMG_DITHER_STEP(6, p6, q6)
-            TIMG_DITHER_STEP(7, p7, q7)
-        }
-#undef TIMG_DITHER_STEP
-    }
-}
-
-// ---- K4, second form: two lanes per row ----------------------------------------------------
-// A wave issues in order, and with one wave per SIMD the diffusion above is bound by the
-// instructions of one step, not by throughput.  Here a row is handled by a PAIR of lanes:
-// the even lane carries (r, g), the odd lane (b, -) as packed 16-bit values, so add / clamp /
-// the four error terms are v_pk_*_i16 instructions that serve two channels at once and the
-// two lanes together do in one instruction stream what a lane did in three.  A wave covers
-// 32 rows (row y still two columns behind row y-1), the hand-down from the row above is two
-// wave_shr:1 moves, boundary rows and progress counters between waves are those of the first
-// form (same byte layout: r | g << 8 | b << 16 per term).
 typedef short PairI16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ PairI16 AsPair(uint32_t u) { return __builtin_bit_cast(PairI16, u); }
 __device__ __forceinline__ uint32_t AsBits(PairI16 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -1027,28 +758,31 @@ __device__ __forceinline__ PairI16 ApplyPair(PairI16 v, uint32_t q) {
     return __builtin_elementwise_add_sat(v, AsPair(q));
 }
 
-constexpr int kPairRows = 32;  // rows per wave
+constexpr int kPairRows       = 32;  // rows per wave
+constexpr int kDitherSpinLimit = 1 << 22;
 
-__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGeom g, SixelBatch b) {
+// kNarrow: frames of 1 or 2 columns, where the row-wrap term and the 7/16 term come from
+// the same pixel and arrive in the other order
+template <bool kNarrow>
+__global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
     const int n_pad    = H - g.h;
     uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);  // [cell ^ kCellBias] -> palette index
     uint32_t *pal      = lds + 8192;                        // [2][256]: 16 * (colour - 128) as (r, g) / (b, 0)
-    uint8_t *padflag   = reinterpret_cast<uint8_t *>(pal + 512);
-    const int pad_words = (n_pad * W + 3) / 4;
     // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it
     // reads): slot c + 1 holds, for the CONSUMER at column c, the three terms it needs as three
     // consecutive words {1/16 of e(c-1), 5/16 of e(c), 3/16 of e(c+1)} -- the producer at column x
     // writes into slots x + 2, x + 1 and x.  Slots nobody writes (1/16 left of column 0, 3/16
     // right of column W-1) keep the zero they are initialised with.
     const int brow     = (W + 2) * 3;
-    uint32_t *boundary = pal + 512 + pad_words;  // [n_waves + 1][W + 2][3]
+    uint32_t *boundary = pal + 512;  // [n_waves + 1][W + 2][3]
     __shared__ int progress[kDitherMaxWaves];
     const int f   = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (in a scalar register: what depends on it branches for free)
     const int rl   = lane >> 1;        // row inside the wave
     const bool odd = (lane & 1) != 0;  // the (b, -) half
     // Number format.  A channel value c (0..255) is held as the signed 16-bit number
@@ -1074,12 +808,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
         pal[i]       = ((uint32_t)((pr - 128) * 16) & 0xffffu) | ((uint32_t)((pg - 128) * 16) << 16);
         pal[256 + i] = (uint32_t)((pb - 128) * 16) & 0xffffu;
     }
-    for (int i = tid; i < n_pad * W; i += blockDim.x)
-        padflag[i] = PaddedPixel(frame, g, i % W, g.h + i / W) == g.pad[1] ? 1 : 0;
+    // the rows SixelCanvas::Send appends below the frame, as pixels in scratch memory: the
+    // steps then fetch every row the same way (written and read by this workgroup only)
+    uint32_t *pad_rows = b.pad_rows + (size_t)f * 5 * W;
+    for (int i = tid; i < n_pad * W; i += blockDim.x) pad_rows[i] = PaddedPixel(frame, g, i % W, g.h + i / W);
     for (int i = tid; i < (n_waves + 1) * brow; i += blockDim.x) boundary[i] = 0u;
     if (tid < n_waves) progress[tid] = 0;
     const bool dither = s.meta[1] != 0;
-    const uint32_t pad0 = g.pad[0], pad_xor = g.pad[0] ^ g.pad[1];
     __syncthreads();
 
     const uint32_t *pal_half = pal + (odd ? 256 : 0);
@@ -1088,12 +823,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
 
     const int rows_per_round = n_waves * kPairRows;
     const int steps          = W + 2 * (kPairRows - 1);
+    bool gave_up             = false;
     for (int round = 0; round * rows_per_round + wave * kPairRows < H; ++round) {
         const int row      = round * rows_per_round + wave * kPairRows + rl;
         const bool has_row = row < H;
-        const bool is_pad       = row >= g.h;
-        const uint8_t *src_row  = frame + (size_t)min(row, g.h - 1) * g.stride;
-        const uint8_t *pad_row  = padflag + (size_t)(is_pad && has_row ? row - g.h : 0) * W;
+        const uint8_t *src_row  = row < g.h ? frame + (size_t)row * g.stride
+                                            : reinterpret_cast<const uint8_t *>(pad_rows + (size_t)(min(row, H - 1) - g.h) * W);
         uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
         const bool diffuses     = dither && row < H - 1;
         const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
@@ -1105,7 +840,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
         const int out_base       = round * W;
         int avail = follows ? 0 : W;  // columns of the row above known to be published
 
-        uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;  // 16-bit pairs, see the first form
+        // terms of this row's own recent errors (pairs of q << 8):
+        //   own7 = 7/16 of e(x-1)  -> this row's next pixel
+        //   a1   = 3/16 of e(x-1), b2 = 5/16 of e(x-2), c3 = 1/16 of e(x-3) -> the row below
+        uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;
         uint32_t first_q3 = 0;
         uint32_t packed_idx = 0;
         uint32_t bl = 0, bc = 0, br = 0;        // terms from above for the wave's first row, this step
@@ -1114,13 +852,20 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
         // enough ahead, wait until it is kPollBatch columns further than needed, so that a wave
         // that runs right behind its producer polls every kPollBatch steps, not every step.
         constexpr int kPollBatch = 4;
+        int spins = 0;
         auto wait_for = [&](int need) __attribute__((always_inline)) {
             if (avail < need) {
                 const int target = min(W, need + kPollBatch - 1);
                 while (avail < target) {
                     avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                 &progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - in_base;
-                    if (avail < target) __builtin_amdgcn_s_sleep(1);
+                    if (avail < target) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kDitherSpinLimit) {  // never on a healthy run: give up (reported below), do not hang
+                            gave_up = true;
+                            avail   = W;
+                        }
+                    }
                 }
             }
             asm volatile("" ::: "memory");
@@ -1141,26 +886,24 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
         br = unpack_term(n_br);
         request(1);
 
-        const bool wave_has_pad = __any(is_pad && has_row);
-        // UNCONDITIONAL loads from clamped addresses: a load inside a branch makes the compiler
-        // lose count of what is in flight and wait for vmcnt(0) -- the prefetch issued one step
-        // earlier -- in every step, which bounds the step by a memory round trip
-        auto fetch_frame = [&](int t) -> uint32_t {
-            const int x = min(max(t - 2 * rl, 0), W - 1);
-            return *reinterpret_cast<const uint32_t *>(src_row + (size_t)x * 4);
-        };
-        auto fetch_pad = [&](int t) -> uint32_t {
-            if (!wave_has_pad) return 0u;  // wave-uniform
-            const int x = min(max(t - 2 * rl, 0), W - 1);
-            return (uint32_t)pad_row[x];  // which of the two pad colours: turned into the colour when consumed
+        // Source pixels: unconditional, from clamped addresses, 8 steps ahead, as inline assembly
+        // with hand-placed waits.  Left to the compiler, the ring of 8 loads in flight loses its
+        // count at the loop header (and at any branch around a load) and the step waits for
+        // vmcnt(0): a memory round trip every step or every 8 steps, depending on the version.
+        // The loads return in order, so "at most 7 younger operations outstanding" means the
+        // oldest has arrived (the index stores in between only make the wait more conservative).
+        auto fetch = [&](int t) -> uint32_t {
+            const uint32_t x = (uint32_t)min(max(t - 2 * rl, 0), W - 1);
+            const uint8_t *p = src_row + (size_t)x * 4;
+            uint32_t v;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));
+            return v;
         };
         // One step.  Everything is computed by every lane, in range or not (the loads are
         // clamped, the tables indexed with clamped values): straight-line code the compiler can
         // schedule across the two dependent LDS reads; only the stores are predicated, and a
         // lane outside its row produces zero terms.
-        auto step = [&](int t, uint32_t px_frame, uint32_t px_pad) __attribute__((always_inline)) {
-            uint32_t px = px_frame;
-            if (wave_has_pad) px = is_pad ? pad0 ^ ((0u - px_pad) & pad_xor) : px_frame;  // wave-uniform
+        auto step = [&](int t, uint32_t px) __attribute__((always_inline)) {
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
             const int x       = t - 2 * rl;
             const bool active = has_row && (unsigned)x < (unsigned)W;
@@ -1174,8 +917,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
             v = ApplyPair(v, up_c);
             v = ApplyPair(v, up_r);
             const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
-            v = ApplyPair(v, wrap);  // (W > 2: the narrower frames, where the order differs, use the first form)
-            v = ApplyPair(v, own7);
+            // the last pixel of a row also receives 3/16 of the row's FIRST error (its "below-left"
+            // neighbour in libsixel's linear addressing)
+            if (!kNarrow) {
+                v = ApplyPair(v, wrap);
+                v = ApplyPair(v, own7);
+            } else {
+                v = ApplyPair(v, own7);
+                v = ApplyPair(v, wrap);
+            }
             const uint32_t c5   = AsBits(__builtin_bit_cast(PairU16, v) >> 11);  // 5 bits per channel, biased
             const uint32_t part = ((c5 & 0xffffu) << cell_shift) | ((c5 >> 16) << 5);
             const uint32_t cell = part | FromPairPartner(part);
@@ -1225,28 +975,35 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherPairKernel(SixelGe
             a1   = m3;
         };
 
-        uint32_t p0 = fetch_frame(0), p1 = fetch_frame(1), p2 = fetch_frame(2), p3 = fetch_frame(3),
-                 p4 = fetch_frame(4), p5 = fetch_frame(5), p6 = fetch_frame(6), p7 = fetch_frame(7);
-        uint32_t q0 = fetch_pad(0), q1 = fetch_pad(1), q2 = fetch_pad(2), q3 = fetch_pad(3),
-                 q4 = fetch_pad(4), q5 = fetch_pad(5), q6 = fetch_pad(6), q7 = fetch_pad(7);
+        asm volatile("" ::: "memory");
+        uint32_t p0 = fetch(0), p1 = fetch(1), p2 = fetch(2), p3 = fetch(3), p4 = fetch(4), p5 = fetch(5),
+                 p6 = fetch(6), p7 = fetch(7);
         // (no early exit inside the unrolled body: with one the compiler loses count of the
         // loads in flight; the up to 7 extra steps find every lane out of range)
-#define TIMG_DITHER_STEP(k, P, Q)           \
-    step(t + k, P, Q);                      \
-    P = fetch_frame(t + k + kDitherAhead);  \
-    Q = fetch_pad(t + k + kDitherAhead);
+#define TIMG_DITHER_STEP(k, P)                                    \
+    asm volatile("s_waitcnt vmcnt(7)" : "+v"(P) : : "memory");    \
+    step(t + k, P);                                               \
+    P = fetch(t + k + kDitherAhead);
         for (int t = 0; t < steps; t += 8) {
-            TIMG_DITHER_STEP(0, p0, q0)
-            TIMG_DITHER_STEP(1, p1, q1)
-            TIMG_DITHER_STEP(2, p2, q2)
-            TIMG_DITHER_STEP(3, p3, q3)
-            TIMG_DITHER_STEP(4, p4, q4)
-            TIMG_DITHER_STEP(5, p5, q5)
-            TIMG_DITHER_STEP(6, p6, q6)
-            TIMG_DITHER_STEP(7, p7, q7)
+            TIMG_DITHER_STEP(0, p0)
+            TIMG_DITHER_STEP(1, p1)
+            TIMG_DITHER_STEP(2, p2)
+            TIMG_DITHER_STEP(3, p3)
+            TIMG_DITHER_STEP(4, p4)
+            TIMG_DITHER_STEP(5, p5)
+            TIMG_DITHER_STEP(6, p6)
+            TIMG_DITHER_STEP(7, p7)
         }
+        // the 8 requests still in flight must land before their registers are used for anything else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                     :
+                     : "memory");
 #undef TIMG_DITHER_STEP
     }
+    // (outside the loops: a memory operation inside the poll loop would cost the compiler its
+    // count of the prefetches in flight)
+    if (gave_up && lane == 0) atomicExch(b.error, 1);
 }
 
 // ---- K5: band encode, three kernels --------------------------------------------------------
@@ -1971,7 +1728,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_bxs   = carve(n_band * g.band_ne * 2);
     const size_t o_brec  = carve(n_band * g.band_ne * sizeof(uint2));
     const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
-    const size_t o_brdg  = carve(nf * (size_t)w * 2 * sizeof(unsigned long long));
+    const size_t o_prow  = carve(nf * (size_t)w * 5 * sizeof(uint32_t));
     const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
     char *base = (char *)ctx->dev[5].ptr;
@@ -1994,31 +1751,19 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.band_xs     = (uint16_t *)(base + o_bxs);
     b.band_rec    = (uint2 *)(base + o_brec);
     b.band_cnt    = (int *)(base + o_bcnt);
-    b.bridge      = (unsigned long long *)(base + o_brdg);
+    b.pad_rows    = (uint32_t *)(base + o_prow);
     b.error       = (int *)(base + o_len + nf * sizeof(unsigned long long));
     b.out        = dout;
     b.out_cap    = out_cap;
     b.out_len    = (unsigned long long *)(base + o_len);
 
-    // one wave per 64 rows, as many as the boundary rows leave room for next to the tables;
-    // frames of 4+ waves that fit one round are diffused by two workgroups (see K4)
-    const int rows64 = (g.h6 + 63) / 64;
-    int dither_parts = 1;
-    int dither_waves = std::max(1, std::min(kDitherMaxWaves, rows64));
+    // one wave per 32 rows, as many as the boundary rows leave room for next to the tables.
+    // (MEASURED, MI355X 800x450: spreading a frame over two workgroups / CUs with a global-memory
+    // bridge between them was not faster.)
+    int dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + kPairRows - 1) / kPairRows));
     auto dither_bytes = [&](int waves) {
-        return (8192 + 512 + ((size_t)(g.h6 - h) * w + 3) / 4 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
+        return (8192 + 512 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
     };
-    // MEASURED (MI355X, 800x450): two workgroups per frame are NOT faster (0.96 vs 0.94 ms): a
-    // wave issues in order, so a step costs its ~165 instructions plus two LDS round trips no
-    // matter how many waves share the SIMD.  Kept behind TIMG_HIP_DITHER_TWO_WG for experiments.
-    if (rows64 >= 4 && rows64 <= 2 * kDitherMaxWaves && dither_bytes((rows64 + 1) / 2) <= 160 * 1024 &&
-        getenv("TIMG_HIP_DITHER_TWO_WG")) {
-        dither_parts = 2;
-        dither_waves = (rows64 + 1) / 2;
-    }
-    // default: the two-lanes-per-row form, one wave per 32 rows (TIMG_HIP_DITHER_V1 selects the first form)
-    const bool dither_pairs = dither_parts == 1 && w > 2 && !getenv("TIMG_HIP_DITHER_V1");
-    if (dither_pairs) dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + kPairRows - 1) / kPairRows));
     if (const char *cap = getenv("TIMG_HIP_DITHER_WAVES")) dither_waves = std::max(1, std::min(dither_waves, atoi(cap)));
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
@@ -2027,7 +1772,7 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
                                          : ((size_t)2 * 2048 + 2 * g.band_ne + g.band_ne / 2 + 16) * sizeof(uint32_t);
     const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(dither_pairs ? (const void *)DitherPairKernel : (const void *)DitherKernel,
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false> : (const void *)DitherKernel<true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dither_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true>
@@ -2084,20 +1829,17 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.band_xs     = b.band_xs + o * g.bands * g.band_ne;
         gb.band_rec    = b.band_rec + o * g.bands * g.band_ne;
         gb.band_cnt    = b.band_cnt + o * g.bands * 4;
-        gb.bridge      = b.bridge + o * w * 2;
+        gb.pad_rows    = b.pad_rows + o * w * 5;
         gb.out         = b.out + o * b.out_cap;
         gb.out_len     = b.out_len + o;
 
         hipLaunchKernelGGL(HistKernel, dim3(nfr), dim3(kHistThreads), kHistLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
-        if (dither_parts > 1)
-            TIMG_HIP_TRY(ctx, hipMemsetAsync(gb.bridge, 0, (size_t)nfr * w * 2 * sizeof(unsigned long long), gs));
-        if (dither_pairs)
-            hipLaunchKernelGGL(DitherPairKernel, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+        if (w > 2)
+            hipLaunchKernelGGL(DitherKernel<false>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
         else
-            hipLaunchKernelGGL(DitherKernel, dim3(nfr * dither_parts), dim3(dither_waves * 64), dither_lds, gs, g,
-                               gb, dither_parts);
+            hipLaunchKernelGGL(DitherKernel<true>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
         if (wide_bands)
             hipLaunchKernelGGL(BandNodesKernel<true>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         else

@@ -229,6 +229,21 @@ struct CutBox {
 // this drains them and keeps the compiler from moving or caching accesses across the point.
 #define TIMG_WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 
+// maximum over the wave, in every lane's hands as a scalar: four row_shr steps leave each
+// 16-lane row's maximum in its last lane, row_bcast:15 / :31 carry it on to lane 63
+__device__ __forceinline__ uint32_t WaveMaxU32(uint32_t v) {
+#define TIMG_MAX_STEP(ctrl, rows) \
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false))
+    TIMG_MAX_STEP(0x111, 0xf);  // row_shr:1
+    TIMG_MAX_STEP(0x112, 0xf);  // row_shr:2
+    TIMG_MAX_STEP(0x114, 0xf);  // row_shr:4
+    TIMG_MAX_STEP(0x118, 0xf);  // row_shr:8
+    TIMG_MAX_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    TIMG_MAX_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef TIMG_MAX_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Prepares the split of `box` by one wave: sorts its colours (stable, by the plane
 // with the largest luminosity-weighted spread) into the other table half and finds
 // the median.  scratch: kCutScratch words owned by this wave.
@@ -396,10 +411,8 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 #ifdef TIMG_CUT_TRACE
     const long long t_kernel = wall_clock64();
 #endif
-    __shared__ CutBox box_a[2 * kMaxColors];
-    CutBox *box_b = box_a + kMaxColors;
-    __shared__ uint32_t l_id[2][kMaxColors], l_sum[2][kMaxColors], l_col[2][kMaxColors];
-    __shared__ uint32_t s_n, s_total, s_nboxes, s_done, s_flip;
+    __shared__ CutBox box_a[kMaxColors];
+    __shared__ uint32_t s_n, s_total, s_nboxes, s_done;
     const int f    = blockIdx.x;
     const int tid  = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -474,59 +487,89 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         tab[0] = s.tab_a;
         tab[1] = s.tab_b;
     }
-    // Boxes live in a pool and never move; the sum-descending LIST holds, per position,
-    // the box id plus copies of what the bookkeeping scans: sum and colour count (bit 31 of
-    // the count = "split prepared").  Two copies of the list (ping-pong on every replace).
-    CutBox *pool = box_a;  // 2 * kMaxColors - 1 boxes at most: box_a and box_b are contiguous
-    (void)box_b;
-    if (tid == 0) {
-        pool[0]     = CutBox{0, n, s_total, 0, 0, 0, 0, 0};
-        l_id[0][0]  = 0;
-        l_sum[0][0] = s_total;
-        l_col[0][0] = n;
-        s_nboxes    = 1;
-        s_done      = 0;
-        s_flip      = 0;
+    // The box list.  libsixel keeps a vector sorted by pixel sum (descending, stable), replaces
+    // the split box by its low half and appends the high half, then sorts again.  In the sorted
+    // result the low half comes FIRST among boxes of equal sum (everything of its sum stood
+    // behind the parent) and the high half LAST (it was appended), and nothing else changes
+    // its relative order -- so the whole order is that of the key (sum, tie) with tie = -step
+    // for the low half and +step for the high half of the step-th split.  Boxes therefore never
+    // move: the low half takes the parent's slot, the high half the next free one, "the first
+    // box of the list with >= 2 colours" is a maximum over keys, and the list positions are
+    // only needed once, at the end, for the palette order.  Wave 0 holds keys and colour
+    // counts of all <= 256 slots in registers (slot = q * 64 + lane) for the whole kernel.
+    constexpr uint32_t kReady = 0x80000000u;  // in the colour count: split prepared (or being prepared)
+    constexpr uint32_t kNone  = 0xffffffffu;
+    __shared__ uint32_t s_pick[kCutWaves];
+    __shared__ uint32_t s_key[kMaxColors], s_rank[kMaxColors];
+    CutBox *pool = box_a;
+    auto order_key = [](uint32_t sum, uint32_t tie /* 256 -+ step */) { return (sum << 9) | (511u - tie); };
+    uint32_t K[4] = {0, 0, 0, 0}, C[4] = {0, 0, 0, 0};
+    if (wave == 0 && lane == 0) {
+        K[0] = order_key(s_total, 256);
+        C[0] = n;
     }
+    // this lane's best slot among those that satisfy `want`: (key << 2 | q, colour word)
+    auto lane_best = [&](auto want, uint32_t *best_c) {
+        uint32_t best = 0;
+        *best_c       = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t kk = want(C[q]) ? (K[q] << 2) | (uint32_t)q : 0u;
+            if (kk > best) {
+                best    = kk;
+                *best_c = C[q];
+            }
+        }
+        return best;
+    };
+    // wave 0: choose the boxes the next round prepares -- the first kCutWaves of the list that
+    // can be split and have not been prepared
+    auto pick = [&]() {
+        for (int w = 0; w < kCutWaves; ++w) {
+            uint32_t c;
+            const uint32_t best = lane_best([](uint32_t cc) { return cc - 2u < kReady - 2u; }, &c);
+            const uint32_t m    = WaveMaxU32(best);
+            uint32_t slot       = kNone;
+            if (m != 0) {
+                const int l = __ffsll((long long)__ballot(best == m)) - 1;
+                slot        = (m & 3u) * 64 + (uint32_t)l;
+                if (lane == l) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((m & 3u) == (uint32_t)q) C[q] |= kReady;
+                }
+            }
+            if (lane == 0) s_pick[w] = slot;
+        }
+    };
+    if (tid == 0) {
+        pool[0]  = CutBox{0, n, s_total, 0, 0, 0, 0, 0};
+        s_nboxes = 1;
+        s_done   = 0;
+    }
+    if (wave == 0) pick();
+    __threadfence_block();
     __syncthreads();
 
-    constexpr uint32_t kReady = 0x80000000u;
 #ifdef TIMG_CUT_TRACE
     long long t_mark = wall_clock64(), t_split = 0, t_replay = 0;
     int n_rounds = 0;
     if (tid == 0 && f == 0) printf("cut: n=%u setup %lld ticks\n", n, wall_clock64() - t_kernel);
 #endif
     for (;;) {
-        const uint32_t flip   = s_flip;
-        const uint32_t nboxes = s_nboxes;
 #ifdef TIMG_CUT_TRACE
         t_mark = wall_clock64();
 #endif
-        // ---- speculative splits: wave w prepares the w-th unprepared splittable box
+        // ---- speculative splits: wave w prepares the w-th picked box
         {
-            uint32_t mine = 0xffffffffu, seen = 0;
-            for (uint32_t i0 = 0; i0 < nboxes && mine == 0xffffffffu; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                const uint32_t c = i < nboxes ? l_col[flip][i] : 0u;
-                const bool cand  = c >= 2 && !(c & kReady);
-                const unsigned long long m = __ballot(cand);
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                if (seen + cnt > (uint32_t)wave) {  // the (wave - seen)-th set bit of m
-                    unsigned long long mm = m;
-                    for (uint32_t k = seen; k < (uint32_t)wave; ++k) mm &= mm - 1;
-                    mine = i0 + (uint32_t)__ffsll((long long)mm) - 1;
-                }
-                seen += cnt;
-            }
-            if (mine != 0xffffffffu) {
-                const uint32_t id = l_id[flip][mine];
-                const CutBox box  = pool[id];
+            const uint32_t slot = s_pick[wave];
+            if (slot != kNone) {
+                const CutBox box = pool[slot];
                 uint32_t median, lowersum;
                 SplitBox(box, tab, scratch, lane, &median, &lowersum);
                 if (lane == 0) {
-                    pool[id].median   = median;
-                    pool[id].lowersum = lowersum;
-                    l_col[flip][mine] = box.colors | kReady;
+                    pool[slot].median   = median;
+                    pool[slot].lowersum = lowersum;
                 }
             }
         }
@@ -540,98 +583,63 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             ++n_rounds;
         }
 #endif
-        // ---- replay of the serial bookkeeping (wave 0)
+        // ---- replay of the serial bookkeeping (wave 0), for as long as the box libsixel would
+        // take next has been prepared
         if (wave == 0) {
-            uint32_t nb = nboxes, cur = flip, done = 0;
+            uint32_t nb = s_nboxes, done = 0;
             while (nb < (uint32_t)kMaxColors) {
-                // this lane's four list positions
-                uint32_t sm[4], cl[4], id[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = q * 64 + lane;
-                    const bool in    = i < nb;
-                    sm[q] = in ? l_sum[cur][i] : 0u;
-                    cl[q] = in ? l_col[cur][i] : 0u;
-                    id[q] = in ? l_id[cur][i] : 0u;
-                }
-                // first box (in sum-descending order) that still holds >= 2 colours; whether its
-                // split is prepared and which box it is come out of the same registers
-                uint32_t bi = 0xffffffffu, bi_id = 0;
-                bool bi_ready = false;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned long long m = __ballot((cl[q] & ~kReady) >= 2);
-                    if (m && bi == 0xffffffffu) {
-                        const int l = __ffsll((long long)m) - 1;
-                        bi          = q * 64 + (uint32_t)l;
-                        bi_ready    = ((uint32_t)__builtin_amdgcn_readlane((int)cl[q], l) & kReady) != 0;
-                        bi_id       = (uint32_t)__builtin_amdgcn_readlane((int)id[q], l);
-                    }
-                }
-                if (bi == 0xffffffffu) {
+                uint32_t c;
+                const uint32_t best = lane_best([](uint32_t cc) { return (cc & ~kReady) >= 2u; }, &c);
+                const uint32_t m    = WaveMaxU32(best);
+                if (m == 0) {  // no box with two colours left
                     done = 1;
                     break;
                 }
-                if (!bi_ready) break;  // its split has not been prepared yet: next round
-                const CutBox box      = pool[bi_id];
+                const int l = __ffsll((long long)__ballot(best == m)) - 1;
+                if (!((uint32_t)__builtin_amdgcn_readlane((int)c, l) & kReady)) break;  // not prepared: next round
+                const uint32_t qq = m & 3u, slot = qq * 64 + (uint32_t)l;
+                const CutBox box      = pool[slot];
                 const uint32_t median = box.median, lowersum = box.lowersum;
-                // replace the box by its halves and restore the stable sum-descending order:
-                // the low half keeps the parent's place in the pre-sort sequence, the high
-                // half is appended (libsixel qsorts the whole vector; pinned as stable).
                 const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 0};
                 const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u,
                                 0, 0, 0, 0};
-                const uint32_t lo_id = 2 * nb - 1, hi_id = 2 * nb;  // pool grows by two per split
-                uint32_t cnt_gt_lo = 0, cnt_ge_hi = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = q * 64 + lane;
-                    const bool other = i < nb && i != bi;
-                    cnt_gt_lo += (uint32_t)__popcll(__ballot(other && sm[q] > lo.sum));
-                    cnt_ge_hi += (uint32_t)__popcll(__ballot(other && sm[q] >= hi.sum));
+                if (lane == 0) {
+                    pool[slot] = lo;
+                    pool[nb]   = hi;
                 }
-                const uint32_t nxt = cur ^ 1u;
+                const uint32_t k_lo = order_key(lo.sum, 256 - nb), k_hi = order_key(hi.sum, 256 + nb);
+                const uint32_t hq = nb >> 6;
+                const int hl      = (int)(nb & 63u);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = q * 64 + lane;
-                    if (i < nb && i != bi) {
-                        const uint32_t pos = (i < bi ? i : i - 1) + (sm[q] > lo.sum ? 0u : 1u) +
-                                             (sm[q] >= hi.sum ? 0u : 1u);
-                        l_sum[nxt][pos] = sm[q];
-                        l_col[nxt][pos] = cl[q];
-                        l_id[nxt][pos]  = id[q];
+                    if (lane == l && qq == (uint32_t)q) {
+                        K[q] = k_lo;
+                        C[q] = lo.colors;
+                    }
+                    if (lane == hl && hq == (uint32_t)q) {
+                        K[q] = k_hi;
+                        C[q] = hi.colors;
                     }
                 }
-                if (lane == 0) {
-                    const uint32_t plo = cnt_gt_lo + (lo.sum < hi.sum ? 1u : 0u);
-                    const uint32_t phi = cnt_ge_hi + (lo.sum >= hi.sum ? 1u : 0u);
-                    pool[lo_id]     = lo;
-                    pool[hi_id]     = hi;
-                    l_sum[nxt][plo] = lo.sum;
-                    l_col[nxt][plo] = lo.colors;
-                    l_id[nxt][plo]  = lo_id;
-                    l_sum[nxt][phi] = hi.sum;
-                    l_col[nxt][phi] = hi.colors;
-                    l_id[nxt][phi]  = hi_id;
-                }
                 ++nb;
-                cur = nxt;
-                TIMG_WAVE_SYNC();
             }
             if (nb >= (uint32_t)kMaxColors) done = 1;
+            if (!done) pick();
             if (lane == 0) {
                 s_nboxes = nb;
-                s_flip   = cur;
                 s_done   = done;
             }
         }
         __threadfence_block();
         __syncthreads();
 #ifdef TIMG_CUT_TRACE
-        t_replay += wall_clock64() - t_mark;
-        if (tid == 0 && f == 0 && n_rounds <= 6)
-            printf("cut: round %d nboxes->%u split %lld replay-so-far %lld (100MHz ticks)\n", n_rounds, s_nboxes,
-                   t_split, t_replay);
+        {
+            const long long d_replay = wall_clock64() - t_mark;
+            t_replay += d_replay;
+            if (tid == 0 && f == 0)
+                printf("cut: round %d nboxes ->%u split-so-far %lld this-replay %lld (100MHz ticks)\n", n_rounds,
+                       s_nboxes, t_split, d_replay);
+        }
 #endif
         if (s_done) break;
     }
@@ -640,9 +648,27 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         printf("cut: rounds %d split %lld replay %lld ticks(100MHz)\n", n_rounds, t_split, t_replay);
 #endif
     const uint32_t nboxes = s_nboxes;
+    // list position of every box: the number of boxes with a larger key
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_key[q * 64 + lane] = K[q];
+    }
+    if (tid < kMaxColors) s_rank[tid] = 0;
+    __syncthreads();
+    {
+        const uint32_t box = tid & (kMaxColors - 1), part = tid / kMaxColors, parts = blockDim.x / kMaxColors;
+        if (box < nboxes) {
+            const uint32_t mine = s_key[box];
+            uint32_t r = 0;
+            for (uint32_t j = part; j < nboxes; j += parts) r += s_key[j] > mine ? 1u : 0u;
+            atomicAdd(&s_rank[box], r);
+        }
+    }
+    __syncthreads();
     // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
     for (uint32_t bi = tid; bi < nboxes; bi += blockDim.x) {
-        const CutBox box    = pool[l_id[s_flip][bi]];
+        const CutBox box    = pool[bi];
+        const uint32_t at   = s_rank[bi];
         const uint32_t *src = tab[box.buf] + box.ind;
         uint32_t sum[3]     = {0, 0, 0};
         for (uint32_t i = 0; i < box.colors; ++i) {
@@ -651,9 +677,9 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             sum[1] += ((e >> 5) & 0x1f) << 3;
             sum[2] += (e & 0x1f) << 3;
         }
-        s.palette[bi * 3 + 0] = (uint8_t)(sum[0] / box.colors);
-        s.palette[bi * 3 + 1] = (uint8_t)(sum[1] / box.colors);
-        s.palette[bi * 3 + 2] = (uint8_t)(sum[2] / box.colors);
+        s.palette[at * 3 + 0] = (uint8_t)(sum[0] / box.colors);
+        s.palette[at * 3 + 1] = (uint8_t)(sum[1] / box.colors);
+        s.palette[at * 3 + 2] = (uint8_t)(sum[2] / box.colors);
     }
     if (tid == 0) {
         s.meta[0] = (int)nboxes;

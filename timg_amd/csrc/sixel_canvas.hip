@@ -1172,6 +1172,12 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     uint32_t *aux      = lds;
     uint32_t *ent_a, *ent_b;
     uint16_t *nfirst_u;
+    // narrow frames, first phase: presence bitmap [256 colours][nws words], 16-bit word prefixes
+    // of the same shape, per-colour bases -- in the space the node phase reuses (aux, ent_b, nfirst_u)
+    const int nws       = ((g.w + 31) >> 5) | 1;  // odd row stride: a lane per colour walks its row conflict-free
+    uint32_t *bitmap    = lds;
+    uint16_t *wprefix   = reinterpret_cast<uint16_t *>(lds + 256 * nws);
+    uint32_t *cbase     = lds + 256 * nws + 128 * nws;
     {
         const size_t fslot = ((size_t)blockIdx.y * g.bands + blockIdx.x) * NE;
         if (kWide) {
@@ -1179,9 +1185,9 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             ent_b    = b.band_pi + fslot;
             nfirst_u = reinterpret_cast<uint16_t *>(b.band_rec + fslot);
         } else {
-            ent_a    = lds + 2 * kBucket;  // sorted entries end up here
-            ent_b    = ent_a + NE;         // radix partner, then the unsorted node keys
+            ent_b    = lds + 2 * kBucket;                         // the unsorted node keys
             nfirst_u = reinterpret_cast<uint16_t *>(ent_b + NE);  // first entry of node k
+            ent_a    = lds + max(384 * nws + 256, 2 * kBucket + NE + NE / 2);  // sorted entries
         }
     }
     __shared__ uint32_t s_tmp[5];
@@ -1223,48 +1229,86 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             }
         }
     };
-    uint32_t mine = 0;
-    for_columns([&](int n) { mine += (uint32_t)n; });
-    uint32_t n_ent_u;
-    uint32_t at = BlockExclusiveScan(mine, s_tmp, &n_ent_u);
-    const int n_ent = (int)n_ent_u;
-    for_columns([&](int n) {
-        for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
-        at += (uint32_t)n;
-    });
-    if (kWide) __threadfence_block();
-    __syncthreads();
+    int n_ent;
+    if constexpr (!kWide) {
+        // ---- entries sorted by (colour, column) in one pass.  The sort is stable by construction:
+        // the rank of (colour c, column x) among c's entries is the number of c's columns below
+        // x -- a popcount over c's row of a presence bitmap plus a per-word prefix.  No
+        // per-lane chains of dependent LDS updates (which is what a counting sort over lane
+        // chunks is), just atomics, one row scan per colour and one placement per entry.
+        for (int i = tid; i < 256 * nws; i += 256) bitmap[i] = 0;  // (while the index loads are in flight)
+        __syncthreads();
+        for_columns([&](int n) {
+            for (int j = 0; j < n; ++j) {
+                const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
+                atomicOr(&bitmap[c * nws + (x >> 5)], 1u << (x & 31u));
+            }
+        });
+        __syncthreads();
+        uint32_t total = 0;
+        for (int w = 0; w < nws; ++w) {  // lane = colour
+            wprefix[tid * nws + w] = (uint16_t)total;
+            total += (uint32_t)__popc(bitmap[tid * nws + w]);
+        }
+        uint32_t n_ent_u;
+        cbase[tid] = BlockExclusiveScan(total, s_tmp, &n_ent_u);
+        n_ent      = (int)n_ent_u;
+        __syncthreads();
+        for_columns([&](int n) {
+            for (int j = 0; j < n; ++j) {
+                const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
+                const uint32_t at = c * nws + (x >> 5);
+                ent_a[cbase[c] + wprefix[at] + (uint32_t)__popc(bitmap[at] & ((1u << (x & 31u)) - 1u))] = e6[j];
+            }
+        });
+        __syncthreads();
+    } else {
+        uint32_t mine = 0;
+        for_columns([&](int n) { mine += (uint32_t)n; });
+        uint32_t n_ent_u;
+        uint32_t at = BlockExclusiveScan(mine, s_tmp, &n_ent_u);
+        n_ent = (int)n_ent_u;
+        for_columns([&](int n) {
+            for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
+            at += (uint32_t)n;
+        });
+        if (kWide) __threadfence_block();
+        __syncthreads();
 
-    // ---- stable LSD radix sort by colour: two 4-bit passes, a contiguous chunk per lane
+        // ---- stable LSD radix sort by colour: two 4-bit passes, a contiguous chunk per lane
+        const int per_e = (n_ent + 255) / 256;
+        const int e0 = min(n_ent, tid * per_e), e1 = min(n_ent, e0 + per_e);
+        for (int pass = 0; pass < 2; ++pass) {
+            const int shift     = 22 + 4 * pass;
+            const uint32_t *src = pass ? ent_b : ent_a;
+            uint32_t *dst       = pass ? ent_a : ent_b;
+            for (int d = 0; d < 16; ++d) aux[d * 256 + tid] = 0;
+            for (int i = e0; i < e1; ++i) aux[((src[i] >> shift) & 15u) * 256 + tid] += 1;
+            if (kWide) __threadfence_block();
+            __syncthreads();
+            // exclusive scan over the 4096 counters in (digit, lane) order
+            uint32_t sum = 0;
+            for (int j = 0; j < 16; ++j) sum += aux[tid * 16 + j];
+            uint32_t run = BlockExclusiveScan(sum, s_tmp, nullptr);
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t t  = aux[tid * 16 + j];
+                aux[tid * 16 + j] = run;
+                run += t;
+            }
+            if (kWide) __threadfence_block();
+            __syncthreads();
+            for (int i = e0; i < e1; ++i) {
+                const uint32_t e = src[i];
+                const uint32_t d = (e >> shift) & 15u;
+                dst[aux[d * 256 + tid]++] = e;
+            }
+            if (kWide) __threadfence_block();
+            __syncthreads();
+        }
+
+    }
     const int per_e = (n_ent + 255) / 256;
     const int e0 = min(n_ent, tid * per_e), e1 = min(n_ent, e0 + per_e);
-    for (int pass = 0; pass < 2; ++pass) {
-        const int shift     = 22 + 4 * pass;
-        const uint32_t *src = pass ? ent_b : ent_a;
-        uint32_t *dst       = pass ? ent_a : ent_b;
-        for (int d = 0; d < 16; ++d) aux[d * 256 + tid] = 0;
-        for (int i = e0; i < e1; ++i) aux[((src[i] >> shift) & 15u) * 256 + tid] += 1;
-        if (kWide) __threadfence_block();
-        __syncthreads();
-        // exclusive scan over the 4096 counters in (digit, lane) order
-        uint32_t sum = 0;
-        for (int j = 0; j < 16; ++j) sum += aux[tid * 16 + j];
-        uint32_t run = BlockExclusiveScan(sum, s_tmp, nullptr);
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t t  = aux[tid * 16 + j];
-            aux[tid * 16 + j] = run;
-            run += t;
-        }
-        if (kWide) __threadfence_block();
-        __syncthreads();
-        for (int i = e0; i < e1; ++i) {
-            const uint32_t e = src[i];
-            const uint32_t d = (e >> shift) & 15u;
-            dst[aux[d * 256 + tid]++] = e;
-        }
-        if (kWide) __threadfence_block();
-        __syncthreads();
-    }
 
     // ---- nodes: a node starts at a new colour or after a gap of >= 10 empty columns
     auto breaks = [&](int i) {  // is there a node boundary between entries i-1 and i?
@@ -1794,8 +1838,11 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
     const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
-    const size_t nodes_lds  = wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
-                                         : ((size_t)2 * 2048 + 2 * g.band_ne + g.band_ne / 2 + 16) * sizeof(uint32_t);
+    const int nodes_nws     = ((w + 31) >> 5) | 1;
+    const size_t nodes_lds =
+        wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
+                   : (std::max((size_t)384 * nodes_nws + 256, (size_t)2 * 2048 + g.band_ne + g.band_ne / 2) +
+                      g.band_ne + 16) * sizeof(uint32_t);
     const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false> : (const void *)DitherKernel<true>,

@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include "context.h"
+#include "wave_ops.h"
 #include "pixel_math.h"
 
 namespace timg_amd {
@@ -229,21 +230,6 @@ struct CutBox {
 // this drains them and keeps the compiler from moving or caching accesses across the point.
 #define TIMG_WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 
-// maximum over the wave, in every lane's hands as a scalar: four row_shr steps leave each
-// 16-lane row's maximum in its last lane, row_bcast:15 / :31 carry it on to lane 63
-__device__ __forceinline__ uint32_t WaveMaxU32(uint32_t v) {
-#define TIMG_MAX_STEP(ctrl, rows) \
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false))
-    TIMG_MAX_STEP(0x111, 0xf);  // row_shr:1
-    TIMG_MAX_STEP(0x112, 0xf);  // row_shr:2
-    TIMG_MAX_STEP(0x114, 0xf);  // row_shr:4
-    TIMG_MAX_STEP(0x118, 0xf);  // row_shr:8
-    TIMG_MAX_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-    TIMG_MAX_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
-#undef TIMG_MAX_STEP
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // Prepares the split of `box` by one wave: sorts its colours (stable, by the plane
 // with the largest luminosity-weighted spread) into the other table half and finds
 // the median.  scratch: kCutScratch words owned by this wave.
@@ -259,25 +245,19 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
     const uint32_t half = box.sum / 2;
     uint32_t median, lowersum;
 
-    // per-plane extent of the box (5-bit keys)
-    uint32_t mn[3] = {31, 31, 31}, mx[3] = {0, 0, 0};
+    // per-plane extent of the box (5-bit keys): which key values occur, OR-ed over the wave
+    uint32_t seen[3] = {0, 0, 0};
     for (uint32_t i = lane; i < box.colors; i += 64) {
         const uint32_t e = src[i];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const uint32_t k = PlaneKey(e, p);
-            mn[p] = k < mn[p] ? k : mn[p];
-            mx[p] = k > mx[p] ? k : mx[p];
-        }
+        for (int p = 0; p < 3; ++p) seen[p] |= 1u << PlaneKey(e, p);
     }
+    uint32_t mn[3], mx[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t a = __shfl_xor(mn[p], d), c = __shfl_xor(mx[p], d);
-            mn[p] = a < mn[p] ? a : mn[p];
-            mx[p] = c > mx[p] ? c : mx[p];
-        }
+        const uint32_t m = WaveOr(seen[p]);  // (a box has at least one colour)
+        mn[p] = (uint32_t)__ffs((int)m) - 1u;
+        mx[p] = 31u - (uint32_t)__clz((int)m);
     }
     // SIXEL_LARGE_LUM: plane with the largest luminosity-weighted spread
     int plane = 0;
@@ -314,17 +294,12 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         }
         if (live) dst[lane] = e;
         const uint32_t c = live ? (e >> 15) : 0u;
-        uint32_t incl    = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        const uint32_t pre = incl - c;  // P(lane): pixels in front of entry `lane`
+        const uint32_t incl = WaveInclusiveAdd(c);
+        const uint32_t pre  = incl - c;  // P(lane): pixels in front of entry `lane`
         const unsigned long long hit = __ballot(live && lane >= 1 && pre >= half);
         median = hit ? (uint32_t)__ffsll((long long)hit) - 1 : box.colors - 1;
         if (median > box.colors - 1) median = box.colors - 1;
-        lowersum = __shfl(pre, (int)median);
+        lowersum = ReadLane(pre, (int)median);
     } else {
         // ---- large box: stable counting sort, one contiguous segment per lane -
         // (odd segment length keeps the lanes on different LDS banks)
@@ -346,17 +321,13 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
                 run += t;
             }
             TIMG_WAVE_SYNC();
-            const uint32_t lower = __shfl(run, key);        // total of lanes 0-31 for this key
+            const uint32_t other = __shfl_xor(run, 32);     // the other half's total for this key
+            const uint32_t lower = lane < 32 ? run : other;  // total of lanes 0-31 for this key
             if (lane >= 32)
                 for (int l = 32; l < 64; ++l) lane_cnt[l * 33 + key] = (uint16_t)(lane_cnt[l * 33 + key] + lower);
-            const uint32_t total = lower + __shfl(run, 32 + key);
+            const uint32_t total = run + other;
             if (lane < 32) s_key_total[lane] = total;
-            uint32_t incl = lane < 32 ? total : 0u;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if ((lane & 31) >= d) incl += o;
-            }
+            const uint32_t incl = WaveInclusiveAdd(lane < 32 ? total : 0u);
             if (lane < 32) s_key_base[lane] = incl - total;
         }
         TIMG_WAVE_SYNC();
@@ -372,13 +343,7 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         // median: the lane whose segment of the sorted box holds the crossing walks it
         uint32_t seg_sum = 0;
         for (uint32_t i = a; i < z; ++i) seg_sum += dst[i] >> 15;
-        uint32_t incl = seg_sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        uint32_t run  = incl - seg_sum;  // P(a)
+        uint32_t run  = WaveInclusiveAdd(seg_sum) - seg_sum;  // P(a)
         uint32_t cand = 0xffffffffu, cand_sum = 0;
         for (uint32_t i = a; i < z; ++i) {
             if (i >= 1 && run >= half) {
@@ -391,8 +356,8 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         const unsigned long long hit = __ballot(cand != 0xffffffffu);
         if (hit) {
             const int l = __ffsll((long long)hit) - 1;  // lowest lane = lowest index
-            median      = __shfl(cand, l);
-            lowersum    = __shfl(cand_sum, l);
+            median      = ReadLane(cand, l);
+            lowersum    = ReadLane(cand_sum, l);
         } else {
             median   = box.colors - 1;
             lowersum = 0;
@@ -435,8 +400,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             cnt += (uint32_t)__popcll(__ballot(e != 0));
             sum += e >> 15;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        sum = WaveSum(sum);
         if (lane == 0) {
             s_wave_cnt[wave] = cnt;
             s_wave_sum[wave] = sum;
@@ -1127,12 +1091,7 @@ __device__ int EmitNode(char *p, const uint32_t *entries, int first_entry, int c
 __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_tmp, uint32_t *total) {
     // 256 threads; s_tmp: 5 words of LDS.  Returns the exclusive prefix of v.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t incl  = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    const uint32_t incl = WaveInclusiveAdd(v);
     __syncthreads();  // s_tmp may still be read from a previous scan
     if (lane == 63) s_tmp[wv] = incl;
     __syncthreads();
@@ -1489,14 +1448,9 @@ __global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b,
     uint32_t carry = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        uint32_t incl = c[q];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        pb[q * 64 + lane] = carry + incl - c[q];
-        carry += __shfl(incl, 63);
+        const uint32_t incl = WaveInclusiveAdd(c[q]);
+        pb[q * 64 + lane]   = carry + incl - c[q];
+        carry += ReadLane(incl, 63);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's pi/xs stores and pb writes
     // one record per OUTPUT SLOT (passes back to back, nodes of a pass in packing order): the
@@ -1556,13 +1510,8 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         const int begin = min(tid * per, n_nodes), end = min(begin + per, n_nodes);
         uint32_t sum    = 0;
         for (int k = begin; k < end; ++k) sum += node_off[k];
-        uint32_t incl  = sum;
+        const uint32_t incl = WaveInclusiveAdd(sum);
         const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
         if (lane == 63) s_scan[wv] = incl;
         __syncthreads();
         uint32_t before = 0;

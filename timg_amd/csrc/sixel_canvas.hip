@@ -210,9 +210,9 @@ __global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBat
 constexpr int kCutWaves      = 8;
 constexpr int kCutLdsEntries = 12288;             // colour table kept in LDS up to this size
 // words of per-wave scratch: [64][33] 16-bit counters (a lane's segment of a box and every
-// exclusive prefix stay below 65536: a box has at most 32768 colours), 32 + 32 key totals /
-// bases, and 64 words for the register sort's permutation
-constexpr int kCutScratch    = 64 * 33 / 2 + 64 + 64;
+// exclusive prefix stay below 65536: a box has at most 32768 colours) plus 32 + 32 key totals /
+// bases; the medium path uses the first 256 words as its permutation buffer instead
+constexpr int kCutScratch    = 64 * 33 / 2 + 64;
 constexpr size_t kCutLdsBytes =
     ((size_t)2 * kCutLdsEntries + (size_t)kCutWaves * kCutScratch) * sizeof(uint32_t);
 
@@ -238,7 +238,7 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
     uint16_t *lane_cnt    = reinterpret_cast<uint16_t *>(scratch);  // [64][33]
     uint32_t *s_key_total = scratch + 64 * 33 / 2;                  // [32]
     uint32_t *s_key_base  = s_key_total + 32;                       // [32]
-    uint32_t *perm        = s_key_base + 32;                        // [64]
+    uint32_t *perm        = scratch;  // [256]: the medium path's permutation buffer (never together with lane_cnt)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t *src = tab[box.buf] + box.ind;
     uint32_t *dst       = tab[box.buf ^ 1u] + box.ind;
@@ -279,18 +279,15 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         const bool live = (uint32_t)lane < box.colors;
         uint32_t e      = live ? src[lane] : 0xffffffffu;
 #pragma unroll
-        for (int bit = 0; bit < 6; ++bit) {
-            // dead lanes carry key 32 so that they sort behind everything
-            const uint32_t key = e == 0xffffffffu ? 32u : PlaneKey(e, plane);
+        for (int bit = 0; bit < 5; ++bit) {
+            // dead lanes stand behind the live ones and carry the largest key: stable passes keep them there
+            const uint32_t key = e == 0xffffffffu ? 31u : PlaneKey(e, plane);
             const bool one     = (key >> bit) & 1u;
             const unsigned long long ones = __ballot(one);
             const int n_zero   = 64 - __popcll(ones);
             const int dest     = one ? n_zero + __popcll(ones & lt_mask) : __popcll(~ones & lt_mask);
-            // forward permutation through LDS
-            perm[dest] = e;
-            TIMG_WAVE_SYNC();
-            e = perm[lane];
-            TIMG_WAVE_SYNC();
+            // forward permutation through the LDS crossbar (ds_permute_b32: lane -> lane dest)
+            e = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)e);
         }
         if (live) dst[lane] = e;
         const uint32_t c = live ? (e >> 15) : 0u;
@@ -300,6 +297,73 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         median = hit ? (uint32_t)__ffsll((long long)hit) - 1 : box.colors - 1;
         if (median > box.colors - 1) median = box.colors - 1;
         lowersum = ReadLane(pre, (int)median);
+    } else if (box.colors <= 256) {
+        // ---- medium box: the same radix sort with four consecutive entries per lane (entry
+        // lane * 4 + r), the permutation through LDS.  A counting sort pays ~2 us of fixed cost
+        // (its per-key prefix over the lanes is a chain of dependent LDS updates) whatever the size.
+        uint32_t e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = (uint32_t)lane * 4 + r;
+            e[r]             = i < box.colors ? src[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int bit = 0; bit < 5; ++bit) {
+            bool one[4];
+            uint32_t nz = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t key = e[r] == 0xffffffffu ? 31u : PlaneKey(e[r], plane);
+                one[r]             = (key >> bit) & 1u;
+                nz += one[r] ? 0u : 1u;
+            }
+            const uint32_t incl  = WaveInclusiveAdd(nz);
+            const uint32_t zeros = ReadLane(incl, 63);
+            uint32_t zb          = incl - nz;  // zeros in front of this lane's first entry
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t i = (uint32_t)lane * 4 + r;
+                perm[one[r] ? zeros + (i - zb) : zb] = e[r];
+                zb += one[r] ? 0u : 1u;
+            }
+            TIMG_WAVE_SYNC();
+            const uint4 v = *reinterpret_cast<const uint4 *>(perm + lane * 4);
+            e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
+            TIMG_WAVE_SYNC();
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = (uint32_t)lane * 4 + r;
+            if (i < box.colors) dst[i] = e[r];
+            cnt += i < box.colors ? e[r] >> 15 : 0u;
+        }
+        uint32_t run  = WaveInclusiveAdd(cnt) - cnt;  // pixels in front of entry lane * 4
+        uint32_t cand = 0xffffffffu, cand_sum = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = (uint32_t)lane * 4 + r;
+            if (cand == 0xffffffffu && i >= 1 && i < box.colors && run >= half) {
+                cand     = i;
+                cand_sum = run;
+            }
+            run += i < box.colors ? e[r] >> 15 : 0u;
+        }
+        const unsigned long long hit = __ballot(cand != 0xffffffffu);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;  // lowest lane = lowest index
+            median      = ReadLane(cand, l);
+            lowersum    = ReadLane(cand_sum, l);
+        } else {
+            median   = box.colors - 1;
+            lowersum = 0;
+        }
+        if (median >= box.colors - 1) {  // (as in the large path: everything but the last colour below)
+            median = box.colors - 1;
+            __threadfence_block();
+            TIMG_WAVE_SYNC();
+            lowersum = box.sum - (dst[box.colors - 1] >> 15);
+        }
     } else {
         // ---- large box: stable counting sort, one contiguous segment per lane -
         // (odd segment length keeps the lanes on different LDS banks)
@@ -461,53 +525,41 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     // box of the list with >= 2 colours" is a maximum over keys, and the list positions are
     // only needed once, at the end, for the palette order.  Wave 0 holds keys and colour
     // counts of all <= 256 slots in registers (slot = q * 64 + lane) for the whole kernel.
-    constexpr uint32_t kReady = 0x80000000u;  // in the colour count: split prepared (or being prepared)
+    // Per slot one word S: 0 for a box that cannot be split (one colour), else
+    // order key << 3 | prepared << 2 | q -- the maximum over S is the box libsixel takes next,
+    // and carries along where it lives and whether its split is ready.
+    constexpr uint32_t kReady = 4u;
     constexpr uint32_t kNone  = 0xffffffffu;
     __shared__ uint32_t s_pick[kCutWaves];
     __shared__ uint32_t s_key[kMaxColors], s_rank[kMaxColors];
     CutBox *pool = box_a;
     auto order_key = [](uint32_t sum, uint32_t tie /* 256 -+ step */) { return (sum << 9) | (511u - tie); };
-    uint32_t K[4] = {0, 0, 0, 0}, C[4] = {0, 0, 0, 0};
-    if (wave == 0 && lane == 0) {
-        K[0] = order_key(s_total, 256);
-        C[0] = n;
-    }
-    // this lane's best slot among those that satisfy `want`: (key << 2 | q, colour word)
-    auto lane_best = [&](auto want, uint32_t *best_c) {
-        uint32_t best = 0;
-        *best_c       = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t kk = want(C[q]) ? (K[q] << 2) | (uint32_t)q : 0u;
-            if (kk > best) {
-                best    = kk;
-                *best_c = C[q];
-            }
-        }
-        return best;
+    auto slot_word = [&](uint32_t colors, uint32_t sum, uint32_t tie, uint32_t q) {
+        return colors >= 2u ? (order_key(sum, tie) << 3) | q : 0u;
     };
+    uint32_t S[4] = {0, 0, 0, 0};
+    if (wave == 0 && lane == 0) S[0] = slot_word(n, s_total, 256, 0);
     // wave 0: choose the boxes the next round prepares -- the first kCutWaves of the list that
-    // can be split and have not been prepared
+    // can be split and have not been prepared -- and mark them
     auto pick = [&]() {
         for (int w = 0; w < kCutWaves; ++w) {
-            uint32_t c;
-            const uint32_t best = lane_best([](uint32_t cc) { return cc - 2u < kReady - 2u; }, &c);
-            const uint32_t m    = WaveMaxU32(best);
-            uint32_t slot       = kNone;
+            uint32_t best = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) best = max(best, (S[q] & kReady) ? 0u : S[q]);
+            const uint32_t m = WaveMaxU32(best);
+            uint32_t slot    = kNone;
             if (m != 0) {
                 const int l = __ffsll((long long)__ballot(best == m)) - 1;
                 slot        = (m & 3u) * 64 + (uint32_t)l;
-                if (lane == l) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if ((m & 3u) == (uint32_t)q) C[q] |= kReady;
-                }
+                for (int q = 0; q < 4; ++q)
+                    if (lane == l && (m & 3u) == (uint32_t)q) S[q] |= kReady;
             }
             if (lane == 0) s_pick[w] = slot;
         }
     };
     if (tid == 0) {
-        pool[0]  = CutBox{0, n, s_total, 0, 0, 0, 0, 0};
+        pool[0]  = CutBox{0, n, s_total, 0, 0, 0, 0, 256};
         s_nboxes = 1;
         s_done   = 0;
     }
@@ -552,38 +604,33 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         if (wave == 0) {
             uint32_t nb = s_nboxes, done = 0;
             while (nb < (uint32_t)kMaxColors) {
-                uint32_t c;
-                const uint32_t best = lane_best([](uint32_t cc) { return (cc & ~kReady) >= 2u; }, &c);
+                const uint32_t best = max(max(S[0], S[1]), max(S[2], S[3]));
                 const uint32_t m    = WaveMaxU32(best);
                 if (m == 0) {  // no box with two colours left
                     done = 1;
                     break;
                 }
-                const int l = __ffsll((long long)__ballot(best == m)) - 1;
-                if (!((uint32_t)__builtin_amdgcn_readlane((int)c, l) & kReady)) break;  // not prepared: next round
+                if (!(m & kReady)) break;  // not prepared: next round
+                const int l       = __ffsll((long long)__ballot(best == m)) - 1;
                 const uint32_t qq = m & 3u, slot = qq * 64 + (uint32_t)l;
                 const CutBox box      = pool[slot];
                 const uint32_t median = box.median, lowersum = box.lowersum;
-                const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 0};
+                // the low half takes the parent's slot, the high half the next free one
+                const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 256 - nb};
                 const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u,
-                                0, 0, 0, 0};
+                                0, 0, 0, 256 + nb};
                 if (lane == 0) {
                     pool[slot] = lo;
                     pool[nb]   = hi;
                 }
-                const uint32_t k_lo = order_key(lo.sum, 256 - nb), k_hi = order_key(hi.sum, 256 + nb);
                 const uint32_t hq = nb >> 6;
                 const int hl      = (int)(nb & 63u);
+                const uint32_t s_lo = slot_word(lo.colors, lo.sum, lo.pad, qq);
+                const uint32_t s_hi = slot_word(hi.colors, hi.sum, hi.pad, hq);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (lane == l && qq == (uint32_t)q) {
-                        K[q] = k_lo;
-                        C[q] = lo.colors;
-                    }
-                    if (lane == hl && hq == (uint32_t)q) {
-                        K[q] = k_hi;
-                        C[q] = hi.colors;
-                    }
+                    if (lane == l && qq == (uint32_t)q) S[q] = s_lo;
+                    if (lane == hl && hq == (uint32_t)q) S[q] = s_hi;
                 }
                 ++nb;
             }
@@ -613,11 +660,10 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 #endif
     const uint32_t nboxes = s_nboxes;
     // list position of every box: the number of boxes with a larger key
-    if (wave == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s_key[q * 64 + lane] = K[q];
+    if (tid < kMaxColors) {
+        s_key[tid]  = (uint32_t)tid < nboxes ? order_key(pool[tid].sum, pool[tid].pad) : 0u;
+        s_rank[tid] = 0;
     }
-    if (tid < kMaxColors) s_rank[tid] = 0;
     __syncthreads();
     {
         const uint32_t box = tid & (kMaxColors - 1), part = tid / kMaxColors, parts = blockDim.x / kMaxColors;

@@ -457,12 +457,24 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         const uint32_t chunks = (g.n_samples + 63) / 64;
         const uint32_t per    = (chunks + kCutWaves - 1) / kCutWaves;
         const uint32_t c0 = min(chunks, (uint32_t)wave * per), c1 = min(chunks, c0 + per);
+        // (8 chunks at a time, their loads in flight together and unconditional: one load per
+        // iteration makes the loop a chain of memory round trips)
+        auto load8 = [&](uint32_t c, uint32_t e[8]) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = s.entries[min((c + j) * 64 + lane, g.n_samples - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = c + j < c1 && (c + j) * 64 + lane < g.n_samples ? v[j] : 0u;
+        };
         uint32_t cnt = 0, sum = 0;
-        for (uint32_t c = c0; c < c1; ++c) {
-            const uint32_t k = c * 64 + lane;
-            const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
-            cnt += (uint32_t)__popcll(__ballot(e != 0));
-            sum += e >> 15;
+        for (uint32_t c = c0; c < c1; c += 8) {
+            uint32_t e[8];
+            load8(c, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cnt += (uint32_t)__popcll(__ballot(e[j] != 0));
+                sum += e[j] >> 15;
+            }
         }
         sum = WaveSum(sum);
         if (lane == 0) {
@@ -476,12 +488,18 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             n_all += s_wave_cnt[w];
             sum_all += s_wave_sum[w];
         }
-        for (uint32_t c = c0; c < c1; ++c) {
-            const uint32_t k = c * 64 + lane;
-            const uint32_t e = k < g.n_samples ? s.entries[k] : 0u;
-            const unsigned long long m = __ballot(e != 0);
-            if (e) s.tab_a[at + (uint32_t)__popcll(m & lt_mask)] = e;
-            at += (uint32_t)__popcll(m);
+        // straight into the LDS table when the colours fit there (and are not few enough to skip
+        // the median cut altogether)
+        uint32_t *table = n_all > (uint32_t)kMaxColors && n_all <= (uint32_t)kCutLdsEntries ? cut_lds : s.tab_a;
+        for (uint32_t c = c0; c < c1; c += 8) {
+            uint32_t e[8];
+            load8(c, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long m = __ballot(e[j] != 0);
+                if (e[j]) table[at + (uint32_t)__popcll(m & lt_mask)] = e[j];
+                at += (uint32_t)__popcll(m);
+            }
         }
         if (tid == 0) {
             s_n     = n_all;
@@ -508,9 +526,8 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     }
     uint32_t *tab[2];
     if (n <= (uint32_t)kCutLdsEntries) {
-        tab[0] = cut_lds;
+        tab[0] = cut_lds;  // (filled by the compaction above)
         tab[1] = cut_lds + kCutLdsEntries;
-        for (uint32_t i = tid; i < n; i += blockDim.x) tab[0][i] = s.tab_a[i];
     } else {
         tab[0] = s.tab_a;
         tab[1] = s.tab_b;

@@ -62,10 +62,15 @@ struct SixelFrameScratch {
     // per band, band_ne slots each (see the K5 kernels)
     uint32_t *band_ent;    // (colour, x, mask) entries sorted by colour, x
     uint32_t *band_nkey;   // nodes sorted by sx asc, mx desc, colour asc
-    uint16_t *band_nfirst; // first entry of each node
+    uint16_t *band_nfirst; // node id (colour, start order) of each sorted node
     uint32_t *band_pi;     // per node: pass << 16 | index inside the pass
     uint16_t *band_xs;     // per node: pen position when it is put
-    uint2 *band_rec;       // per OUTPUT SLOT: {node key, first entry | pen << 15 | '$' << 27}
+    uint2 *band_rec;       // per OUTPUT SLOT: {node key, node id | pen << 15 | '$' << 27}
+    // per sorted entry: byte offset of what it emits inside its band's node bodies (exclusive
+    // prefix over the band), length of the run that ends with it (0: none), its node id;
+    // per node id (colour, start order): its first entry
+    uint32_t *band_ep;
+    uint16_t *band_erl, *band_enode, *band_nf;
     int *band_cnt;         // [bands * 4]: entries, nodes
 };
 
@@ -81,6 +86,8 @@ struct SixelBatch {
     uint32_t *band_ent, *band_nkey, *band_pi;
     uint16_t *band_nfirst, *band_xs;
     uint2 *band_rec;
+    uint32_t *band_ep;
+    uint16_t *band_erl, *band_enode, *band_nf;
     int *band_cnt;
     uint32_t *pad_rows;          // [frames][5][w] the rows appended below the frame, as pixels (K4)
     int *error;                  // [1] set when a device-side wait gives up
@@ -109,6 +116,10 @@ __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, c
     s.band_pi     = b.band_pi + fb * g.band_ne;
     s.band_xs     = b.band_xs + fb * g.band_ne;
     s.band_rec    = b.band_rec + fb * g.band_ne;
+    s.band_ep     = b.band_ep + fb * g.band_ne;
+    s.band_erl    = b.band_erl + fb * g.band_ne;
+    s.band_enode  = b.band_enode + fb * g.band_ne;
+    s.band_nf     = b.band_nf + fb * g.band_ne;
     s.band_cnt    = b.band_cnt + fb * 4;
     return s;
 }
@@ -1111,45 +1122,13 @@ __device__ __forceinline__ int FlushRun(char *&p, int ch, int count) {
     return n;
 }
 
-// Bytes of one node (libsixel sixel_put_node): optional "#c", the gap of empty
-// columns from the pen position, then the node's columns sx..mx-1 read from the
-// band's (colour, x)-sorted entries.  Returns the byte count.
-template <bool kWrite>
-__device__ int EmitNode(char *p, const uint32_t *entries, int first_entry, int color, int sx,
-                        int mx, int x_start, bool tag) {
-    int n = 0;
-    if (tag) {
-        if (kWrite) {
-            *p++ = '#';
-            p    = PutUInt(p, (uint32_t)color);
-        }
-        n += 1 + NumLen((uint32_t)color);
-    }
-    int run_ch = 0, run_n = 0;
-    auto push = [&](int bits, int count) {
-        const int ch = bits + '?';
-        if (ch == run_ch) {
-            run_n += count;
-        } else {
-            if (run_n) n += FlushRun<kWrite>(p, run_ch, run_n);
-            run_ch = ch;
-            run_n  = count;
-        }
-    };
-    if (sx > x_start) push(0, sx - x_start);
-    int x = sx, e = first_entry;
-    while (x < mx) {
-        const uint32_t ent = entries[e];
-        const int ex       = (int)((ent >> 6) & 0xffffu);
-        if (ex > x) push(0, ex - x);
-        push((int)(ent & 0x3fu), 1);
-        x = ex + 1;
-        ++e;
-    }
-    if (run_n) n += FlushRun<kWrite>(p, run_ch, run_n);
-    return n;
+// byte count of FlushRun for a run of `count` (0: nothing): "!255c" for every full 255 beyond
+// the last piece, then "!nc" or up to three plain characters
+__device__ __forceinline__ int RunBytes(int count) {
+    const int full = count > 255 ? (count - 1) / 255 : 0;
+    const int rest = count - 255 * full;  // 1..255 (0 only for count == 0)
+    return 5 * full + (rest > 3 ? 2 + NumLen((uint32_t)rest) : rest);
 }
-
 
 __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_tmp, uint32_t *total) {
     // 256 threads; s_tmp: 5 words of LDS.  Returns the exclusive prefix of v.
@@ -1333,28 +1312,96 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     const int e0 = min(n_ent, tid * per_e), e1 = min(n_ent, e0 + per_e);
 
     // ---- nodes: a node starts at a new colour or after a gap of >= 10 empty columns
-    auto breaks = [&](int i) {  // is there a node boundary between entries i-1 and i?
-        const uint32_t p = ent_a[i - 1], e = ent_a[i];
-        return (p >> 22) != (e >> 22) ||
-               (int)((e >> 6) & 0xffffu) - (int)((p >> 6) & 0xffffu) - 1 >= 10;
+    // A node's bytes are an RLE of its columns; a RUN is a maximal stretch of entries of one node
+    // in adjacent columns with the same sixel, and between runs lie gaps of '?'.  What every run
+    // and gap costs -- and so where each goes inside its node's body -- is computed here, in
+    // parallel over the entries and while they are in LDS: the emit kernel then never walks a
+    // node (serial per node, divergent per wave: it used to cost 37 us per band).
+    // (a lane's chunk of entries: flags gathered once, as bit masks when the chunk is short
+    // enough -- it always is for frames whose bands fit LDS)
+    auto node_break2 = [](uint32_t p, uint32_t e) {
+        return (p >> 22) != (e >> 22) || (int)((e >> 6) & 0xffffu) - (int)((p >> 6) & 0xffffu) - 1 >= 10;
     };
-    uint32_t starts = 0;
-    for (int i = e0; i < e1; ++i) starts += (i == 0 || breaks(i)) ? 1u : 0u;
-    uint32_t n_nodes_u;
-    uint32_t k = BlockExclusiveScan(starts, s_tmp, &n_nodes_u);
-    const int n_nodes = (int)n_nodes_u;
-    for (int i = e0; i < e1; ++i)
-        if (i == 0 || breaks(i)) nfirst_u[k++] = (uint16_t)i;
+    auto run_break2 = [](uint32_t p, uint32_t e) {  // does a new run start at e, p being the entry before it?
+        return (p >> 22) != (e >> 22) || ((e >> 6) & 0xffffu) != ((p >> 6) & 0xffffu) + 1 || ((e ^ p) & 0x3fu) != 0;
+    };
+    constexpr bool kMasks = !kWide;  // per_e <= kLdsEntries / 256 = 32
+    uint32_t node_bits = 0, run_bits = 0, starts = 0;  // starts: node starts << 16 | run starts
+    {
+        uint32_t prev = e0 > 0 ? ent_a[e0 - 1] : 0u;
+        for (int i = e0; i < e1; ++i) {
+            const uint32_t e = ent_a[i];
+            const bool ns = i == 0 || node_break2(prev, e), rs = i == 0 || run_break2(prev, e);
+            if (kMasks) {
+                node_bits |= (ns ? 1u : 0u) << (i - e0);
+                run_bits |= (rs ? 1u : 0u) << (i - e0);
+            }
+            starts += (ns ? 0x10000u : 0u) + (rs ? 1u : 0u);
+            prev = e;
+        }
+    }
+    auto node_starts_at = [&](int i) {
+        return kMasks ? ((node_bits >> (i - e0)) & 1u) != 0 : (i == 0 || node_break2(ent_a[i - 1], ent_a[i]));
+    };
+    auto run_starts_at = [&](int i) {
+        return kMasks ? ((run_bits >> (i - e0)) & 1u) != 0 : (i == 0 || run_break2(ent_a[i - 1], ent_a[i]));
+    };
+    uint32_t totals;
+    const uint32_t before = BlockExclusiveScan(starts, s_tmp, &totals);
+    const int n_nodes = (int)(totals >> 16);
+    uint16_t *run_first = reinterpret_cast<uint16_t *>(ent_b);       // [run] first entry   } both until the
+    uint16_t *ent_bytes = reinterpret_cast<uint16_t *>(ent_b) + NE;  // [entry] its bytes   } node keys move in
+    uint16_t *enode_g   = s.band_enode + slot;
+    {
+        uint32_t k = before >> 16, r = before & 0xffffu;
+        for (int i = e0; i < e1; ++i) {
+            if (node_starts_at(i)) nfirst_u[k++] = (uint16_t)i;
+            if (run_starts_at(i)) run_first[r++] = (uint16_t)i;
+            enode_g[i] = (uint16_t)(k - 1);
+        }
+    }
     for (int x = tid; x <= W; x += 256) {
         aux[x]           = 0;  // nodes starting in column x
         aux[kBucket + x] = 0;  // fill counter
     }
     if (kWide) __threadfence_block();
     __syncthreads();
+    // bytes per entry: the gap in front of a run at the run's first entry, the run at its last
+    {
+        uint16_t *erl_g = s.band_erl + slot;
+        uint32_t r = before & 0xffffu, mine = 0;
+        uint32_t prev = e0 > 0 ? ent_a[e0 - 1] : 0u, e = e0 < e1 ? ent_a[e0] : 0u;
+        for (int i = e0; i < e1; ++i) {
+            const uint32_t next = i + 1 < n_ent ? ent_a[i + 1] : 0u;
+            if (run_starts_at(i)) ++r;
+            // (inside a node gaps are shorter than 10 columns: RunBytes(gap) without its loops)
+            const int gap  = node_starts_at(i) ? 0 : (int)((e >> 6) & 0xffffu) - (int)((prev >> 6) & 0xffffu) - 1;
+            const bool end = i == n_ent - 1 || (i + 1 < e1 ? run_starts_at(i + 1) : run_break2(e, next));
+            const int len  = end ? i - (int)run_first[r - 1] + 1 : 0;
+            const int by   = (gap > 3 ? 3 : gap) + RunBytes(len);
+            erl_g[i]       = (uint16_t)len;
+            ent_bytes[i]   = (uint16_t)by;
+            mine += (uint32_t)by;
+            prev = e;
+            e    = next;
+        }
+        uint32_t body_total;
+        uint32_t at = BlockExclusiveScan(mine, s_tmp, &body_total);
+        uint32_t *ep_g = s.band_ep + slot;
+        for (int i = e0; i < e1; ++i) {
+            ep_g[i] = at;
+            at += ent_bytes[i];
+        }
+        if (tid == 0) s.band_cnt[band * 4 + 2] = (int)body_total;
+    }
+    if (kWide) __threadfence_block();
+    __syncthreads();
     uint32_t *key_u = ent_b;
+    uint16_t *nf_g = s.band_nf + slot;
     for (int n = tid; n < n_nodes; n += 256) {
         const int first   = nfirst_u[n];
         const int last    = (n + 1 < n_nodes ? (int)nfirst_u[n + 1] : n_ent) - 1;
+        nf_g[n]           = (uint16_t)first;
         const uint32_t e  = ent_a[first];
         const uint32_t sx = (e >> 6) & 0xffffu, mx = ((ent_a[last] >> 6) & 0xffffu) + 1;
         key_u[n]          = (sx << 20) | ((4095u - mx) << 8) | (e >> 22);
@@ -1384,7 +1431,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         const uint32_t sx  = key >> 20;
         const uint32_t pos = aux[sx] + atomicAdd(&aux[kBucket + sx], 1u);
         nkey[pos]          = key;
-        nfirst[pos]        = nfirst_u[n];
+        nfirst[pos]        = (uint16_t)n;
     }
     if (kWide) __threadfence_block();
     __syncthreads();  // (also orders the global writes above inside the workgroup)
@@ -1539,31 +1586,45 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
     const size_t slot         = (size_t)band * g.band_ne;
     const uint32_t *ent       = s.band_ent + slot;
     const uint2 *rec          = s.band_rec + slot;
+    const uint32_t *ep        = s.band_ep + slot;
+    const uint16_t *erl       = s.band_erl + slot;
+    const uint16_t *enode     = s.band_enode + slot;
+    const uint16_t *nf        = s.band_nf + slot;
+    uint32_t *node_base       = s.band_pi + slot;  // (free again after the packing kernel)
+    const int n_ent           = s.band_cnt[band * 4 + 0];
     const int n_nodes         = s.band_cnt[band * 4 + 1];
+    const uint32_t body_total = (uint32_t)s.band_cnt[band * 4 + 2];
     if (tid == 0) s_overflow = 0;
     __syncthreads();
 
-    auto describe = [&](int k, int *node_first, int *color, int *sx, int *mx, int *x_start, bool *tag,
-                        bool *cr) {
+    // A slot's node: what stands in front of its body ('$', "#c", the gap from the pen position)
+    // and where the body's bytes lie in the band-wide prefix the node kernel left behind.
+    struct Slot {
+        int color, sx, x_start, node;
+        bool tag, cr;
+        uint32_t body0, body;  // prefix at the node's first entry, bytes of its runs and inner gaps
+    };
+    auto describe = [&](int k) {
         const uint2 r      = rec[k];
         const uint32_t key = r.x;
-        *node_first        = (int)(r.y & 0x7fffu);
-        *x_start           = (int)((r.y >> 15) & 0xfffu);
-        *cr                = ((r.y >> 27) & 1u) != 0;
-        *color             = (int)(key & 0xffu);
-        *sx                = (int)(key >> 20);
-        *mx                = 4095 - (int)((key >> 8) & 0xfffu);
+        Slot d;
+        d.node    = (int)(r.y & 0x7fffu);
+        d.x_start = (int)((r.y >> 15) & 0xfffu);
+        d.cr      = ((r.y >> 27) & 1u) != 0;
+        d.color   = (int)(key & 0xffu);
+        d.sx      = (int)(key >> 20);
         // "#c" only when the active colour changes (first node: always, fixed up later)
-        *tag = k == 0 || (int)(rec[k - 1].x & 0xffu) != *color;
+        d.tag = k == 0 || (int)(rec[k - 1].x & 0xffu) != d.color;
+        const int first = nf[d.node], next = d.node + 1 < n_nodes ? (int)nf[d.node + 1] : n_ent;
+        d.body0 = ep[first];
+        d.body  = (next < n_ent ? ep[next] : body_total) - d.body0;
+        return d;
     };
-    // phase 1: byte size of every output slot
+    // phase 1: byte size of every output slot -- no walk over the node, see BandNodes
     for (int k = tid; k < n_nodes; k += 256) {
-        int first_e, color, sx, mx, x_start;
-        bool tag, cr;
-        describe(k, &first_e, &color, &sx, &mx, &x_start, &tag, &cr);
-        char *none = nullptr;
-        node_off[k] = (uint32_t)EmitNode<false>(none, ent, first_e, color, sx, mx, x_start, tag) +
-                      (cr ? 1u : 0u);
+        const Slot d = describe(k);
+        node_off[k]  = (d.cr ? 1u : 0u) + (d.tag ? 1u + (uint32_t)NumLen((uint32_t)d.color) : 0u) +
+                      (uint32_t)RunBytes(d.sx - d.x_start) + d.body;
     }
     __syncthreads();
     // exclusive scan (256 contiguous chunks)
@@ -1589,21 +1650,38 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         __syncthreads();
     }
     const uint32_t band_len = s_scan[4];
-    // phase 2: bytes into the band's scratch slot.  (Staging the bytes in LDS and flushing them
-    // with 16-byte stores was measured slower: 345 vs 225 us per batch -- the staging buffer
-    // costs more in occupancy than the byte stores cost in memory instructions.)
     char *out_band = s.band_bytes + (size_t)band * g.band_cap;
     if (band_len > g.band_cap) {
         if (tid == 0) s_overflow = 1;
     } else {
         if (tid == 0 && lead) out_band[0] = '-';
+        // phase 2a, per slot: what stands in front of the body; and where the body goes, as an
+        // offset to add to an entry's prefix
         for (int k = tid; k < n_nodes; k += 256) {
-            int first_e, color, sx, mx, x_start;
-            bool tag, cr;
-            describe(k, &first_e, &color, &sx, &mx, &x_start, &tag, &cr);
-            char *p = out_band + node_off[k];
-            if (cr) *p++ = '$';
-            EmitNode<true>(p, ent, first_e, color, sx, mx, x_start, tag);
+            const Slot d = describe(k);
+            char *p      = out_band + node_off[k];
+            if (d.cr) *p++ = '$';
+            if (d.tag) {
+                *p++ = '#';
+                p    = PutUInt(p, (uint32_t)d.color);
+            }
+            if (d.sx > d.x_start) FlushRun<true>(p, '?', d.sx - d.x_start);
+            node_base[d.node] = (uint32_t)(p - out_band) - d.body0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // phase 2b, per ENTRY: the gap in front of a run is written by the run's first entry, the
+        // run by its last
+        for (int i = tid; i < n_ent; i += 256) {
+            const uint32_t e  = ent[i];
+            const int node    = enode[i];
+            const int len     = erl[i];
+            const bool inside = i > 0 && (int)enode[i - 1] == node;
+            const int gap     = inside ? (int)((e >> 6) & 0xffffu) - (int)((ent[i - 1] >> 6) & 0xffffu) - 1 : 0;
+            if (gap <= 0 && len == 0) continue;
+            char *p = out_band + (uint32_t)(node_base[node] + ep[i]);  // (the sum wraps in 32 bits by design)
+            if (gap > 0) FlushRun<true>(p, '?', gap);
+            if (len > 0) FlushRun<true>(p, (int)(e & 0x3fu) + '?', len);
         }
     }
     __syncthreads();
@@ -1809,6 +1887,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     const size_t o_bpi   = carve(n_band * g.band_ne * 4);
     const size_t o_bxs   = carve(n_band * g.band_ne * 2);
     const size_t o_brec  = carve(n_band * g.band_ne * sizeof(uint2));
+    const size_t o_bep   = carve(n_band * g.band_ne * 4);
+    const size_t o_berl  = carve(n_band * g.band_ne * 2);
+    const size_t o_ben   = carve(n_band * g.band_ne * 2);
+    const size_t o_bnf   = carve(n_band * g.band_ne * 2);
     const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
     const size_t o_prow  = carve(nf * (size_t)w * 5 * sizeof(uint32_t));
     const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
@@ -1832,6 +1914,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     b.band_pi     = (uint32_t *)(base + o_bpi);
     b.band_xs     = (uint16_t *)(base + o_bxs);
     b.band_rec    = (uint2 *)(base + o_brec);
+    b.band_ep     = (uint32_t *)(base + o_bep);
+    b.band_erl    = (uint16_t *)(base + o_berl);
+    b.band_enode  = (uint16_t *)(base + o_ben);
+    b.band_nf     = (uint16_t *)(base + o_bnf);
     b.band_cnt    = (int *)(base + o_bcnt);
     b.pad_rows    = (uint32_t *)(base + o_prow);
     b.error       = (int *)(base + o_len + nf * sizeof(unsigned long long));
@@ -1913,6 +1999,10 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.band_pi     = b.band_pi + o * g.bands * g.band_ne;
         gb.band_xs     = b.band_xs + o * g.bands * g.band_ne;
         gb.band_rec    = b.band_rec + o * g.bands * g.band_ne;
+        gb.band_ep     = b.band_ep + o * g.bands * g.band_ne;
+        gb.band_erl    = b.band_erl + o * g.bands * g.band_ne;
+        gb.band_enode  = b.band_enode + o * g.bands * g.band_ne;
+        gb.band_nf     = b.band_nf + o * g.bands * g.band_ne;
         gb.band_cnt    = b.band_cnt + o * g.bands * 4;
         gb.pad_rows    = b.pad_rows + o * w * 5;
         gb.out         = b.out + o * b.out_cap;

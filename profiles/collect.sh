@@ -13,12 +13,13 @@ set -e
 tag=${1:-r1}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag; rm -rf "$out"; mkdir -p "$out"
-args="--no-cpu-baseline --steps 5 --warmup 2 $*"
+ulimit -c 0   # (a crashing run must not spend minutes dumping a core of the GPU mappings)
+args="--no-cpu-baseline --batched-streams 0 --steps 5 --warmup 2 $*"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o prof -- python bench.py $args > "$out/bench_trace.log" 2>&1
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o prof -- python bench.py $args > "$out/bench_trace.log" 2>&1
 cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o pmc -- python bench.py $args > "$out/bench_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pmc -- python bench.py $args > "$out/bench_write.log" 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o pmc -- python bench.py $args > "$out/bench_fetch.log" 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pmc -- python bench.py $args > "$out/bench_write.log" 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]

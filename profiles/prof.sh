@@ -2,11 +2,12 @@
 # tools/prof.sh <outdir-name> <bench args...>: rocprofv3 kernel trace + stats of bench.py on the
 # GPU box (run through gpurun); writes CSVs under gpurun_out/<name>/ and prints the timg kernels.
 set -e
+ulimit -c 0
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$name
 rm -rf "$out"; mkdir -p "$out"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o prof -- \
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o prof -- \
     python bench.py --no-cpu-baseline "$@" > "$out/bench.log" 2>&1 || { tail -20 "$out/bench.log"; exit 1; }
 tail -1 "$out/bench.log" | cut -c1-400
 f=$(find "$out" -name '*kernel_stats.csv' | head -1)

@@ -216,8 +216,9 @@ __global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBat
 // libsixel's list bookkeeping with the prepared results for as long as the box it
 // needs next has been prepared.  Boxes near the head of the sum-ordered list are exactly
 // the ones the serial algorithm takes next, so almost no speculation is wasted.
-// Inside a split: boxes of <= 64 colours are sorted in registers with ballots, larger
-// ones by a stable per-lane-segment counting sort on the 5-bit key.
+// Inside a split: boxes of <= 64 colours are sorted in registers (ds_permute), up to 256
+// colours four entries per lane, larger ones by a stable per-lane-segment counting sort on
+// the 5-bit key.  The list itself is never materialised: see "The box list" in the kernel.
 constexpr int kCutWaves      = 8;
 constexpr int kCutLdsEntries = 12288;             // colour table kept in LDS up to this size
 // words of per-wave scratch: [64][33] 16-bit counters (a lane's segment of a box and every
@@ -1074,13 +1075,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
 // libsixel encodes a 6-row band as "nodes" (a colour's run of columns, gaps of < 10
 // empty columns merged), sorts them by (start asc, end desc, colour asc) and packs them
 // greedily into left-to-right passes separated by '$'.  Per band:
-//   K5a BandNodes  (256 lanes)  entries in column order -> stable radix sort by colour
-//                               -> nodes -> bucket sort by start column
+//   K5a BandNodes  (256 lanes)  entries sorted by (colour, column) through a presence bitmap
+//                               (radix sort for frames too wide for that) -> nodes -> bucket
+//                               sort by start column; per entry: run length, byte prefix, node id
 //   K5b BandPack   (ONE wave)   the greedy packing is first-fit over the passes' pen
 //                               positions in sorted node order: serial by nature, so it
 //                               runs one wave per band with no LDS and every band of the
 //                               batch in flight at once
-//   K5c BandEmit   (256 lanes)  pass-major output order, byte size per node, scan, bytes
+//   K5c BandEmit   (256 lanes)  pass-major output order; byte size per node in O(1) from the
+//                               prefix, scan, then bytes: one lane per slot for what stands in
+//                               front of a node's body, one lane per ENTRY for runs and gaps
 __device__ __forceinline__ int NumLen(uint32_t v) {
     return v >= 10000 ? 5 : v >= 1000 ? 4 : v >= 100 ? 3 : v >= 10 ? 2 : 1;
 }

@@ -968,7 +968,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // clamped, the tables indexed with clamped values): straight-line code the compiler can
         // schedule across the two dependent LDS reads; only the stores are predicated, and a
         // lane outside its row produces zero terms.
-        auto step = [&](int t, uint32_t px) __attribute__((always_inline)) {
+        // (k_odd: the parity of the step inside the unrolled body = the parity of every lane's column)
+        auto step = [&](int t, uint32_t px, bool k_odd) __attribute__((always_inline)) {
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
             const int x       = t - 2 * rl;
             const bool active = has_row && (unsigned)x < (unsigned)W;
@@ -1017,8 +1018,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             first_q3 = x == 0 ? m3 : first_q3;
             // four indices per 32-bit store: the newest enters at the top byte
             packed_idx = __builtin_amdgcn_alignbyte(i8, packed_idx, 1);
-            if (active && ((x & 3) == 3 || x == W - 1) && !odd)
-                *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx >> (8 * (3 - (x & 3)));
+            // (a group of four ends in an odd column; the row's last column is odd unless W is)
+            if (k_odd || (W & 1))
+                if (active && ((x & 3) == 3 || x == W - 1) && !odd)
+                    *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx >> (8 * (3 - (x & 3)));
             if (active && rl == kPairRows - 1) {  // the row above the next wave's first row
                 // term word r | g << 8 | b << 16: the even lane writes its low half (r, g), the
                 // odd lane the high half (b, 0), each the low bytes of its two 16-bit values
@@ -1047,7 +1050,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // loads in flight; the up to 7 extra steps find every lane out of range)
 #define TIMG_DITHER_STEP(k, P)                                    \
     asm volatile("s_waitcnt vmcnt(7)" : "+v"(P) : : "memory");    \
-    step(t + k, P);                                               \
+    step(t + k, P, (k & 1) != 0);                                 \
     P = fetch(t + k + kDitherAhead);
         for (int t = 0; t < steps; t += 8) {
             TIMG_DITHER_STEP(0, p0)
@@ -1712,6 +1715,7 @@ __global__ void __launch_bounds__(256) AssembleFrameKernel(SixelGeom g, SixelBat
     const SixelFrameScratch s = FrameScratch(b, g, f);
     char *out                 = b.out + (size_t)f * b.out_cap;
     __shared__ uint32_t pal_off[kMaxColors + 1];
+    __shared__ uint32_t s_tmp[5], s_header;
     const int ncolors = s.meta[0];
     // cursor mode string + DCS + raster attributes, by one thread
     if (tid == 0) {
@@ -1728,29 +1732,42 @@ __global__ void __launch_bounds__(256) AssembleFrameKernel(SixelGeom g, SixelBat
         const uint32_t n = (uint32_t)(p - tmp);
         for (uint32_t i = 0; i < n; ++i)
             if (i < b.out_cap) out[i] = tmp[i];
-        uint32_t acc = n;
-        for (int c = 0; c < ncolors; ++c) {
-            pal_off[c] = acc;
-            acc += (uint32_t)PaletteEntryLen(c, s.palette + c * 3);
-        }
-        pal_off[ncolors] = acc;
-        // band offsets with the '#c' elision across band boundaries
-        uint32_t at = acc;
-        for (int band = 0; band < g.bands; ++band) {
-            const int *m   = s.band_meta + band * 4;
-            uint32_t elide = 0;
-            if (band > 0 && m[1] >= 0 && m[1] == s.band_meta[(band - 1) * 4 + 2]) elide = (uint32_t)m[3];
+        s_header = n;
+    }
+    // where every palette entry and every band goes: lengths in parallel, two scans (a single
+    // lane walking 256 colours and all bands is a chain of dependent global loads)
+    uint32_t pal_total;
+    const uint32_t my_pal = tid < ncolors ? (uint32_t)PaletteEntryLen(tid, s.palette + tid * 3) : 0u;
+    const uint32_t pal_at = BlockExclusiveScan(my_pal, s_tmp, &pal_total);  // (its barriers publish s_header)
+    const uint32_t bands0 = s_header + pal_total;
+    if (tid < ncolors) pal_off[tid] = s_header + pal_at;
+    {
+        // '#c' at the start of a band is elided when the previous band ended in the same colour
+        auto elided = [&](int band) -> uint32_t {
+            const int *m = s.band_meta + band * 4;
+            return band > 0 && m[1] >= 0 && m[1] == s.band_meta[(band - 1) * 4 + 2] ? (uint32_t)m[3] : 0u;
+        };
+        const int per = (g.bands + 255) / 256;
+        const int b0 = min(g.bands, tid * per), b1 = min(g.bands, b0 + per);
+        uint32_t mine = 0;
+        for (int band = b0; band < b1; ++band) mine += (uint32_t)s.band_meta[band * 4 + 0] - elided(band);
+        uint32_t bands_total;
+        uint32_t at = bands0 + BlockExclusiveScan(mine, s_tmp, &bands_total);
+        for (int band = b0; band < b1; ++band) {
+            const uint32_t elide     = elided(band);
             s.band_off[band * 2 + 0] = at;
             s.band_off[band * 2 + 1] = elide;
-            at += (uint32_t)m[0] - elide;
+            at += (uint32_t)s.band_meta[band * 4 + 0] - elide;
         }
-        // ST + cursor suffix
-        const char tail[3] = {'\033', '\\', g.broken_cursor ? '\n' : '\r'};
-        for (int i = 0; i < 3; ++i)
-            if (at + i < b.out_cap) out[at + i] = tail[i];
-        b.out_len[f] = (unsigned long long)at + 3ull;
+        if (tid == 0) {
+            // ST + cursor suffix
+            const uint32_t end = bands0 + bands_total;
+            const char tail[3] = {'\033', '\\', g.broken_cursor ? '\n' : '\r'};
+            for (int i = 0; i < 3; ++i)
+                if (end + i < b.out_cap) out[end + i] = tail[i];
+            b.out_len[f] = (unsigned long long)end + 3ull;
+        }
     }
-    __syncthreads();
     if (tid < ncolors) {
         char tmp[24];
         char *p            = tmp;

@@ -63,7 +63,13 @@ int timg_hip_sync(timg_hip_ctx *ctx, void *stream);
  * 101-116) and ImageScaler::Scale (src/image-scaler.h:39; STB back-end
  * src/image-scaler.cc:83-92).  Creating a scaler builds the resampling plan
  * (stb_image_resize2-compatible coefficient tables) once on the host and
- * uploads it; Scale is then pure device work. */
+ * uploads it; Scale is then pure device work.
+ * Threads: calls that use a context's scratch memory (host-side buffers, the
+ * canvas encoders) are serialised by the library, so loader threads may create
+ * and use scalers concurrently, as they do in the reference
+ * (src/timg.cc:948-968); everything on one context runs on its one stream.  One
+ * timg_hip_scaler carries per-launch device state of its own: use a scaler
+ * from one thread at a time (the reference creates one per image as well). */
 #define TIMG_HIP_FMT_RGBA 0 /* ImageScaler::ColorFmt::kRGBA */
 #define TIMG_HIP_FMT_BGRA 1 /* ImageScaler::ColorFmt::kRGB32 (b,g,r,a in memory) */
 #define TIMG_HIP_FILTER_STB_DEFAULT 0 /* bit-exact with the STB back-end */

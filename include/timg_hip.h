@@ -192,6 +192,10 @@ void timg_hip_block_canvas_destroy(timg_hip_block_canvas *c);
 int timg_hip_block_canvas_send(timg_hip_block_canvas *c, int x, int dy, const uint8_t *fb,
                                int w, int h, int stride, int fb_on_device, char *out,
                                size_t out_cap, size_t *out_len, void *stream);
+/* Forgets the previous frame: the next send encodes every cell, as Send does whenever
+ * position or size differ from the previous call (:343-346).  For callers that encoded
+ * frames in between through timg_hip_block_encode_grid (a grid row in one launch). */
+void timg_hip_block_canvas_forget(timg_hip_block_canvas *c);
 
 /* ---- sixel canvas: timg::SixelCanvas -------------------------------------
  * Replaces the two libsixel calls of SixelCanvas::Send

@@ -735,6 +735,10 @@ void timg_hip_block_canvas_destroy(timg_hip_block_canvas *c) {
     delete c;
 }
 
+void timg_hip_block_canvas_forget(timg_hip_block_canvas *c) {
+    if (c) c->last_height = c->last_width = 0;
+}
+
 int timg_hip_block_canvas_send(timg_hip_block_canvas *c, int x, int dy, const uint8_t *fb, int w,
                                int h, int stride, int fb_on_device, char *out, size_t out_cap,
                                size_t *out_len, void *stream) {

@@ -92,6 +92,8 @@ def load_library():
     L.timg_hip_block_canvas_create.argtypes = [vp, c_int, POINTER(vp)]
     L.timg_hip_block_canvas_destroy.argtypes = [vp]
     L.timg_hip_block_canvas_destroy.restype = None
+    L.timg_hip_block_canvas_forget.argtypes = [vp]
+    L.timg_hip_block_canvas_forget.restype = None
     L.timg_hip_block_canvas_send.argtypes = [vp, c_int, c_int, vp, c_int, c_int, c_int, c_int, vp,
                                              c_size_t, POINTER(c_size_t), vp]
     L.timg_hip_sixel_max_bytes.argtypes = [c_int, c_int]
@@ -154,6 +156,10 @@ class BlockCanvas:
             self.handle, x, dy, p, w, h, stride, int(dev), c_void_p(out.ctypes.data), cap,
             byref(n), None))
         return out[:n.value].tobytes()
+
+    def forget(self):
+        """The next send encodes every cell (as after a Send at another position)."""
+        self.owner.L.timg_hip_block_canvas_forget(self.handle)
 
     def close(self):
         if self.handle:

@@ -24,6 +24,7 @@
 #include "hip-sixel-canvas.h"
 #include "hip-unicode-block-canvas.h"
 #include "image-scaler.h"
+#include "renderer.h"
 #include "thread-pool.h"
 #include "unicode-block-canvas.h"
 
@@ -154,6 +155,62 @@ static void CheckBlockCanvas() {
     fflush(stdout);
 }
 
+// The reference's OWN grid renderer (src/renderer.cc:81-189) drives both canvases; the twin
+// holds a grid row's Sends back and encodes them with one device call (SetGridColumns).
+static void CheckGridRenderer() {
+    for (int flags : {0, 1, 5}) {
+        for (int with_title = 0; with_title < 2; ++with_title) {
+            const bool quarter = flags & 1, upper = flags & 2, c256 = flags & 4;
+            volatile sig_atomic_t intr = 0;
+            const int fd_ref = memfd_create("ref", 0), fd_hip = memfd_create("hip", 0);
+            {
+                BufferedWriteSequencer seq_ref(fd_ref, false, 4, true, intr);
+                BufferedWriteSequencer seq_hip(fd_hip, false, 4, true, intr);
+                UnicodeBlockCanvas ref(&seq_ref, quarter, upper, c256);
+                HipUnicodeBlockCanvas hip(&seq_hip, quarter, upper, c256);
+                const int columns = 4;
+                hip.SetGridColumns(columns);
+                DisplayOptions opts;
+                opts.cell_x_px  = quarter ? 2 : 1;
+                opts.cell_y_px  = 2;
+                opts.width      = 104;  // the column's width in pixels
+                opts.height     = 60;
+                opts.show_title = with_title != 0;
+                // (the renderers go first: their destructors still move the cursor)
+                auto r_ref = Renderer::Create(&ref, opts, columns, 3, Duration(), Duration());
+                auto r_hip = Renderer::Create(&hip, opts, columns, 3, Duration(), Duration());
+                for (int i = 0; i < 11; ++i) {
+                    // most images fill their cell; one is smaller, one is an animation
+                    const int w = i == 5 ? 61 : 100, h = i == 5 ? 39 : 56;
+                    Framebuffer fb(w, h);
+                    Fill(&fb, i % 3);
+                    const std::string title = "image " + std::to_string(i);
+                    auto cb_ref = r_ref->render_cb(title);
+                    auto cb_hip = r_hip->render_cb(title);
+                    cb_ref(0, 0, fb, SeqType::FrameImmediate, {});
+                    cb_hip(0, 0, fb, SeqType::FrameImmediate, {});
+                    if (i == 2 || i == 7) {
+                        for (int f = 0; f < 3; ++f) {
+                            rgba_t c;
+                            c.r = (uint8_t)(60 * f); c.g = 20; c.b = 220; c.a = 255;
+                            for (int x = 3 * f; x < 3 * f + 11; ++x) fb.SetPixel(x, 5 + 9 * f, c);
+                            cb_ref(0, -h, fb, SeqType::AnimationFrame, {});
+                            cb_hip(0, -h, fb, SeqType::AnimationFrame, {});
+                        }
+                    }
+                }
+            }
+            const std::string r = Slurp(fd_ref), h = Slurp(fd_hip);
+            CHECK(r == h && !r.empty(), "grid renderer flags %d title %d: %zu vs %zu bytes", flags, with_title,
+                  r.size(), h.size());
+            close(fd_ref);
+            close(fd_hip);
+        }
+    }
+    printf("grid renderer over the block canvas twin: checked\n");
+    fflush(stdout);
+}
+
 static void CheckSixelCanvas(const char *dump_path) {
     volatile sig_atomic_t intr = 0;
     const int fd = memfd_create("six", 0);
@@ -189,7 +246,7 @@ static void CheckSixelCanvas(const char *dump_path) {
 }
 
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|sixel] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -197,6 +254,7 @@ int main(int argc, char **argv) {
     }
     if (what == "all" || what == "scaler") CheckScaler();
     if (what == "all" || what == "block") CheckBlockCanvas();
+    if (what == "all" || what == "grid") CheckGridRenderer();
     if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);

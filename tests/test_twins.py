@@ -36,6 +36,8 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     # (includes MultiColumnRenderer from the reference driving the block canvas twin in its
     # grid mode: a row of Sends held back and encoded by one device call)
     assert "grid renderer over the block canvas twin: checked" in r.stdout
+    # (and the sixel twin's grid mode -- one batched encode per grid row -- against the twin itself)
+    assert "grid renderer over the sixel canvas twin: checked" in r.stdout
     # the sixel twin's stream: two frames, each decodable to a 200x114 raster
     data = dump.read_bytes()
     frames = [b"\x1bP" + part.split(b"\x1b\\")[0] + b"\x1b\\" for part in data.split(b"\x1bP")[1:]]

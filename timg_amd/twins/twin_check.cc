@@ -245,8 +245,57 @@ static void CheckSixelCanvas(const char *dump_path) {
     printf("sixel canvas twin: %zu bytes\n", s.size());
 }
 
+// No reference class to compare with (libsixel is absent), so the sixel twin's grid mode is
+// checked against the twin itself: the reference's MultiColumnRenderer drives one canvas that
+// encodes every Send on its own and one that holds grid rows back; the streams must be equal.
+static void CheckSixelGrid() {
+    std::string streams[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        rng_state = 777;
+        volatile sig_atomic_t intr = 0;
+        const int fd = memfd_create("six", 0);
+        {
+            ThreadPool pool(2);  // (outlives the sequencer, see above)
+            BufferedWriteSequencer seq(fd, false, 4, true, intr);
+            DisplayOptions opts;
+            opts.cell_x_px      = 9;
+            opts.cell_y_px      = 18;
+            opts.width          = 126;  // the column's width in pixels
+            opts.height         = 90;
+            opts.show_title     = true;
+            opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+            SixelOptions so;
+            HipSixelCanvas canvas(&seq, &pool, so, opts);
+            const int columns = 3;
+            if (mode == 1) canvas.SetGridColumns(columns);
+            auto renderer = Renderer::Create(&canvas, opts, columns, 3, Duration(), Duration());
+            for (int i = 0; i < 8; ++i) {
+                const int w = i == 4 ? 90 : 120, h = i == 4 ? 50 : 85;  // (85 pads to 90 rows)
+                Framebuffer fb(w, h);
+                Fill(&fb, i % 3);
+                auto cb = renderer->render_cb("image " + std::to_string(i));
+                cb(0, 0, fb, i == 6 ? SeqType::StartOfAnimation : SeqType::FrameImmediate, {});
+                if (i == 6) {
+                    for (int f = 0; f < 2; ++f) {
+                        rgba_t c;
+                        c.r = 250; c.g = (uint8_t)(90 * f); c.b = 20; c.a = 255;
+                        for (int x = 10; x < 40; ++x) fb.SetPixel(x, 20 + 11 * f, c);
+                        cb(0, -h, fb, SeqType::AnimationFrame, {});
+                    }
+                }
+            }
+        }
+        streams[mode] = Slurp(fd);
+        close(fd);
+    }
+    CHECK(streams[0] == streams[1] && streams[0].size() > 10000, "sixel grid mode: %zu vs %zu bytes",
+          streams[0].size(), streams[1].size());
+    printf("grid renderer over the sixel canvas twin: checked (%zu bytes)\n", streams[0].size());
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|sixelgrid] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -256,6 +305,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "block") CheckBlockCanvas();
     if (what == "all" || what == "grid") CheckGridRenderer();
     if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
+    if (what == "all" || what == "sixelgrid") CheckSixelGrid();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);
         return 1;

@@ -234,6 +234,7 @@ def test_sixel_batch_device_resident(hip, oracle):
     ("noise", 800, 450),   # > 8192 distinct colours: median cut runs on the global-memory table
     ("photo", 64, 1100),   # 1104 padded rows: the diffusion pipeline goes round three times (16 waves x 32 rows)
     ("photo", 1200, 600),  # wide boundary rows leave LDS for 7 diffusion waves only: three rounds of 224 rows
+    ("photo", 766, 450),   # 13 diffusion waves fill the 160 KB of LDS to the byte: the static part must still fit
     ("alpha", 801, 77),    # odd width: padded index rows, pad rows (77 -> 78) with a checkerboard
     ("photo", 1365, 30),   # widest frame the band encoder takes
     ("noise", 3, 130),     # narrower than the row skew

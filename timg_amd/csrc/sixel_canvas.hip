@@ -1954,7 +1954,8 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         return (8192 + 512 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
     };
     if (const char *cap = getenv("TIMG_HIP_DITHER_WAVES")) dither_waves = std::max(1, std::min(dither_waves, atoi(cap)));
-    while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024) --dither_waves;
+    // (the kernel's static LDS -- the progress counters -- comes on top of the dynamic part)
+    while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024 - 512) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
     const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
     const int nodes_nws     = ((w + 31) >> 5) | 1;

@@ -152,3 +152,61 @@ int ref_cell_height_for_pixels(int quarter, int pixels) {
 uint8_t ref_as_256_term_color(uint32_t c) { return unpack(c).As256TermColor(); }
 
 }  // extern "C"
+
+#ifndef TIMG_REF_NO_PNG
+// ---- graphics protocols: png::Encode (src/timg-png.cc + the libdeflate of this image),
+// KittyGraphicsCanvas / ITerm2GraphicsCanvas (src/kitty-canvas.cc, src/iterm2-canvas.cc) ----
+#include "display-options.h"
+#include "iterm2-canvas.h"
+#include "kitty-canvas.h"
+#include "thread-pool.h"
+#include "timg-png.h"
+
+extern "C" {
+
+long ref_png_encode(const uint8_t *fb, int w, int h, int level, int with_alpha, char *out, long cap) {
+    Framebuffer f(w, h);
+    memcpy((void *)f.begin(), fb, (size_t)w * h * 4);
+    if ((size_t)cap < timg::png::UpperBound(w, h)) return -1;
+    return (long)timg::png::Encode(f, level,
+                                   with_alpha ? timg::png::ColorEncoding::kRGBA_32
+                                              : timg::png::ColorEncoding::kRGB_24,
+                                   out, (size_t)cap);
+}
+
+size_t ref_png_upper_bound(int w, int h) { return timg::png::UpperBound(w, h); }
+
+// One Send(0, 0, fb) of the real canvas (kind 0: kitty, 1: iTerm2) through the real
+// thread pool and write sequencer; returns everything that reached the terminal.
+long ref_graphics_send(int kind, const uint8_t *fb, int w, int h, int level, int local_alpha, char *out,
+                       long cap) {
+    volatile sig_atomic_t interrupt = 0;
+    const int fd = memfd_create("gfx", 0);
+    if (fd < 0) return -1;
+    {
+        timg::ThreadPool pool(1);  // (outlives the sequencer: ~ThreadPool drops queued work)
+        timg::BufferedWriteSequencer seq(fd, false, 4, true, interrupt);
+        timg::DisplayOptions opts;
+        opts.cell_x_px            = 9;
+        opts.cell_y_px            = 18;
+        opts.compress_pixel_level = level;
+        opts.local_alpha_handling = local_alpha != 0;
+        Framebuffer f(w, h);
+        memcpy((void *)f.begin(), fb, (size_t)w * h * 4);
+        std::unique_ptr<timg::TerminalCanvas> canvas;
+        if (kind == 0)
+            canvas.reset(new timg::KittyGraphicsCanvas(&seq, &pool, false, opts));
+        else
+            canvas.reset(new timg::ITerm2GraphicsCanvas(&seq, &pool, opts));
+        canvas->Send(0, 0, f, timg::SeqType::FrameImmediate, {});
+        canvas.reset();
+    }
+    const off_t n = lseek(fd, 0, SEEK_END);
+    long got      = -1;
+    if (n <= cap && pread(fd, out, (size_t)n, 0) == n) got = (long)n;
+    close(fd);
+    return got;
+}
+
+}  // extern "C"
+#endif  // TIMG_REF_NO_PNG

@@ -88,6 +88,27 @@ int oracle_sixel_palette(const uint8_t *rgba, int w, int h, uint8_t *pal_rgb,
 int oracle_sixel_decode(const char *data, long len, uint8_t *rgba_out,
                         int cap_w, int cap_h, int *w, int *h, int *ncolors);
 
+/* ---- graphics protocols at --compress=0 (oracle/png.c) --------------------------
+ * png::Encode (src/timg-png.cc:91-153) with libdeflate level 0 (stored blocks),
+ * EncodeBase64 (src/timg-base64.h), the bytes KittyGraphicsCanvas::Send
+ * (src/kitty-canvas.cc:126-221, no tmux) and ITerm2GraphicsCanvas::Send
+ * (src/iterm2-canvas.cc:40-75) put behind their cursor prefix.  Pinned against the
+ * real reference + libdeflate through oracle/_ref (tests/test_png_oracle.py). */
+size_t oracle_png_bytes(int w, int h, int with_alpha); /* exact size of the level-0 PNG */
+long oracle_png_encode(const uint8_t *fb, int w, int h, int with_alpha, char *out, long cap);
+long oracle_base64(const uint8_t *in, long n, char *out);
+size_t oracle_kitty_max_bytes(int w, int h);
+long oracle_kitty_encode(const uint8_t *fb, int w, int h, int with_alpha, uint32_t id,
+                         char *scratch, char *out, long cap);
+long oracle_iterm2_encode(const uint8_t *fb, int w, int h, int with_alpha, char *scratch,
+                          char *out, long cap);
+/* checksum building blocks (the parallel forms are what a device implementation needs) */
+uint32_t oracle_crc32(uint32_t crc, const uint8_t *p, size_t n);
+uint32_t oracle_adler32(const uint8_t *p, size_t n);
+uint32_t oracle_crc32_multmodp(uint32_t a, uint32_t b);
+uint32_t oracle_crc32_xpow_bytes(uint64_t n_bytes);
+uint32_t oracle_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,36 @@ def main():
             out[f"fb{k}"] = fb
             out[f"bytes{k}"] = np.frombuffer(data, np.uint8)
     np.savez_compressed(os.path.join(HERE, "sixel_unpinned.npz"), **out)
+    # ---- graphics protocols at --compress=0: the REAL png::Encode (+ libdeflate) and the real
+    # kitty / iTerm2 canvases --------------------------------------------------
+    if ref.has_png():
+        import re
+        out, k = {}, 0
+        rng = np.random.default_rng(11)
+        for (w, h, kind) in [(1, 1, "noise"), (5, 3, "noise"), (67, 50, "noise"), (30, 26, "ramp"), (200, 56, "ramp"),
+                             (200, 90, "ramp"), (129, 127, "ramp")]:
+            if kind == "noise":
+                fb = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+            else:
+                y, x = np.mgrid[0:h, 0:w]
+                fb = np.stack([(x * 3 + y) & 255, (x + y * 5) & 255, (x * y) & 255, 255 - ((x + y) & 127)], -1).astype(np.uint8)
+            for with_alpha in (True, False):
+                if not with_alpha and k % 4 != 1:
+                    continue  # (a few RGB-only cases are enough)
+                real = ref.graphics_send(0, fb, level=0, local_alpha=not with_alpha)
+                image_id = int(re.search(rb"i=(\d+),", real).group(1))
+                kitty = real[real.index(b"\x1b_G"):]
+                iterm = ref.graphics_send(1, fb, level=0, local_alpha=not with_alpha)
+                iterm = iterm[iterm.index(b"\x1b]1337"):]
+                out[f"fb{k}"] = fb
+                out[f"alpha{k}"] = np.array(with_alpha)
+                out[f"id{k}"] = np.array(image_id, np.uint32)
+                out[f"png{k}"] = np.frombuffer(ref.png_encode(fb, 0, with_alpha), np.uint8)
+                out[f"kitty{k}"] = np.frombuffer(kitty, np.uint8)
+                out[f"iterm{k}"] = np.frombuffer(iterm, np.uint8)
+                k += 1
+        out["count"] = np.array(k)
+        np.savez_compressed(os.path.join(HERE, "png.npz"), **out)
     print("golden vectors written to", HERE)
 
 

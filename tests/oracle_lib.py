@@ -96,6 +96,76 @@ class Oracle:
         assert n >= 0, n
         return out.raw[:n]
 
+    # ---- graphics protocols at --compress=0 (oracle/png.c) ----
+    def _png_setup(self):
+        L = self.L
+        if getattr(self, "_png_ready", False):
+            return
+        L.oracle_png_bytes.restype = c_size_t
+        L.oracle_png_encode.restype = c_long
+        L.oracle_png_encode.argtypes = [vp, c_int, c_int, c_int, vp, c_long]
+        L.oracle_base64.restype = c_long
+        L.oracle_base64.argtypes = [vp, c_long, vp]
+        L.oracle_kitty_max_bytes.restype = c_size_t
+        L.oracle_kitty_encode.restype = c_long
+        L.oracle_kitty_encode.argtypes = [vp, c_int, c_int, c_int, c_uint32, vp, vp, c_long]
+        L.oracle_iterm2_encode.restype = c_long
+        L.oracle_iterm2_encode.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_long]
+        L.oracle_crc32.restype = c_uint32
+        L.oracle_crc32.argtypes = [c_uint32, vp, c_size_t]
+        L.oracle_adler32.restype = c_uint32
+        L.oracle_adler32.argtypes = [vp, c_size_t]
+        L.oracle_crc32_combine.restype = c_uint32
+        L.oracle_crc32_combine.argtypes = [c_uint32, c_uint32, ctypes.c_uint64]
+        self._png_ready = True
+
+    def png_encode(self, fb, with_alpha=True) -> bytes:
+        self._png_setup()
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        cap = self.L.oracle_png_bytes(w, h, int(with_alpha))
+        out = ctypes.create_string_buffer(cap)
+        n = self.L.oracle_png_encode(_d(fb), w, h, int(with_alpha), out, cap)
+        assert n == cap, (n, cap)
+        return out.raw[:n]
+
+    def base64(self, data: bytes) -> bytes:
+        self._png_setup()
+        out = ctypes.create_string_buffer((len(data) + 2) // 3 * 4 + 4)
+        n = self.L.oracle_base64(ctypes.c_char_p(data), len(data), out)
+        return out.raw[:n]
+
+    def _gfx(self, fn, fb, with_alpha, *mid):
+        self._png_setup()
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        scratch = ctypes.create_string_buffer(self.L.oracle_png_bytes(w, h, int(with_alpha)))
+        cap = self.L.oracle_kitty_max_bytes(w, h)
+        out = ctypes.create_string_buffer(cap)
+        n = fn(_d(fb), w, h, int(with_alpha), *mid, scratch, out, cap)
+        assert n > 0
+        return out.raw[:n]
+
+    def kitty_encode(self, fb, image_id: int, with_alpha=True) -> bytes:
+        self._png_setup()
+        return self._gfx(self.L.oracle_kitty_encode, fb, with_alpha, c_uint32(image_id))
+
+    def iterm2_encode(self, fb, with_alpha=True) -> bytes:
+        self._png_setup()
+        return self._gfx(self.L.oracle_iterm2_encode, fb, with_alpha)
+
+    def crc32(self, data: bytes, crc=0) -> int:
+        self._png_setup()
+        return int(self.L.oracle_crc32(crc, ctypes.c_char_p(data), len(data)))
+
+    def adler32(self, data: bytes) -> int:
+        self._png_setup()
+        return int(self.L.oracle_adler32(ctypes.c_char_p(data), len(data)))
+
+    def crc32_combine(self, a, b, len_b) -> int:
+        self._png_setup()
+        return int(self.L.oracle_crc32_combine(a, b, len_b))
+
     def sixel_decode(self, data: bytes, cap_w=4096, cap_h=4096):
         img = np.zeros((cap_h, cap_w, 4), np.uint8)
         w, h, nc = c_int(), c_int(), c_int()
@@ -204,6 +274,33 @@ class Ref:
 
     def block_canvas(self, quarter=False, upper=False, color256=False):
         return _RefCanvas(self, quarter, upper, color256)
+
+    # ---- graphics protocols (only when the reference library was built with libdeflate) ----
+    def has_png(self):
+        return hasattr(self.L, "ref_png_encode")
+
+    def png_encode(self, fb, level=0, with_alpha=True) -> bytes:
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        self.L.ref_png_upper_bound.restype = c_size_t
+        self.L.ref_png_encode.restype = c_long
+        cap = self.L.ref_png_upper_bound(w, h)
+        out = ctypes.create_string_buffer(cap)
+        n = self.L.ref_png_encode(_d(fb), w, h, level, int(with_alpha), out, c_long(cap))
+        assert n > 0
+        return out.raw[:n]
+
+    def graphics_send(self, kind, fb, level=0, local_alpha=False) -> bytes:
+        """Everything one Send(0, 0, fb) of the real KittyGraphicsCanvas (kind 0) or
+        ITerm2GraphicsCanvas (kind 1) writes to the terminal."""
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        self.L.ref_graphics_send.restype = c_long
+        cap = 4096 + (w * h * 4 + h + 1024) * 2
+        out = ctypes.create_string_buffer(cap)
+        n = self.L.ref_graphics_send(kind, _d(fb), w, h, level, int(local_alpha), out, c_long(cap))
+        assert n > 0
+        return out.raw[:n]
 
     def as_256(self, c):
         return int(self.L.ref_as_256_term_color(c_uint32(pack(c)))) & 0xFF

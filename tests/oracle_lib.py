@@ -237,7 +237,10 @@ class Ref:
         p = os.path.join(ROOT, "oracle", "_ref", "libtimg_ref.so")
         if not os.path.exists(p):
             return None
-        return Ref(p)
+        try:
+            return Ref(p)
+        except OSError:  # e.g. a box without the libdeflate the library was linked against
+            return None
 
     def __init__(self, path):
         self.L = L = ctypes.CDLL(path)

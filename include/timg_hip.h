@@ -219,6 +219,35 @@ int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
                           char *out, size_t out_cap, int out_on_device,
                           size_t *out_len, void *stream);
 
+/* ---- graphics-protocol canvases at --compress=0: timg::KittyGraphicsCanvas,
+ * timg::ITerm2GraphicsCanvas, png::Encode ------------------------------------
+ * Replace what the encoder closure of KittyGraphicsCanvas::Send
+ * (src/kitty-canvas.cc:167-214, no tmux pass-through) and of
+ * ITerm2GraphicsCanvas::Send (src/iterm2-canvas.cc:52-71) computes -- png::Encode
+ * (src/timg-png.cc:91-153), EncodeBase64 (src/timg-base64.h:28-55) and the escape
+ * framing -- for DisplayOptions::compress_pixel_level == 0 (`--compress=0`): the
+ * zlib stream then consists of stored blocks and every byte is positional.  Other
+ * levels are libdeflate's match finder and stay on the host.
+ * flags: TIMG_HIP_GFX_RGB24 = png::ColorEncoding::kRGB_24 (local alpha handling).
+ * Frames of a batch share (w, h); frame i goes to out + i * out_cap, out_len[i]
+ * bytes.  kitty image ids are the caller's (the reference derives them from
+ * time(), src/kitty-canvas.cc:47-52). */
+#define TIMG_HIP_GFX_RGB24 1
+size_t timg_hip_png_bytes(int w, int h, int flags); /* exact size of the PNG */
+size_t timg_hip_gfx_max_bytes(int w, int h);        /* any of the three outputs fits */
+int timg_hip_png_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                        size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                        char *out, size_t out_cap, int out_on_device, size_t *out_len,
+                        void *stream);
+int timg_hip_kitty_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                          size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                          const uint32_t *image_ids, char *out, size_t out_cap,
+                          int out_on_device, size_t *out_len, void *stream);
+int timg_hip_iterm2_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                           size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                           char *out, size_t out_cap, int out_on_device, size_t *out_len,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,7 @@
 """-m gpu: the HIP path, called through the C-ABI, against the oracle on the
 same seeded inputs.  Bit-exact for scale, blend and block bytes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -478,3 +480,50 @@ def test_streaming_fallback_chain_on_mixed_tiles(hip, oracle):
     hip.scale_blend(sc, src, got)
     assert np.array_equal(got, want)
     sc.close()
+
+
+# ---- graphics protocols at --compress=0: png / kitty / iTerm2 -----------------
+# The oracle (oracle/png.c) is pinned against the real png::Encode + libdeflate and the real
+# canvases (tests/test_png_oracle.py); the golden vectors come from the real reference.
+GFX_SIZES = [(1, 1), (5, 3), (67, 50), (200, 56), (129, 127), (400, 300), (4095, 5), (800, 450)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", GFX_SIZES)
+def test_png_kitty_iterm2_bytes_match_oracle(hip, oracle, w, h):
+    fb = synth.make("noise" if (w + h) % 2 else "alpha", w, h, seed=w * 3 + h)
+    for rgb24 in (False, True):
+        assert hip.gfx_encode("png", fb, w, h, rgb24=rgb24)[0] == oracle.png_encode(fb, not rgb24), (w, h, rgb24)
+        got = hip.gfx_encode("kitty", fb, w, h, rgb24=rgb24, image_ids=[4_000_000_123])[0]
+        assert got == oracle.kitty_encode(fb, 4_000_000_123, not rgb24), (w, h, rgb24)
+        assert hip.gfx_encode("iterm2", fb, w, h, rgb24=rgb24)[0] == oracle.iterm2_encode(fb, not rgb24), (w, h, rgb24)
+
+
+@pytest.mark.gpu
+def test_gfx_batch_device_resident(hip, oracle):
+    import torch
+    w, h, n = 200, 90, 5
+    frames = np.stack([synth.make("photo", w, h, seed=40 + i) for i in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    cap = hip.L.timg_hip_gfx_max_bytes(w, h)
+    out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+    ids = [7, 70, 700, 7000, 70000]
+    lens = hip.gfx_encode("kitty", dev.data_ptr(), w, h, n_frames=n, image_ids=ids, out=out.data_ptr(), out_cap=cap)
+    host = out.cpu().numpy()
+    for i in range(n):
+        assert host[i, :lens[i]].tobytes() == oracle.kitty_encode(frames[i], ids[i], True), i
+    pngs = hip.gfx_encode("png", frames, w, h, n_frames=n)
+    for i in range(n):
+        assert pngs[i] == oracle.png_encode(frames[i], True), i
+
+
+@pytest.mark.gpu
+def test_gfx_golden_vectors_from_the_real_reference(hip):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "png.npz"))
+    for i in range(int(g["count"])):
+        fb, with_alpha = np.ascontiguousarray(g[f"fb{i}"]), bool(g[f"alpha{i}"])
+        h, w = fb.shape[:2]
+        assert hip.gfx_encode("png", fb, w, h, rgb24=not with_alpha)[0] == g[f"png{i}"].tobytes(), i
+        assert hip.gfx_encode("kitty", fb, w, h, rgb24=not with_alpha,
+                              image_ids=[int(g[f"id{i}"])])[0] == g[f"kitty{i}"].tobytes(), i
+        assert hip.gfx_encode("iterm2", fb, w, h, rgb24=not with_alpha)[0] == g[f"iterm{i}"].tobytes(), i

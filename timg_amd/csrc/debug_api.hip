@@ -3,6 +3,9 @@
 // part of the public ABI (not declared in include/timg_hip.h).
 #include <cstring>
 
+#include <vector>
+
+#include "gfx_layout.h"
 #include "resample_plan.h"
 
 extern "C" int timg_hip_debug_plan_dump(int sw, int sh, int in_fmt, int dw, int dh, int filter,
@@ -30,4 +33,51 @@ extern "C" int timg_hip_debug_plan_dump(int sw, int sh, int in_fmt, int dw, int 
     memcpy(v_rows, p.v_rows.data(), p.v_rows.size() * sizeof(int));
     memcpy(v_coeff, p.v_coeff.data(), p.v_coeff.size() * sizeof(float));
     return (int)p.v_rows.size();
+}
+
+// The graphics-protocol path (gfx_canvas.hip) with plain loops in place of the kernels' lanes:
+// the same per-index functions (gfx_layout.h), the same order of passes.  Host only, for
+// tests/test_gfx_layout.py.  kind: 0 png, 1 kitty, 2 iTerm2; flags bit 0: RGB (alpha dropped).
+extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, int h, int flags, uint32_t image_id,
+                                           uint8_t *out, long cap) {
+    using namespace timg_amd;
+    const PngGeom g = MakePngGeom(w, h, !(flags & 1));
+    std::vector<uint8_t> png_store(g.png_n);
+    uint8_t *png = kind == kGfxPng ? out : png_store.data();
+    if (kind == kGfxPng && cap < (long)g.png_n) return -1;
+    // pass 1: head, filtered bytes, block headers, the two sums
+    for (uint32_t i = 0; i < kPngIdatData + 2; ++i) png[i] = g.head[i];
+    unsigned long long sum_a = 0, sum_b = 0;
+    for (uint32_t j = 0; j < g.raw_n; ++j) {
+        const uint8_t v      = PngRawByte(fb, (size_t)w * 4, g, j);
+        png[PngRawOffset(j)] = v;
+        sum_a += v;
+        sum_b += (unsigned long long)(g.raw_n - j) * v;
+    }
+    for (uint32_t b = 0; b < g.n_blocks; ++b) PngBlockHeader(g, b, png + PngBlockHeaderOffset(b));
+    // pass 2: Adler-32 closes the zlib stream
+    PutBE32(png + PngAdlerOffset(g), AdlerFromSums(g, sum_a, sum_b));
+    // passes 3 and 4: CRC of "IDAT" + stream from chunk CRCs
+    std::vector<uint32_t> chunk(g.n_chunks), segment(g.n_segments);
+    for (uint32_t c = 0; c < g.n_chunks; ++c) chunk[c] = PngChunkCrc(png, g, c);
+    for (uint32_t s = 0; s < g.n_segments; ++s) segment[s] = PngSegmentCrc(chunk.data(), g, s);
+    PngTail(png, g, PngTotalCrc(segment.data(), g));
+    if (kind == kGfxPng) return (long)g.png_n;
+    // pass 5: base64 and framing
+    char header[kGfxHeaderCap];
+    const GfxFraming f = MakeFraming(kind, g, FormatGfxHeader(kind, g, image_id, header));
+    if (cap < (long)f.total) return -1;
+    for (uint32_t i = 0; i < f.header_len; ++i) out[i] = (uint8_t)header[i];
+    for (uint32_t grp = 0; grp < f.n_groups; ++grp) {
+        const uint32_t q = Base64Quad(png, g.png_n, grp);
+        uint8_t *o       = out + GfxGroupOffset(f, grp);
+        o[0] = (uint8_t)q;
+        o[1] = (uint8_t)(q >> 8);
+        o[2] = (uint8_t)(q >> 16);
+        o[3] = (uint8_t)(q >> 24);
+    }
+    if (kind == kGfxKitty)
+        for (uint32_t c = 1; c < f.n_kitty_chunks; ++c) KittySeparator(f, c, out + KittySeparatorOffset(f, c));
+    GfxTrailer(f, out);
+    return (long)f.total;
 }

@@ -1,0 +1,262 @@
+// timg_amd/csrc/gfx_layout.h -- per-element arithmetic of the graphics-protocol path at
+// --compress=0 (png::Encode over stored deflate blocks, base64, kitty / iTerm2 framing;
+// src/timg-png.cc:91-153, src/timg-base64.h:28-55, src/kitty-canvas.cc:167-214,
+// src/iterm2-canvas.cc:52-71).
+//
+// Everything here is a pure function of an index, usable from host and device alike: the
+// kernels of gfx_canvas.hip call these per lane, and the host-only debug entry point
+// timg_hip_debug_gfx_emulate (debug_api.hip) walks the same indices in plain loops, so the
+// whole layout -- offsets, block headers, checksum composition, chunk framing -- is checked
+// on the CPU against the real reference before a GPU is involved (tests/test_gfx_layout.py).
+#ifndef TIMG_AMD_GFX_LAYOUT_H_
+#define TIMG_AMD_GFX_LAYOUT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#if defined(__HIPCC__)
+#define TIMG_HD __host__ __device__ inline
+#else
+#define TIMG_HD inline
+#endif
+
+namespace timg_amd {
+
+constexpr uint32_t kStoredBlock  = 65535;  // libdeflate level 0: stored blocks of at most this
+constexpr uint32_t kPngIdatData  = 8 + 25 + 8;  // signature, IHDR chunk, IDAT length + type
+constexpr uint32_t kCrcChunk     = 512;    // bytes per lane in the chunk CRC pass
+constexpr uint32_t kCrcSegment   = 64;     // chunks combined serially by one lane
+constexpr uint32_t kKittyChunk   = 3072;   // bytes per kitty escape (4096 base64 characters)
+constexpr uint32_t kKittySepLen  = 13;     // ESC \ ESC _ G q = 2 , m = X ;
+constexpr uint32_t kGfxHeaderCap = 96;
+
+enum GfxKind { kGfxPng = 0, kGfxKitty = 1, kGfxIterm2 = 2 };
+
+struct PngGeom {
+    int w, h, bpp;         // bpp: 4 (RGBA) or 3 (RGB, alpha dropped)
+    uint32_t row;          // 1 + w * bpp filtered bytes per row
+    uint32_t raw_n;        // h * row
+    uint32_t n_blocks;     // stored blocks
+    uint32_t zlen;         // zlib stream: 2 + 5 * n_blocks + raw_n + 4
+    uint32_t png_n;        // whole file: 57 + zlen
+    uint32_t crc_len;      // "IDAT" + zlib stream
+    uint32_t n_chunks;     // CRC chunks of kCrcChunk bytes
+    uint32_t n_segments;   // groups of kCrcSegment chunks
+    // x^(8 * len) mod P for the lengths the combination steps shift by
+    uint32_t x_chunk, x_last_chunk, x_segment, x_last_segment;
+    uint8_t head[kPngIdatData + 2];  // signature, IHDR (with its CRC), IDAT length + "IDAT", 78 01
+};
+
+TIMG_HD uint32_t MultModP(uint32_t a, uint32_t b) {  // a(x) * b(x) mod the (reflected) CRC-32 polynomial
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+    }
+    return p;
+}
+
+TIMG_HD uint32_t XPowBytes(uint64_t n_bytes) {  // x^(8 n) mod P
+    uint32_t sq = 1u << 30, r = 1u << 31;
+    uint64_t e = n_bytes * 8;
+    while (e) {
+        if (e & 1) r = MultModP(sq, r);
+        sq = MultModP(sq, sq);
+        e >>= 1;
+    }
+    return r;
+}
+
+TIMG_HD uint32_t Crc32Bytes(const uint8_t *p, uint32_t n) {  // standard CRC-32 of n bytes
+    uint32_t crc = 0xffffffffu;
+    for (uint32_t i = 0; i < n; ++i) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; ++k) crc = (crc & 1u) ? (crc >> 1) ^ 0xedb88320u : crc >> 1;
+    }
+    return ~crc;
+}
+
+TIMG_HD void PutBE32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+
+inline PngGeom MakePngGeom(int w, int h, bool with_alpha) {
+    PngGeom g{};
+    g.w   = w;
+    g.h   = h;
+    g.bpp = with_alpha ? 4 : 3;
+    g.row      = 1u + (uint32_t)w * g.bpp;
+    g.raw_n    = (uint32_t)h * g.row;
+    g.n_blocks = (g.raw_n + kStoredBlock - 1) / kStoredBlock;
+    g.zlen     = 2 + 5 * g.n_blocks + g.raw_n + 4;
+    g.png_n    = 8 + 25 + 12 + g.zlen + 12;
+    g.crc_len  = 4 + g.zlen;
+    g.n_chunks   = (g.crc_len + kCrcChunk - 1) / kCrcChunk;
+    g.n_segments = (g.n_chunks + kCrcSegment - 1) / kCrcSegment;
+    const uint32_t last_chunk   = g.crc_len - (g.n_chunks - 1) * kCrcChunk;
+    const uint32_t last_segment = g.crc_len - (g.n_segments - 1) * kCrcSegment * kCrcChunk;
+    g.x_chunk        = XPowBytes(kCrcChunk);
+    g.x_last_chunk   = XPowBytes(last_chunk);
+    g.x_segment      = XPowBytes((uint64_t)kCrcSegment * kCrcChunk);
+    g.x_last_segment = XPowBytes(last_segment);
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4e, 0x47, '\r', '\n', 0x1a, '\n'};
+    uint8_t *p = g.head;
+    for (int i = 0; i < 8; ++i) *p++ = sig[i];
+    PutBE32(p, 13);
+    p[4] = 'I'; p[5] = 'H'; p[6] = 'D'; p[7] = 'R';
+    PutBE32(p + 8, (uint32_t)w);
+    PutBE32(p + 12, (uint32_t)h);
+    p[16] = 8;
+    p[17] = with_alpha ? 6 : 2;
+    p[18] = p[19] = p[20] = 0;
+    PutBE32(p + 21, Crc32Bytes(p + 4, 17));
+    p += 25;
+    PutBE32(p, g.zlen);
+    p[4] = 'I'; p[5] = 'D'; p[6] = 'A'; p[7] = 'T';
+    p[8] = 0x78;
+    p[9] = 0x01;
+    return g;
+}
+
+// ---- PNG body: one filtered byte per index j < raw_n --------------------------------------
+// value of filtered byte j (row filter type 1 = Sub, src/timg-png.cc:96,:124-135)
+TIMG_HD uint8_t PngRawByte(const uint8_t *frame, size_t stride, const PngGeom &g, uint32_t j) {
+    const uint32_t y = j / g.row, i = j - y * g.row;
+    if (i == 0) return 1;
+    const uint32_t x = (i - 1) / (uint32_t)g.bpp, c = (i - 1) - x * (uint32_t)g.bpp;
+    const uint8_t *line = frame + (size_t)y * stride;
+    const uint8_t cur   = line[x * 4 + c];
+    return x == 0 ? cur : (uint8_t)(cur - line[(x - 1) * 4 + c]);
+}
+// where filtered byte j lies in the file: behind the zlib header and one 5-byte block header
+// per stored block started so far
+TIMG_HD uint32_t PngRawOffset(uint32_t j) { return kPngIdatData + 2 + 5 * (j / kStoredBlock + 1) + j; }
+// header of stored block b (BFINAL | BTYPE=00, LEN, NLEN) and its place
+TIMG_HD uint32_t PngBlockHeaderOffset(uint32_t b) { return kPngIdatData + 2 + b * (5 + kStoredBlock); }
+TIMG_HD void PngBlockHeader(const PngGeom &g, uint32_t b, uint8_t hdr[5]) {
+    const uint32_t left = g.raw_n - b * kStoredBlock, len = left < kStoredBlock ? left : kStoredBlock;
+    hdr[0] = len == left ? 1 : 0;
+    hdr[1] = (uint8_t)len;
+    hdr[2] = (uint8_t)(len >> 8);
+    hdr[3] = (uint8_t)~len;
+    hdr[4] = (uint8_t)(~len >> 8);
+}
+// Adler-32 from the plain sums  A' = sum d_j,  B' = sum (raw_n - j) d_j  over the filtered bytes
+TIMG_HD uint32_t AdlerFromSums(const PngGeom &g, unsigned long long sum_a, unsigned long long sum_b) {
+    const uint32_t a = (uint32_t)((1ull + sum_a) % 65521ull);
+    const uint32_t b = (uint32_t)(((unsigned long long)g.raw_n + sum_b) % 65521ull);
+    return (b << 16) | a;
+}
+TIMG_HD uint32_t PngAdlerOffset(const PngGeom &g) { return kPngIdatData + g.zlen - 4; }
+TIMG_HD uint32_t PngCrcOffset(const PngGeom &g) { return kPngIdatData + g.zlen; }
+TIMG_HD uint32_t PngCrcRegion() { return kPngIdatData - 4; }  // "IDAT" starts the checksummed bytes
+// CRC of chunk c of the checksummed region
+TIMG_HD uint32_t PngChunkCrc(const uint8_t *png, const PngGeom &g, uint32_t c) {
+    const uint32_t at = c * kCrcChunk, left = g.crc_len - at;
+    return Crc32Bytes(png + PngCrcRegion() + at, left < kCrcChunk ? left : kCrcChunk);
+}
+// crc(A || B) = x^(8|B|) * crc(A) + crc(B): chunks of segment s left to right
+TIMG_HD uint32_t PngSegmentCrc(const uint32_t *chunk_crc, const PngGeom &g, uint32_t s) {
+    const uint32_t c0 = s * kCrcSegment, c1 = c0 + kCrcSegment < g.n_chunks ? c0 + kCrcSegment : g.n_chunks;
+    uint32_t acc = chunk_crc[c0];
+    for (uint32_t c = c0 + 1; c < c1; ++c)
+        acc = MultModP(c + 1 == g.n_chunks ? g.x_last_chunk : g.x_chunk, acc) ^ chunk_crc[c];
+    return acc;
+}
+// ... and the segments left to right
+TIMG_HD uint32_t PngTotalCrc(const uint32_t *segment_crc, const PngGeom &g) {
+    uint32_t acc = segment_crc[0];
+    for (uint32_t s = 1; s < g.n_segments; ++s)
+        acc = MultModP(s + 1 == g.n_segments ? g.x_last_segment : g.x_segment, acc) ^ segment_crc[s];
+    return acc;
+}
+TIMG_HD void PngTail(uint8_t *png, const PngGeom &g, uint32_t crc) {  // IDAT's CRC and the IEND chunk
+    uint8_t *p = png + PngCrcOffset(g);
+    PutBE32(p, crc);
+    p[4] = p[5] = p[6] = p[7] = 0;
+    p[8] = 'I'; p[9] = 'E'; p[10] = 'N'; p[11] = 'D';
+    p[12] = 0xae; p[13] = 0x42; p[14] = 0x60; p[15] = 0x82;
+}
+
+// ---- base64 + framing: one group of three PNG bytes per index g ----------------------------
+struct GfxFraming {
+    int kind;               // GfxKind
+    uint32_t header_len;    // bytes in front of the first base64 character
+    uint32_t n_groups;      // ceil(png_n / 3)
+    uint32_t n_kitty_chunks;
+    uint32_t total;         // bytes of the whole frame
+};
+
+TIMG_HD GfxFraming MakeFraming(int kind, const PngGeom &g, uint32_t header_len) {
+    GfxFraming f{};
+    f.kind       = kind;
+    f.header_len = header_len;
+    f.n_groups   = (g.png_n + 2) / 3;
+    f.n_kitty_chunks = (g.png_n + kKittyChunk - 1) / kKittyChunk;
+    if (kind == kGfxKitty)
+        f.total = header_len + 4 * f.n_groups + (f.n_kitty_chunks - 1) * kKittySepLen + 3;  // ESC \ LF
+    else
+        f.total = header_len + 4 * f.n_groups + 2;  // BEL LF
+    return f;
+}
+
+TIMG_HD uint32_t Base64Quad(const uint8_t *png, uint32_t png_n, uint32_t grp) {  // four characters, first in the low byte
+    const char *b64 = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    const uint32_t at = grp * 3, left = png_n - at;
+    const uint32_t b0 = png[at], b1 = left > 1 ? png[at + 1] : 0, b2 = left > 2 ? png[at + 2] : 0;
+    const uint32_t c0 = (uint8_t)b64[b0 >> 2], c1 = (uint8_t)b64[((b0 & 3) << 4) | (b1 >> 4)];
+    const uint32_t c2 = left > 1 ? (uint8_t)b64[((b1 & 15) << 2) | (b2 >> 6)] : '=';
+    const uint32_t c3 = left > 2 ? (uint8_t)b64[b2 & 63] : '=';
+    return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+}
+// where group grp's four characters go
+TIMG_HD uint32_t GfxGroupOffset(const GfxFraming &f, uint32_t grp) {
+    const uint32_t groups_per_chunk = kKittyChunk / 3;
+    const uint32_t sep = f.kind == kGfxKitty ? (grp / groups_per_chunk) * kKittySepLen : 0;
+    return f.header_len + 4 * grp + sep;
+}
+// separator in front of kitty chunk c >= 1: ESC \ ESC _ G q = 2 , m = <more> ;
+TIMG_HD uint32_t KittySeparatorOffset(const GfxFraming &f, uint32_t c) {
+    return f.header_len + c * (4 * (kKittyChunk / 3) + kKittySepLen) - kKittySepLen;
+}
+TIMG_HD void KittySeparator(const GfxFraming &f, uint32_t c, uint8_t sep[13]) {
+    const char *s = "\033\\\033_Gq=2,m=";
+    for (int i = 0; i < 11; ++i) sep[i] = (uint8_t)s[i];
+    sep[11] = c + 1 < f.n_kitty_chunks ? '1' : '0';
+    sep[12] = ';';
+}
+TIMG_HD void GfxTrailer(const GfxFraming &f, uint8_t *frame_out) {
+    uint8_t *p = frame_out + f.total - (f.kind == kGfxKitty ? 3 : 2);
+    if (f.kind == kGfxKitty) {
+        p[0] = 033;
+        p[1] = '\\';
+        p[2] = '\n';
+    } else {
+        p[0] = 007;
+        p[1] = '\n';
+    }
+}
+
+// (host) what stands in front of the base64 data: src/kitty-canvas.cc:180-186 (no tmux),
+// src/iterm2-canvas.cc:63-65.  Returns its length (< kGfxHeaderCap).
+inline uint32_t FormatGfxHeader(int kind, const PngGeom &g, uint32_t image_id, char *buf) {
+    int n = 0;
+    if (kind == kGfxKitty)
+        n = snprintf(buf, kGfxHeaderCap, "\033_Ga=T,i=%u,q=2,f=100,m=%d;", image_id, g.png_n > kKittyChunk ? 1 : 0);
+    else if (kind == kGfxIterm2)
+        n = snprintf(buf, kGfxHeaderCap, "\033]1337;File=size=%d;width=%dpx;height=%dpx;inline=1:", (int)g.png_n, g.w,
+                     g.h);
+    return (uint32_t)n;
+}
+
+}  // namespace timg_amd
+
+#endif  // TIMG_AMD_GFX_LAYOUT_H_

@@ -101,6 +101,14 @@ def load_library():
     L.timg_hip_sixel_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
                                         c_int, POINTER(Blend), vp, c_size_t, c_int,
                                         POINTER(c_size_t), vp]
+    L.timg_hip_png_bytes.argtypes = [c_int, c_int, c_int]
+    L.timg_hip_png_bytes.restype = c_size_t
+    L.timg_hip_gfx_max_bytes.argtypes = [c_int, c_int]
+    L.timg_hip_gfx_max_bytes.restype = c_size_t
+    gfx = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int, c_int]
+    L.timg_hip_png_encode.argtypes = gfx + [vp, c_size_t, c_int, POINTER(c_size_t), vp]
+    L.timg_hip_iterm2_encode.argtypes = gfx + [vp, c_size_t, c_int, POINTER(c_size_t), vp]
+    L.timg_hip_kitty_encode.argtypes = gfx + [vp, vp, c_size_t, c_int, POINTER(c_size_t), vp]
     _lib = L
     return L
 
@@ -296,6 +304,35 @@ class TimgHip:
 
     def block_canvas(self, flags=0) -> BlockCanvas:
         return BlockCanvas(self, flags)
+
+    # ---- graphics protocols at --compress=0 (png / kitty / iTerm2) ----
+    RGB24 = 1
+
+    def gfx_encode(self, kind, fb, w, h, n_frames=1, rgb24=False, image_ids=None, out=None, out_cap=None,
+                   stride=0, frame_stride=0, stream=None):
+        """kind: "png", "kitty" (image_ids: one uint32 per frame) or "iterm2"."""
+        p, dev = _ptr(fb)
+        if out_cap is None:
+            out_cap = int(self.L.timg_hip_gfx_max_bytes(w, h))
+        host_out = out is None
+        if host_out:
+            out = np.empty(out_cap * n_frames, np.uint8)
+        op, o_dev = _ptr(out)
+        lens = (c_size_t * n_frames)()
+        flags = self.RGB24 if rgb24 else 0
+        st = c_void_p(stream) if stream else None
+        if kind == "kitty":
+            ids = (ctypes.c_uint32 * n_frames)(*[int(v) for v in image_ids])
+            rc = self.L.timg_hip_kitty_encode(self.ctx, p, w, h, stride, frame_stride, int(dev), n_frames, flags,
+                                              ids, op, out_cap, int(o_dev), lens, st)
+        else:
+            fn = self.L.timg_hip_png_encode if kind == "png" else self.L.timg_hip_iterm2_encode
+            rc = fn(self.ctx, p, w, h, stride, frame_stride, int(dev), n_frames, flags, op, out_cap, int(o_dev),
+                    lens, st)
+        self._check(rc)
+        if host_out:
+            return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
+        return list(lens)
 
     def sixel_max_bytes(self, w, h) -> int:
         return int(self.L.timg_hip_sixel_max_bytes(w, h))

@@ -3,8 +3,8 @@
 build/twin_check links hzeller/timg's ImageScaler / Framebuffer /
 UnicodeBlockCanvas / BufferedWriteSequencer (compiled from /root/reference in
 this container by timg_amd/twins/Makefile) next to HipImageScaler,
-HipUnicodeBlockCanvas and HipSixelCanvas and drives both through the calls the
-renderer makes.  The binary travels to the GPU box with the snapshot."""
+HipUnicodeBlockCanvas, HipSixelCanvas and the kitty / iTerm2 twins and drives both
+through the calls the renderer makes.  The binary travels to the GPU box with the snapshot."""
 import os
 import subprocess
 
@@ -38,6 +38,8 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     assert "grid renderer over the block canvas twin: checked" in r.stdout
     # (and the sixel twin's grid mode -- one batched encode per grid row -- against the twin itself)
     assert "grid renderer over the sixel canvas twin: checked" in r.stdout
+    # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
+    assert "kitty / iTerm2 canvas twins at --compress=0: checked" in r.stdout
     # the sixel twin's stream: two frames, each decodable to a 200x114 raster
     data = dump.read_bytes()
     frames = [b"\x1bP" + part.split(b"\x1b\\")[0] + b"\x1b\\" for part in data.split(b"\x1bP")[1:]]

@@ -20,10 +20,13 @@
 #include "display-options.h"
 #include "framebuffer.h"
 #include "hip-context.h"
+#include "hip-graphics-canvas.h"
 #include "hip-image-scaler.h"
 #include "hip-sixel-canvas.h"
 #include "hip-unicode-block-canvas.h"
 #include "image-scaler.h"
+#include "iterm2-canvas.h"
+#include "kitty-canvas.h"
 #include "renderer.h"
 #include "thread-pool.h"
 #include "unicode-block-canvas.h"
@@ -294,8 +297,73 @@ static void CheckSixelGrid() {
     fflush(stdout);
 }
 
+// kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside
+// the twins, through the same thread pool / sequencer machinery.  kitty image ids come from
+// time() in both (src/kitty-canvas.cc:47-52): they are blanked out before comparing.
+static std::string BlankKittyIds(std::string s) {
+    size_t at = 0;
+    while ((at = s.find("a=T,i=", at)) != std::string::npos) {
+        at += 6;
+        while (at < s.size() && s[at] >= '0' && s[at] <= '9') s[at++] = '#';
+    }
+    return s;
+}
+
+static void CheckGraphicsCanvases() {
+    for (int kind = 0; kind < 2; ++kind) {          // 0 kitty, 1 iTerm2
+        for (int local_alpha = 0; local_alpha < 2; ++local_alpha) {
+            std::string streams[2];
+            for (int twin = 0; twin < 2; ++twin) {
+                rng_state = 4242;
+                volatile sig_atomic_t intr = 0;
+                const int fd = memfd_create("gfx", 0);
+                {
+                    ThreadPool pool(2);  // (outlives the sequencer, see above)
+                    BufferedWriteSequencer seq(fd, false, 4, true, intr);
+                    DisplayOptions opts;
+                    opts.cell_x_px            = 9;
+                    opts.cell_y_px            = 18;
+                    opts.compress_pixel_level = 0;
+                    opts.local_alpha_handling = local_alpha != 0;
+                    std::unique_ptr<TerminalCanvas> canvas;
+                    if (kind == 0 && twin) canvas.reset(new HipKittyGraphicsCanvas(&seq, &pool, false, opts));
+                    if (kind == 0 && !twin) canvas.reset(new KittyGraphicsCanvas(&seq, &pool, false, opts));
+                    if (kind == 1 && twin) canvas.reset(new HipITerm2GraphicsCanvas(&seq, &pool, opts));
+                    if (kind == 1 && !twin) canvas.reset(new ITerm2GraphicsCanvas(&seq, &pool, opts));
+                    const int sizes[][2] = {{67, 50}, {200, 113}, {400, 300}, {5, 3}};
+                    int col = 0;
+                    for (const auto &wh : sizes) {
+                        Framebuffer fb(wh[0], wh[1]);
+                        Fill(&fb, col % 2);
+                        canvas->Send(18 * col, col ? -wh[1] : 0, fb, SeqType::FrameImmediate, {});
+                        ++col;
+                    }
+                    // an animation: start + two frames (kitty alternates two ids)
+                    Framebuffer anim(90, 40);
+                    Fill(&anim, 1);
+                    canvas->Send(0, 0, anim, SeqType::StartOfAnimation, {});
+                    for (int f = 0; f < 2; ++f) {
+                        rgba_t c;
+                        c.r = 200; c.g = (uint8_t)(100 * f); c.b = 0; c.a = 255;
+                        for (int x = 0; x < 30; ++x) anim.SetPixel(x, 3 + f, c);
+                        canvas->Send(0, -40, anim, SeqType::AnimationFrame, {});
+                    }
+                    canvas.reset();
+                }
+                streams[twin] = Slurp(fd);
+                close(fd);
+            }
+            const std::string r = BlankKittyIds(streams[0]), h = BlankKittyIds(streams[1]);
+            CHECK(r == h && r.size() > 1000, "%s canvas, local alpha %d: %zu vs %zu bytes", kind ? "iTerm2" : "kitty",
+                  local_alpha, r.size(), h.size());
+        }
+    }
+    printf("kitty / iTerm2 canvas twins at --compress=0: checked\n");
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|sixelgrid] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|sixelgrid|graphics] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -306,6 +374,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "grid") CheckGridRenderer();
     if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
     if (what == "all" || what == "sixelgrid") CheckSixelGrid();
+    if (what == "all" || what == "graphics") CheckGraphicsCanvases();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);
         return 1;

@@ -98,7 +98,9 @@ def main():
                          "streams and report it as `batched_streams` (0 = skip)")
     ap.add_argument("--frames", type=int, default=64, help="frames per rank per step (grid 8x8)")
     ap.add_argument("--kind", default="photo", choices=["photo", "noise", "alpha"])
-    ap.add_argument("--mode", default="sixel", choices=["sixel", "quarter", "half"])
+    ap.add_argument("--mode", default="sixel", choices=["sixel", "quarter", "half", "kitty", "iterm2", "png"],
+                    help="canvas: sixel (the BASELINE metric), half/quarter blocks, or a graphics protocol at "
+                         "--compress=0 (kitty, iterm2; png = png::Encode alone)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
@@ -122,7 +124,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     in_w, in_h, out_w, out_h = 3840, 2160, 800, 450
-    if args.mode != "sixel":
+    if args.mode in ("quarter", "half"):
         out_w, out_h = 200, 56  # BASELINE config 3: grid cell of an 800-cell canvas
     bg = (0x1E, 0x1E, 0x2E, 0xFF)
     blend = timg_amd.Blend.make(bg)
@@ -186,7 +188,9 @@ def main():
 
     result = {
         "metric": "Mpixels/s scale+sixel-encode, 4K->800px grid=8x8" if args.mode == "sixel"
-                  else f"Mpixels/s scale+{args.mode}-block-encode, 4K->200x56 grid=8x8",
+                  else (f"Mpixels/s scale+{args.mode}-encode (--compress=0), 4K->800px grid=8x8"
+                        if args.mode in ("kitty", "iterm2", "png")
+                        else f"Mpixels/s scale+{args.mode}-block-encode, 4K->200x56 grid=8x8"),
         "value": round(value, 1),
         "unit": "Mpixels/s",
         "n_gpus": world,

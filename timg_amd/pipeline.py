@@ -26,6 +26,8 @@ class GridPipeline:
         self.scaled = torch.empty((n_frames, out_h, out_w, 4), dtype=torch.uint8, device=device)
         if mode == "sixel":
             self.cap = hip.sixel_max_bytes(out_w, out_h)
+        elif mode in ("kitty", "iterm2", "png"):  # graphics protocols at --compress=0
+            self.cap = int(hip.L.timg_hip_gfx_max_bytes(out_w, out_h))
         else:
             self.cap = hip.block_max_bytes(out_w, out_h)
         self.out = torch.empty((n_frames, self.cap), dtype=torch.uint8, device=device)
@@ -47,6 +49,10 @@ class GridPipeline:
             lens = self.hip.sixel_encode(self.scaled.data_ptr(), self.out_w, self.out_h,
                                          pad_blend=self.blend, n_frames=self.n,
                                          out=self.out.data_ptr(), out_cap=self.cap, stream=st)
+        elif self.mode in ("kitty", "iterm2", "png"):
+            lens = self.hip.gfx_encode(self.mode, self.scaled.data_ptr(), self.out_w, self.out_h, n_frames=self.n,
+                                       image_ids=range(1, self.n + 1) if self.mode == "kitty" else None,
+                                       out=self.out.data_ptr(), out_cap=self.cap, stream=st)
         else:
             flags = {"half": 0, "quarter": TimgHip.QUARTER}[self.mode]
             # --grid=8x8: frame i sits in grid column i % 8, i.e. is Sent at that column's x

@@ -1,4 +1,6 @@
-// Microbenchmark: VALU issue rate of plain vs packed fp32 mul/add on gfx950.
+// Microbenchmark: VALU issue rate of plain vs packed fp32 mul/add, byte->float decode variants on gfx950.
+// columns: time, SIMD cycles per wave-instruction assuming the NOMINAL 2.4 GHz (the clock under these
+// loads is lower: read ratios between rows, not absolute cycles), lane-ops per nominal clock per CU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -33,6 +35,49 @@ __global__ void __launch_bounds__(256) Rate(float *out, float w0, float w1, int 
             for (int i = 0; i < 16; ++i) {
                 unsigned u = __float_as_uint(a[i]);
                 asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u));
+            }
+        } else if (MODE == 5) {  // v_perm_b32 (byte -> mantissa of 2^23)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                unsigned u = __float_as_uint(a[i]), r;
+                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(0x4B000000u), "s"(0x030c0c05u));
+                a[i] = __uint_as_float(r);
+            }
+        } else if (MODE == 6) {  // decode as perm + fma: (2^23 + b) * k - 2^23 * k == b * k, one rounding
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                unsigned u = __float_as_uint(a[i]), r;
+                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(0x4B000000u), "s"(0x030c0c05u));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(r), "s"(w0), "v"(w1));
+            }
+        } else if (MODE == 7) {  // decode as cvt_ubyte + mul
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                unsigned u = __float_as_uint(a[i]);
+                float t;
+                asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(t) : "v"(u));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(t), "v"(w0));
+            }
+        } else if (MODE == 8) {  // decode two channels: 2 perm + 1 pk_fma
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                unsigned u = __float_as_uint(a[i]), r0, r1;
+                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r0) : "v"(u), "v"(0x4B000000u), "s"(0x030c0c05u));
+                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r1) : "v"(u), "v"(0x4B000000u), "s"(0x030c0c06u));
+                float2v v = {__uint_as_float(r0), __uint_as_float(r1)}, ww0 = {w0, w0}, ww1 = {w1, w1};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(v), "v"(ww0), "v"(ww1));
+                a[i] = v.x; a[i + 1] = v.y;
+            }
+        } else if (MODE == 9) {  // plain v_mul only (issue rate of an independent stream)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w0));
+        } else if (MODE == 10) {  // v_pk_mul only
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                float2v v = {a[i], a[i + 1]}, ww0 = {w0, w0};
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(ww0));
+                a[i] = v.x; a[i + 1] = v.y;
             }
         } else if (MODE == 4) {  // pk_fma
 #pragma unroll
@@ -78,5 +123,11 @@ int main() {
     Run<2>("fma", 16, 16);
     Run<3>("cvt_ubyte", 16, 16);
     Run<4>("pk_fma", 8, 16);
+    Run<5>("perm", 16, 16);
+    Run<6>("perm+fma", 32, 16);
+    Run<7>("cvt+mul", 32, 16);
+    Run<8>("2perm+pkfma", 24, 16);
+    Run<9>("mul", 16, 16);
+    Run<10>("pk_mul", 8, 16);
     return 0;
 }

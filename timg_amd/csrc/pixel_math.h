@@ -46,9 +46,8 @@ __device__ __forceinline__ Px7 DecodePx(uint32_t px, int swap_rb) {
 
 __device__ __forceinline__ uint32_t ToByte(float v) {
     // stb_image_resize2.h:8415-8432 / 1391-1403: v*255 + 0.5, clamp, truncate
-    float f = v * 255.0f + 0.5f;
-    f       = f < 0.0f ? 0.0f : f;
-    f       = f > 255.0f ? 255.0f : f;
+    // (one v_med3_f32; the operands are never NaN: sums of finite products)
+    const float f = __builtin_amdgcn_fmed3f(v * 255.0f + 0.5f, 0.0f, 255.0f);
     return (uint32_t)f;
 }
 

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "context.h"
@@ -37,7 +38,14 @@ namespace {
 
 constexpr int kPix       = 4;    // source columns per lane (16-byte loads)
 constexpr int kSlots     = 5;    // output rows in flight per lane
-constexpr int kThreads   = 256;
+#ifndef TIMG_STREAM_THREADS
+#define TIMG_STREAM_THREADS 256
+#endif
+constexpr int kThreads   = TIMG_STREAM_THREADS;
+// (a workgroup of ONE wave needs no barriers: a wave's LDS operations execute in order)
+__device__ __forceinline__ void BlockSync() {
+    if (kThreads > 64) __syncthreads();
+}
 constexpr int kStripCols = kPix * kThreads;
 // staging rows in LDS: two for the 3/4-channel sets (one barrier per completed row), one
 // for the 7-channel set (a second barrier per completed row, but half the LDS: two
@@ -386,11 +394,15 @@ __device__ bool RunTile(const TileCtx &c) {
         }
         if (done) {  // wave- and block-uniform
             if (M != kFull && __any(!ok) && (tid & 63) == 0) *c.fail = 1;
-            __syncthreads();
+#ifndef TIMG_ABL_NOBARRIER
+            BlockSync();
+#endif
             if (M != kFull && *c.fail) return false;
+#ifndef TIMG_ABL_NOHORIZ
             HorizontalRow<M>(c, c.stage + (size_t)(ev & (kStage - 1)) * kStripCols * kStride, done_y, flag,
                              &ok);
-            if (kStage == 1) __syncthreads();  // the single staging row is free again
+#endif
+            if (kStage == 1) BlockSync();  // the single staging row is free again
             ++ev;
         }
         return true;
@@ -417,7 +429,7 @@ __device__ bool RunTile(const TileCtx &c) {
     }
     if (M == kFull) return true;
     if (__any(!ok) && (tid & 63) == 0) *c.fail = 1;
-    __syncthreads();
+    BlockSync();
     return *c.fail == 0;
 }
 
@@ -459,10 +471,339 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
         for (int k = 0; k < plan.h_width; ++k) c.hcoef[k * hrow + o] = in ? hc[k] : 0.0f;
     }
     if (threadIdx.x == 0) fail = 0;
-    __syncthreads();
+    BlockSync();
     if (RunTile<M>(c) && threadIdx.x == 0) tile_state[tile] = 1;
 }
 
+
+// ===================================================================================
+// Vertical-first plans, the vertical products on the matrix cores (kOpaque / kPremult).
+//
+// The vertical chain of stb is  acc = acc + d * w  with the product and the sum rounded
+// separately.  On the VALU that is a multiply and an add per (pixel, channel, output row);
+// measured (profiles/r2): the kernel above is bound by the instructions it issues, not by
+// HBM.  v_mfma_f32_4x4x1_16b_f32 with a zero accumulator delivers correctly rounded fp32
+// PRODUCTS (D = A*B + 0; checked against v_mul_f32 on 10^6 operand pairs including
+// denormals, scratch/ubench/mfma_probe.hip) as 4x4 outer products: with A = the weights of
+// four output rows (lanes 0..3, broadcast to all blocks: cbsz 4) and B = a lane's own sample,
+// every lane receives its sample times the four weights in four registers.  So the
+// multiplications of four output rows leave the VALU (the matrix pipe runs beside it), the
+// VALU keeps the additions -- as packed adds on (row 0,row 1) (row 2,row 3) accumulator
+// pairs -- and the per-row "is this slot active" branches disappear: an idle slot has
+// weight 0 and adds +0.  At most five output rows are live on a source row; the fifth
+// ("overflow") row is carried on the VALU and moves into a matrix slot as soon as one
+// completes (host-built schedule: RowCtl).
+//
+// Everything else -- strips, bands, staging rows, the horizontal even/odd gather, the
+// channel-set fallback chain -- is as in the kernel above.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+constexpr int kMSlots = 4;
+
+struct RowW {
+    float w[kMSlots];  // weights of the matrix slots on this source row (0: idle)
+};
+// flags: bit 0 overflow row active; bits 4..6: completing slot + 1 (1..4 matrix slot,
+// 5 overflow row), 0 none; bit 7: the overflow row moves into the slot that completed
+struct RowCtl {
+    float ovf_w;
+    int flags;
+    int done_y;
+    float alpha_sum;  // vertical sum of an all-opaque alpha column of the completing row
+};
+struct MTables {
+    const RowW *w;      // indexed like StreamTables::sched (BandInfo::sched + row - r0)
+    const RowCtl *ctl;
+};
+
+// Horizontal pass of a completed row, every lane its own output column(s): weights as
+// float4 groups in LDS (taps beyond a column's count have weight 0 and read staged or
+// zeroed data: acc + v * 0 leaves the sum as it is), tap k of the pair (k, k+1) feeds the
+// even / odd chain -- stb_image_resize2.h:5801-6009 as in HorizontalRow above.
+template <int M>
+__device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBlend &blend, const FrameBatch &batch,
+                                               const StripInfo &si, int f, const float *stage_row, const float *hw,
+                                               const int *hbase, int hrow, int hgroups, int y, int *flag, bool need_straight,
+                                               bool *ok) {
+    const int n_out  = si.ox1 - si.ox0;
+    uint8_t *dst_row = batch.dst + (size_t)f * batch.dst_frame_stride + (size_t)y * batch.dst_stride;
+    for (int o = threadIdx.x; o < n_out; o += kThreads) {
+        const int ox          = si.ox0 + o;
+        const char *base      = reinterpret_cast<const char *>(stage_row) + hbase[o];
+        const float *wbase    = hw + (size_t)o * 4;
+        float even[4] = {0.0f, 0.0f, 0.0f, 0.0f}, odd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (plan.h_sequential) {
+            for (int g = 0; g < hgroups; ++g) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wbase + (size_t)g * hrow * 4);
+                const float wk[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = *reinterpret_cast<const float4 *>(base + (g * 4 + j) * 16);
+                    even[0] = even[0] + t.x * wk[j];
+                    even[1] = even[1] + t.y * wk[j];
+                    even[2] = even[2] + t.z * wk[j];
+                    even[3] = even[3] + t.w * wk[j];
+                }
+            }
+        } else {
+            for (int g = 0; g < hgroups; ++g) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wbase + (size_t)g * hrow * 4);
+                const float4 t0 = *reinterpret_cast<const float4 *>(base + (g * 4 + 0) * 16);
+                const float4 t1 = *reinterpret_cast<const float4 *>(base + (g * 4 + 1) * 16);
+                const float4 t2 = *reinterpret_cast<const float4 *>(base + (g * 4 + 2) * 16);
+                const float4 t3 = *reinterpret_cast<const float4 *>(base + (g * 4 + 3) * 16);
+                even[0] = even[0] + t0.x * w4.x;
+                even[1] = even[1] + t0.y * w4.x;
+                even[2] = even[2] + t0.z * w4.x;
+                even[3] = even[3] + t0.w * w4.x;
+                odd[0]  = odd[0] + t1.x * w4.y;
+                odd[1]  = odd[1] + t1.y * w4.y;
+                odd[2]  = odd[2] + t1.z * w4.y;
+                odd[3]  = odd[3] + t1.w * w4.y;
+                even[0] = even[0] + t2.x * w4.z;
+                even[1] = even[1] + t2.y * w4.z;
+                even[2] = even[2] + t2.z * w4.z;
+                even[3] = even[3] + t2.w * w4.z;
+                odd[0]  = odd[0] + t3.x * w4.w;
+                odd[1]  = odd[1] + t3.y * w4.w;
+                odd[2]  = odd[2] + t3.z * w4.w;
+                odd[3]  = odd[3] + t3.w * w4.w;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) even[ch] = even[ch] + odd[ch];
+        }
+        Px7 px;
+        if (M == kOpaque) {  // with alpha == 1 the straight and the weighted sums coincide
+            px.c[0] = even[0];
+            px.c[1] = even[1];
+            px.c[2] = even[2];
+            px.c[3] = even[3];
+            px.c[4] = even[0];
+            px.c[5] = even[1];
+            px.c[6] = even[2];
+        } else {
+            px.c[0] = px.c[1] = px.c[2] = 0.0f;
+            px.c[3] = even[0];
+            px.c[4] = even[1];
+            px.c[5] = even[2];
+            px.c[6] = even[3];
+            // a filtered alpha below 2^-120 makes stb output the straight-filtered RGB, which
+            // this channel set does not carry -- unless the pixel is composed over the
+            // background anyway: its alpha byte is 0 and the result is the background alone
+            if (need_straight && px.c[3] < TIMG_TINY_F32) *ok = false;
+        }
+        const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, blend, flag);
+        *reinterpret_cast<uint32_t *>(dst_row + (size_t)ox * 4) = out;
+    }
+}
+
+template <int M>
+__global__ void __launch_bounds__(kThreads, 3)
+ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
+                   int *tile_state, int hrow, int hgroups) {
+    static_assert(M == kOpaque || M == kPremult, "three or four channels");
+    constexpr int kCh = M == kOpaque ? 3 : 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int fail;
+    const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tile_state[tile] != 0) return;  // uniform: whole workgroup leaves
+    const StripInfo si = LoadConstant(tab.strips + blockIdx.x);
+    const BandInfo bi  = LoadConstant(tab.bands + blockIdx.y);
+    const int f        = blockIdx.z;
+    const int tid      = threadIdx.x;
+    // LDS: two staging rows of (strip + zeroed pad for the padded taps) float4 columns, the
+    // horizontal weights as [group][output] float4, the byte offset of every output's first tap
+    const int stage_cols = kStripCols + 4 * hgroups;
+    float *stage         = lds;
+    float *hw            = stage + (size_t)2 * stage_cols * 4;
+    int *hbase           = reinterpret_cast<int *>(hw + (size_t)hgroups * hrow * 4);
+    for (int i = tid; i < 2 * 4 * hgroups; i += kThreads) {
+        const int row = i / (4 * hgroups), col = kStripCols + i % (4 * hgroups);
+        *reinterpret_cast<float4 *>(stage + ((size_t)row * stage_cols + col) * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    for (int o = tid; o < hrow; o += kThreads) {
+        const int ox  = si.ox0 + o;
+        const bool in = ox < si.ox1;
+        int2 ht       = make_int2(si.cx0, 0);
+        if (in) ht = plan.h_taps[ox];
+        hbase[o]        = (ht.x - si.cx0) * 16;
+        const float *hc = plan.h_coeff + (size_t)ox * plan.h_width;
+        for (int g = 0; g < hgroups; ++g) {
+            float w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = g * 4 + j;
+                w[j]        = (in && k < ht.y && k < plan.h_width) ? hc[k] : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(hw + ((size_t)g * hrow + o) * 4) = make_float4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    if (tid == 0) fail = 0;
+    BlockSync();
+
+    const int col0 = si.cx0 + tid * kPix;
+    // (lanes straddling or past the end of the row: see RunTile)
+    const int over          = col0 + kPix - plan.in_w;
+    const int shift         = (col0 < plan.in_w && over > 0) ? over : 0;
+    const bool any_shift    = (plan.in_w & 3) != 0 && si.cx0 + kStripCols > plan.in_w;  // uniform
+    const uint32_t lane_off = (uint32_t)min(col0, plan.in_w - kPix) * 4u;
+    const uint8_t *frame    = batch.src + (size_t)f * batch.src_frame_stride;
+    int *flag               = batch.transparent_flags ? batch.transparent_flags + f : nullptr;
+    const int r1            = bi.r1;
+    const int r_last        = min(r1, plan.in_h - 1);
+    // straight RGB of pixels with (nearly) no alpha only shows when they are not composed
+    const bool need_straight = !(blend.enabled && blend.start_row <= bi.oy0);
+    auto load_row = [&](int r) -> uint4 {
+        const uint8_t *row = frame + (size_t)min(r, r_last) * batch.src_stride;  // uniform
+        return *reinterpret_cast<const uint4 *>(row + lane_off);
+    };
+
+    f2v acc[kPix][kCh][2];  // the four matrix slots as pairs (0,1) (2,3): packed adds
+    float ovf[kPix][kCh];   // the overflow row
+#pragma unroll
+    for (int p = 0; p < kPix; ++p)
+#pragma unroll
+        for (int ch = 0; ch < kCh; ++ch) {
+            acc[p][ch][0] = acc[p][ch][1] = f2v{0.0f, 0.0f};
+            ovf[p][ch]                    = 0.0f;
+        }
+    uint32_t amin = 0xffffffffu;  // kOpaque: minimum over the pixels seen (alpha is the top byte)
+    bool ok       = true;
+    int ev        = 0;
+    int wa        = 0;  // A operand: lanes 0..3 hold the four slot weights (rewritten every row)
+
+    const RowW *wtab     = mt.w + bi.sched;
+    const RowCtl *ctab   = mt.ctl + bi.sched;
+    RowW w_next          = LoadConstant(wtab);
+    RowCtl ctl_next      = LoadConstant(ctab);
+    auto row_step = [&](const uint4 &q_in, int r) __attribute__((always_inline)) -> bool {
+        uint4 q = q_in;
+        if (any_shift && shift) {  // (one lane of the last strip of an image whose width is not a multiple of 4)
+            if (shift == 1) q = make_uint4(q.y, q.z, q.w, q.w);
+            else if (shift == 2) q = make_uint4(q.z, q.w, q.w, q.w);
+            else q = make_uint4(q.w, q.w, q.w, q.w);
+        }
+        const RowW rw    = w_next;
+        const RowCtl ctl = ctl_next;
+        asm volatile("" ::"s"(ctl.flags), "s"(rw.w[0]));  // both are complete here ...
+        __builtin_amdgcn_sched_barrier(0);
+        w_next   = LoadConstant(wtab + (r + 1 - bi.r0));  // ... before the next requests go out
+        ctl_next = LoadConstant(ctab + (r + 1 - bi.r0));
+        asm volatile("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\t"
+                     "v_writelane_b32 %0, %4, 3\n\ts_nop 3"  // (the compiler does not see this VALU write -> MFMA read hazard)
+                     : "+v"(wa)
+                     : "s"(rw.w[0]), "s"(rw.w[1]), "s"(rw.w[2]), "s"(rw.w[3]));
+        if (M == kOpaque) amin = min(min(amin, min(q.x, q.y)), min(q.z, q.w));
+        // (fully transparent pixels announce filtered alphas of zero: see RunTile)
+        if (M == kPremult && need_straight)
+            ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
+        const f4v zero  = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float waf = __int_as_float(wa);
+        const uint32_t qs[kPix] = {q.x, q.y, q.z, q.w};
+        // kBatch pixels at a time: decode, products, sums (the products' registers are the
+        // kernel's peak, so only one batch of them is in flight)
+        constexpr int kBatch = M == kOpaque ? 2 : 1;
+#pragma unroll
+        for (int p0 = 0; p0 < kPix; p0 += kBatch) {
+            if (p0) __builtin_amdgcn_sched_barrier(0);
+            float d[kBatch][kCh];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) DecodeMode<M>(qs[p0 + b], d[b]);
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)
+#pragma unroll
+                for (int ch = 0; ch < kCh; ++ch) {
+                    // (w0 d, w1 d, w2 d, w3 d), each the correctly rounded product
+                    const f4v prod    = __builtin_amdgcn_mfma_f32_4x4x1f32(waf, d[b][ch], zero, 4, 0, 0);
+                    acc[p0 + b][ch][0] = acc[p0 + b][ch][0] + f2v{prod.x, prod.y};
+                    acc[p0 + b][ch][1] = acc[p0 + b][ch][1] + f2v{prod.z, prod.w};
+                }
+            if (ctl.flags & 1) {  // wave-uniform: the overflow row
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b)
+#pragma unroll
+                    for (int ch = 0; ch < kCh; ++ch) ovf[p0 + b][ch] = ovf[p0 + b][ch] + d[b][ch] * ctl.ovf_w;
+            }
+        }
+        const int code = (ctl.flags >> 4) & 7;
+        if (code == 0) return true;  // wave- and block-uniform
+
+        // an output row is complete: its column sums go to a staging row
+        float *row = stage + (size_t)(ev & 1) * stage_cols * 4;
+        float4 *dst = reinterpret_cast<float4 *>(row + (size_t)tid * kPix * 4);
+        const bool move = (ctl.flags & 0x80) != 0;
+        auto finish_slot = [&](auto comp_tag) {
+            constexpr int C = decltype(comp_tag)::value;
+#pragma unroll
+            for (int p = 0; p < kPix; ++p) {
+                float4 v;
+                v.x = acc[p][0][C >> 1][C & 1];
+                v.y = acc[p][1][C >> 1][C & 1];
+                v.z = acc[p][2][C >> 1][C & 1];
+                v.w = kCh > 3 ? acc[p][kCh > 3 ? 3 : 0][C >> 1][C & 1] : ctl.alpha_sum;
+                dst[p] = v;
+            }
+            if (move) {  // the overflow row continues in the slot that has just been freed
+#pragma unroll
+                for (int p = 0; p < kPix; ++p)
+#pragma unroll
+                    for (int ch = 0; ch < kCh; ++ch) {
+                        acc[p][ch][C >> 1][C & 1] = ovf[p][ch];
+                        ovf[p][ch]                = 0.0f;
+                    }
+            } else {
+#pragma unroll
+                for (int p = 0; p < kPix; ++p)
+#pragma unroll
+                    for (int ch = 0; ch < kCh; ++ch) acc[p][ch][C >> 1][C & 1] = 0.0f;
+            }
+        };
+        if (code == 1) finish_slot(std::integral_constant<int, 0>());
+        else if (code == 2) finish_slot(std::integral_constant<int, 1>());
+        else if (code == 3) finish_slot(std::integral_constant<int, 2>());
+        else if (code == 4) finish_slot(std::integral_constant<int, 3>());
+        else {
+#pragma unroll
+            for (int p = 0; p < kPix; ++p) {
+                float4 v;
+                v.x = ovf[p][0];
+                v.y = ovf[p][1];
+                v.z = ovf[p][2];
+                v.w = kCh > 3 ? ovf[p][kCh > 3 ? 3 : 0] : ctl.alpha_sum;
+                dst[p] = v;
+#pragma unroll
+                for (int ch = 0; ch < kCh; ++ch) ovf[p][ch] = 0.0f;
+            }
+        }
+        if (M == kOpaque) ok = (amin >> 24) == 0xffu;
+        if (__any(!ok) && (tid & 63) == 0) fail = 1;
+        BlockSync();
+        if (fail) return false;
+        HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
+        ++ev;
+        return true;
+    };
+
+    static_assert(kPrefetch == 4, "the register ring below is written out for 4 rows");
+    uint4 q0 = load_row(bi.r0), q1 = load_row(bi.r0 + 1), q2 = load_row(bi.r0 + 2), q3 = load_row(bi.r0 + 3);
+    for (int r = bi.r0; r <= r1; r += kPrefetch) {
+        if (!row_step(q0, r)) return;
+        q0 = load_row(r + 4);
+        if (r + 1 > r1) break;
+        if (!row_step(q1, r + 1)) return;
+        q1 = load_row(r + 5);
+        if (r + 2 > r1) break;
+        if (!row_step(q2, r + 2)) return;
+        q2 = load_row(r + 6);
+        if (r + 3 > r1) break;
+        if (!row_step(q3, r + 3)) return;
+        q3 = load_row(r + 7);
+    }
+    if (M == kOpaque) ok = ok && (amin >> 24) == 0xffu;
+    if (__any(!ok) && (tid & 63) == 0) fail = 1;
+    BlockSync();
+    if (fail == 0 && tid == 0) tile_state[tile] = 1;
+}
 
 // ===================================================================================
 // Horizontal-first plans (what stb picks e.g. for 8K -> 800x450 and 640x480 -> 67x50):
@@ -724,6 +1065,8 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
 struct StreamVariant {
     void *device   = nullptr;
     StreamTables t = {};
+    MTables m      = {};     // matrix-slot schedule (ScaleStreamMKernel), same indexing as t.sched
+    bool m_ok      = false;  // ... exists for this plan
     int band_rows  = 0;
 };
 
@@ -743,6 +1086,9 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
                          int band_rows, StreamVariant *out) {
     std::vector<BandInfo> bands;
     std::vector<RowSched> sched;
+    std::vector<RowW> wrows;    // matrix-slot schedule, indexed like sched
+    std::vector<RowCtl> crows;
+    bool m_ok = p.vertical_first;
     for (int oy = 0; oy < p.out_h; oy += band_rows) {
         BandInfo b;
         memset(&b, 0, sizeof(b));
@@ -789,22 +1135,101 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
             e.flags[s] |= 4;
             e.alpha_sum[s] = alpha;
         }
+        // The same band for the matrix-slot kernel: four slots whose products come from one
+        // MFMA plus one overflow row on the VALU.  A row starts in a free matrix slot, or in
+        // the overflow slot when all four are taken, and moves from there into the slot of
+        // the next row that completes.
+        {
+            RowW wblank;
+            RowCtl cblank;
+            memset(&wblank, 0, sizeof(wblank));
+            memset(&cblank, 0, sizeof(cblank));
+            const size_t base = wrows.size();
+            wrows.resize(base + (size_t)(b.r1 - b.r0 + 1), wblank);
+            crows.resize(base + (size_t)(b.r1 - b.r0 + 1), cblank);
+            int slot_y[kMSlots + 1];
+            for (int &v : slot_y) v = -1;
+            int next_y = b.oy0;
+            for (int r = b.r0; r <= b.r1 && m_ok; ++r) {
+                RowW &we   = wrows[base + (size_t)(r - b.r0)];
+                RowCtl &ce = crows[base + (size_t)(r - b.r0)];
+                while (next_y < b.oy1 && first[next_y] <= r) {
+                    int k = 0;
+                    while (k <= kMSlots && slot_y[k] >= 0) ++k;
+                    if (k > kMSlots) {
+                        m_ok = false;
+                        break;
+                    }
+                    slot_y[k] = next_y++;
+                }
+                for (int k = 0; k <= kMSlots && m_ok; ++k) {
+                    const int y = slot_y[k];
+                    if (y < 0) continue;
+                    const VRun &run = p.v_runs[y];
+                    float w         = 0.0f;  // (past the row's last tap: the virtual tap of weight 0)
+                    for (int j = 0; j < run.count; ++j)
+                        if (p.v_rows[run.first + j] == r) w = p.v_coeff[run.first + j];
+                    if (k < kMSlots) {
+                        we.w[k] = w;
+                    } else {
+                        ce.ovf_w = w;
+                        ce.flags |= 1;
+                    }
+                }
+                for (int k = 0; k <= kMSlots && m_ok; ++k) {
+                    const int y = slot_y[k];
+                    if (y < 0 || comp[y - b.oy0] != r) continue;
+                    if (ce.flags & 0x70) {  // (never: comp[] is strictly increasing)
+                        m_ok = false;
+                        break;
+                    }
+                    const VRun &run = p.v_runs[y];
+                    float alpha     = 0.0f;
+                    for (int j = 0; j < run.count; ++j) {
+                        const float w = p.v_coeff[run.first + j];
+                        alpha         = j == 0 ? 1.0f * w : alpha + 1.0f * w;
+                    }
+                    ce.flags |= (k + 1) << 4;
+                    ce.done_y    = y;
+                    ce.alpha_sum = alpha;
+                    slot_y[k]    = -1;
+                    if (k < kMSlots && slot_y[kMSlots] >= 0) {
+                        ce.flags |= 0x80;
+                        slot_y[k]       = slot_y[kMSlots];
+                        slot_y[kMSlots] = -1;
+                    }
+                }
+            }
+            for (int v : slot_y)
+                if (v >= 0) m_ok = false;  // (every row of the band completes inside the band)
+            if (next_y != b.oy1) m_ok = false;
+        }
         bands.push_back(b);
     }
     {
         RowSched blank;  // row_step reads one entry ahead
         memset(&blank, 0, sizeof(blank));
         sched.push_back(blank);
+        RowW wblank;
+        RowCtl cblank;
+        memset(&wblank, 0, sizeof(wblank));
+        memset(&cblank, 0, sizeof(cblank));
+        wrows.push_back(wblank);
+        crows.push_back(cblank);
     }
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_strips = 0;
     const size_t o_bands  = align(o_strips + strips.size() * sizeof(StripInfo));
     const size_t o_sched  = align(o_bands + bands.size() * sizeof(BandInfo));
-    const size_t total    = align(o_sched + sched.size() * sizeof(RowSched));
+    const size_t o_wrows  = align(o_sched + sched.size() * sizeof(RowSched));
+    const size_t o_crows  = align(o_wrows + wrows.size() * sizeof(RowW));
+    const size_t total    = align(o_crows + crows.size() * sizeof(RowCtl));
     std::vector<char> host(total, 0);
     memcpy(&host[o_strips], strips.data(), strips.size() * sizeof(StripInfo));
     memcpy(&host[o_bands], bands.data(), bands.size() * sizeof(BandInfo));
     memcpy(&host[o_sched], sched.data(), sched.size() * sizeof(RowSched));
+    memcpy(&host[o_wrows], wrows.data(), wrows.size() * sizeof(RowW));
+    memcpy(&host[o_crows], crows.data(), crows.size() * sizeof(RowCtl));
     void *dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) return false;
     if (hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -817,6 +1242,9 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     out->t.sched    = (const RowSched *)((char *)dev + o_sched);
     out->t.n_strips = (int)strips.size();
     out->t.n_bands  = (int)bands.size();
+    out->m.w        = (const RowW *)((char *)dev + o_wrows);
+    out->m.ctl      = (const RowCtl *)((char *)dev + o_crows);
+    out->m_ok       = m_ok && wrows.size() == sched.size();
     out->band_rows  = band_rows;
     return true;
 }
@@ -918,6 +1346,7 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
         return no("uploading the schedule failed");
     }
     s->stream_tables = ss;
+    if (const char *e = getenv("TIMG_HIP_NO_MATRIX")) s->stream_cfg[4] = atoi(e) != 0;  // tuning: all-VALU kernels
     s->stream_cfg[0] = ss->v[0].t.n_strips;
     s->stream_cfg[1] = ss->v[0].t.n_bands;
     s->stream_cfg[2] = ss->v[1].t.n_bands;
@@ -950,6 +1379,25 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL(ScaleStreamKernel<M>, grid, dim3(kThreads), lds, stream, s->dev, v.t, blend,
                        batch, ss->tile_state, ss->hrow);
+    return hipGetLastError();
+}
+
+template <int M>
+static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                              const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    const int hgroups = (s->plan.h_width + 3) / 4;
+    const size_t lds  = ((size_t)2 * (kStripCols + 4 * hgroups) * 4 + (size_t)hgroups * ss->hrow * 4) * sizeof(float) +
+                       (size_t)ss->hrow * sizeof(int);
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamMKernel<M>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
+    hipLaunchKernelGGL(ScaleStreamMKernel<M>, grid, dim3(kThreads), lds, stream, s->dev, v.t, v.m, blend, batch,
+                       ss->tile_state, ss->hrow, hgroups);
     return hipGetLastError();
 }
 
@@ -1016,9 +1464,16 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
             return e;
         return LaunchModeH<kFull>(s, ss, v, blend, batch, stream);
     }
-    if (first_mode <= kOpaque && (e = LaunchMode<kOpaque>(s, ss, v, blend, batch, stream)) != hipSuccess)
+    // the three- and four-channel sets with their vertical products on the matrix cores where
+    // the plan allows (stream_cfg[4]: 1 forces the all-VALU kernels, for comparison)
+    const bool matrix = v.m_ok && s->stream_cfg[4] == 0;
+    if (first_mode <= kOpaque &&
+        (e = matrix ? LaunchModeM<kOpaque>(s, ss, v, blend, batch, stream)
+                    : LaunchMode<kOpaque>(s, ss, v, blend, batch, stream)) != hipSuccess)
         return e;
-    if (first_mode <= kPremult && (e = LaunchMode<kPremult>(s, ss, v, blend, batch, stream)) != hipSuccess)
+    if (first_mode <= kPremult &&
+        (e = matrix ? LaunchModeM<kPremult>(s, ss, v, blend, batch, stream)
+                    : LaunchMode<kPremult>(s, ss, v, blend, batch, stream)) != hipSuccess)
         return e;
     return LaunchMode<kFull>(s, ss, v, blend, batch, stream);
 }

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libtimg_hip.so")
+    # TIMG_HIP_LIB: an experiment build of the same library (scratch/build_variant.sh)
+    return os.environ.get("TIMG_HIP_LIB") or os.path.join(_HERE, "libtimg_hip.so")
 
 
 class TimgHipError(RuntimeError):

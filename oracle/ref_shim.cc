@@ -210,3 +210,66 @@ long ref_graphics_send(int kind, const uint8_t *fb, int w, int h, int level, int
 
 }  // extern "C"
 #endif  // TIMG_REF_NO_PNG
+
+#ifndef TIMG_REF_NO_SIXEL
+// ---- the REAL timg::SixelCanvas (src/sixel-canvas.cc), compiled against oracle/stub/sixel.h:
+// everything the class does itself -- pad rows, their background, cursor strings, prefix, the
+// future on the encoder pool -- is the reference's; only the six libsixel calls land in this
+// repository's restatement (parity of THOSE stays unpinned).
+#include "display-options.h"
+#include "sixel-canvas.h"
+#include "sixel.h"
+#include "term-query.h"
+#include "thread-pool.h"
+
+extern "C" {
+
+// n_sends Sends of the same frame: the first at (x, dy = 0), the others at (x, dy = -h) -- the
+// second form queues a cursor-up prefix (cell_height_for_pixels).  Returns everything that
+// reached the terminal.
+long ref_sixel_send(const uint8_t *fb, int w, int h, int x, int n_sends, int cell_x_px, int cell_y_px,
+                    int has_getter, uint32_t bg, uint32_t pattern, int pattern_size, int broken_cursor,
+                    int full_cell_jump, int lookup_mode, char *out, long cap) {
+    volatile sig_atomic_t interrupt = 0;
+    const int fd = memfd_create("sixel", 0);
+    if (fd < 0) return -1;
+    timg_stub_sixel_set_lookup_mode(lookup_mode);
+    {
+        timg::ThreadPool pool(2);  // (outlives the sequencer: ~ThreadPool drops queued work)
+        timg::BufferedWriteSequencer seq(fd, false, 4, true, interrupt);
+        timg::DisplayOptions opts;
+        opts.cell_x_px        = cell_x_px;
+        opts.cell_y_px        = cell_y_px;
+        opts.pattern_size     = pattern_size;
+        opts.bg_pattern_color = unpack(pattern);
+        if (has_getter) opts.bgcolor_getter = [bg]() { return unpack(bg); };
+        timg::SixelOptions so;
+        so.known_broken_cursor_placement = broken_cursor != 0;
+        so.full_cell_jump                = full_cell_jump != 0;
+        Framebuffer f(w, h);
+        memcpy((void *)f.begin(), fb, (size_t)w * h * 4);
+        timg::SixelCanvas canvas(&seq, &pool, so, opts);
+        for (int i = 0; i < n_sends; ++i) canvas.Send(x, i ? -h : 0, f, timg::SeqType::FrameImmediate, {});
+        seq.Flush();
+    }
+    const off_t n = lseek(fd, 0, SEEK_END);
+    long got      = -1;
+    if (n <= cap && pread(fd, out, (size_t)n, 0) == n) got = (long)n;
+    close(fd);
+    return got;
+}
+
+int ref_sixel_cell_height(int pixels, int cell_y_px, int full_cell_jump) {
+    volatile sig_atomic_t intr = 0;
+    timg::BufferedWriteSequencer seq(-1, false, 1, true, intr);
+    timg::DisplayOptions opts;
+    opts.cell_x_px = 9;
+    opts.cell_y_px = cell_y_px;
+    timg::SixelOptions so;
+    so.full_cell_jump = full_cell_jump != 0;
+    timg::SixelCanvas c(&seq, nullptr, so, opts);
+    return c.cell_height_for_pixels(pixels);
+}
+
+}  // extern "C"
+#endif  // TIMG_REF_NO_SIXEL

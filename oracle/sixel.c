@@ -406,6 +406,36 @@ static int round6(int px) { /* src/sixel-canvas.cc:91-94 */
     return px - px % 6;
 }
 
+/* What the two libsixel calls of SixelCanvas::Send produce for an RGBA8888 frame
+ * (sixel_dither_initialize + sixel_encode, src/sixel-canvas.cc:137-145): DCS q, raster
+ * attributes, palette, bands, ST -- no padding, no cursor strings.  oracle/stub/sixel.h
+ * forwards the reference's OWN sixel-canvas.cc to this function (oracle/_ref), which
+ * pins the wrapper below -- not this function -- to the reference class. */
+long oracle_libsixel_encode(const uint8_t *rgba, int w, int h, int lookup_mode, char *out, long cap) {
+    sout_t o;
+    memset(&o, 0, sizeof o);
+    o.buf = out;
+    o.cap = cap;
+    unsigned char *rgb = (unsigned char *)malloc((size_t)w * h * 3 + 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) memcpy(rgb + i * 3, rgba + i * 4, 3);
+    unsigned char pal[256 * 3];
+    int orig    = 0;
+    int ncolors = make_palette(rgb, w, h, pal, &orig);
+    int dither  = !(orig <= ncolors);
+    unsigned char *index = (unsigned char *)malloc((size_t)w * h);
+    apply_palette(rgb, w, h, pal, ncolors, dither, lookup_mode, index);
+    s_puts(&o, "\033Pq");
+    s_puts(&o, "\"1;1;");
+    s_putnum(&o, w);
+    s_putc(&o, ';');
+    s_putnum(&o, h);
+    encode_body(&o, index, w, h, pal, ncolors);
+    s_puts(&o, "\033\\");
+    free(index);
+    free(rgb);
+    return o.overflow ? -1 : o.pos;
+}
+
 long oracle_sixel_encode(const uint8_t *fb, int w, int h, int has_getter,
                          uint32_t bg, uint32_t pattern, int pw, int ph,
                          int broken_cursor, int lookup_mode, char *out,

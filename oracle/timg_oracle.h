@@ -79,6 +79,9 @@ long oracle_sixel_encode(const uint8_t *fb, int w, int h, int has_getter,
                          uint32_t bg, uint32_t pattern, int pw, int ph,
                          int broken_cursor, int lookup_mode, char *out,
                          long cap);
+/* The libsixel part alone (sixel_dither_initialize + sixel_encode of an RGBA8888 frame whose
+ * height is a multiple of 6): DCS q ... ST.  Used by oracle/stub/sixel.h. */
+long oracle_libsixel_encode(const uint8_t *rgba, int w, int h, int lookup_mode, char *out, long cap);
 /* Palette only (<=256 entries r,g,b); returns ncolors. dither_off set to 1 if
  * the image had <= 256 distinct 15-bit colours. */
 int oracle_sixel_palette(const uint8_t *rgba, int w, int h, uint8_t *pal_rgb,

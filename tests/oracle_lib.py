@@ -308,6 +308,29 @@ class Ref:
     def as_256(self, c):
         return int(self.L.ref_as_256_term_color(c_uint32(pack(c)))) & 0xFF
 
+    # ---- the real timg::SixelCanvas over oracle/stub/sixel.h (libsixel calls -> oracle/sixel.c) ----
+    def has_sixel(self):
+        return hasattr(self.L, "ref_sixel_send")
+
+    def sixel_send(self, fb, x=0, n_sends=1, cell_x_px=9, cell_y_px=18, bg=(0, 0, 0, 0), pattern=(0, 0, 0, 0),
+                   pattern_size=1, has_getter=True, broken_cursor=False, full_cell_jump=False,
+                   lookup_mode=1) -> bytes:
+        """Everything n_sends Sends of the real SixelCanvas write to the terminal: the first at
+        (x, 0), the others at (x, -height)."""
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        self.L.ref_sixel_send.restype = c_long
+        cap = (4096 + w * (h + 6) * 8) * n_sends
+        out = ctypes.create_string_buffer(cap)
+        n = self.L.ref_sixel_send(_d(fb), w, h, x, n_sends, cell_x_px, cell_y_px, int(has_getter),
+                                  c_uint32(pack(bg)), c_uint32(pack(pattern)), pattern_size, int(broken_cursor),
+                                  int(full_cell_jump), lookup_mode, out, c_long(cap))
+        assert n > 0, n
+        return out.raw[:n]
+
+    def sixel_cell_height(self, pixels, cell_y_px, full_cell_jump=False) -> int:
+        return int(self.L.ref_sixel_cell_height(pixels, cell_y_px, int(full_cell_jump)))
+
 
 class _RefCanvas:
     def __init__(self, r: Ref, quarter, upper, color256):

@@ -117,3 +117,89 @@ def test_256_colour_table(oracle, ref):
     cols = [(v, v, v, 255) for v in range(256)] + [tuple(rng.integers(0, 256, 4)) for _ in range(3000)]
     for c in cols:
         assert oracle.as_256(c) == ref.as_256(c)
+
+
+# ---- SixelCanvas::Send: the REAL class, compiled from src/sixel-canvas.cc against
+# oracle/stub/sixel.h, whose libsixel calls land in oracle/sixel.c.  What is pinned here is everything the
+# class does itself: padding to 6-row bands, the background of the pad rows only, cursor strings, the
+# prefix for x / dy, one buffer per Send.  The encoder between is the same code on both sides (unpinned).
+def _sixel_frames(rng):
+    """Frames whose sixel stream fits the reference's fixed buffer guess (1024 + w*h*5 bytes,
+    src/sixel-canvas.cc:122-123 "TODO realloc"): smooth content or few colours, not pure noise."""
+    w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+    m = rng.integers(0, 4)
+    if m == 0:
+        fb = synth.make("photo", w, h, seed=int(rng.integers(0, 1000)))
+    elif m == 1:
+        fb = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        fb[..., :3] = (fb[..., :3] // 128) * 128   # few colours: no dithering
+        fb[..., 3] = 255
+    elif m == 2:
+        fb = synth.make("alpha", w, h, seed=int(rng.integers(0, 1000)))
+    else:
+        fb = np.zeros((h, w, 4), np.uint8)
+        fb[..., 0] = np.linspace(0, 255, w, dtype=np.uint8)[None, :]
+        fb[..., 1] = np.linspace(0, 255, h, dtype=np.uint8)[:, None]
+        fb[..., 3] = 255
+    return fb
+
+
+def _fits_reference_buffer(stream, fb):
+    h, w = fb.shape[:2]
+    h6 = (h + 5) // 6 * 6
+    return len(stream) + 64 < 1024 + w * h6 * 5
+
+
+def test_sixel_canvas_send_matches_the_reference_class(oracle, ref):
+    if not ref.has_sixel():
+        pytest.skip("reference library built without the sixel canvas")
+    rng = np.random.default_rng(21)
+    checked = 0
+    for i in range(150):
+        fb = _sixel_frames(rng)
+        bg = (*rng.integers(0, 256, 3), int(rng.choice([0, 255, 255])))
+        pat = (*rng.integers(0, 256, 3), int(rng.choice([0, 255])))
+        cx = int(rng.integers(1, 12))
+        cy = int(rng.integers(2, 24))
+        psize = int(rng.integers(1, 4))
+        hg, broken = bool(rng.random() < 0.85), bool(rng.random() < 0.3)
+        mode = int(rng.integers(0, 2))
+        # the pattern cell of the pad rows: src/sixel-canvas.cc:115-118
+        want = oracle.sixel_encode(fb, bg, pat, psize * cx, psize * cy // 2, has_getter=hg,
+                                   broken_cursor=broken, lookup_mode=mode)
+        if not _fits_reference_buffer(want, fb):
+            continue
+        checked += 1
+        got = ref.sixel_send(fb, cell_x_px=cx, cell_y_px=cy, bg=bg, pattern=pat, pattern_size=psize,
+                             has_getter=hg, broken_cursor=broken, lookup_mode=mode)
+        assert got == want, (i, fb.shape, bg, pat, cx, cy, psize, hg, broken, mode)
+    assert checked > 100
+
+
+def test_sixel_canvas_cursor_prefix_and_cell_height(oracle, ref):
+    if not ref.has_sixel():
+        pytest.skip("reference library built without the sixel canvas")
+    rng = np.random.default_rng(22)
+
+    def round6(px):  # src/sixel-canvas.cc:91-94
+        px += 5
+        return px - px % 6
+
+    for _ in range(40):
+        fb = _sixel_frames(rng)
+        h = fb.shape[0]
+        cx, cy = int(rng.integers(1, 12)), int(rng.integers(2, 24))
+        x = int(rng.integers(0, 60))
+        full = bool(rng.random() < 0.5)
+        bg = (30, 30, 46, 255)
+        # src/sixel-canvas.cc:157-172
+        rows = (round6(h) - 6) // cy + 1 if full else (round6(h) + cy - 1) // cy
+        assert ref.sixel_cell_height(-h, cy, full) == -rows
+        one = oracle.sixel_encode(fb, bg, (0, 0, 0, 0), cx, cy // 2, lookup_mode=1)
+        if not _fits_reference_buffer(one, fb):
+            continue
+        right = b"\033[%dC" % (x // cx) if x // cx else b""   # src/terminal-canvas.cc:66-82
+        up = b"\033[%dA" % rows
+        want = right + one + up + right + one + up + right + one
+        got = ref.sixel_send(fb, x=x, n_sends=3, cell_x_px=cx, cell_y_px=cy, bg=bg, full_cell_jump=full)
+        assert got == want

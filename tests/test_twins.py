@@ -36,15 +36,19 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     # (includes MultiColumnRenderer from the reference driving the block canvas twin in its
     # grid mode: a row of Sends held back and encoded by one device call)
     assert "grid renderer over the block canvas twin: checked" in r.stdout
-    # (and the sixel twin's grid mode -- one batched encode per grid row -- against the twin itself)
-    assert "grid renderer over the sixel canvas twin: checked" in r.stdout
+    # the REAL SixelCanvas (src/sixel-canvas.cc over oracle/stub/sixel.h) beside the twin: pad rows,
+    # their background, cursor strings, prefix, one future per Send
+    assert "sixel canvas twin: identical to the reference class" in r.stdout
+    # the grid as src/timg.cc drives it: CursorOff / CursorOn around every image, a partial last row,
+    # sequencer->Flush() before the canvas goes, the encoder pool destroyed last -- block and sixel
+    # twins in grid mode against the reference canvases, queue lengths 4 (timg's), 9 and 2
+    assert "grid as src/timg.cc drives it" in r.stdout
     # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
     assert "kitty / iTerm2 canvas twins at --compress=0: checked" in r.stdout
-    # the sixel twin's stream: two frames, each decodable to a 200x114 raster
+    # the sixel twin's stream (variant 0): five frames, the first decodable to a 200x114 raster
     data = dump.read_bytes()
     frames = [b"\x1bP" + part.split(b"\x1b\\")[0] + b"\x1b\\" for part in data.split(b"\x1bP")[1:]]
-    assert len(frames) == 2
-    for fr in frames:
-        img, ncolors = oracle.sixel_decode(fr)
-        assert img.shape[:2] == (114, 200) and 2 <= ncolors <= 256
-        assert (img[..., 3] == 255).all()  # every pixel drawn (pad rows blended, not transparent)
+    assert len(frames) == 6
+    img, ncolors = oracle.sixel_decode(frames[0])
+    assert img.shape[:2] == (114, 200) and 2 <= ncolors <= 256
+    assert (img[..., 3] == 255).all()  # every pixel drawn (pad rows blended, not transparent)

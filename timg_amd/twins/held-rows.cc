@@ -1,0 +1,111 @@
+#include "held-rows.h"
+
+#include <algorithm>
+#include <utility>
+
+namespace timg {
+
+constexpr std::chrono::milliseconds HeldRows::kIdle;
+
+HeldRows::HeldRows(std::function<void(HeldBatch &)> encode)
+    : encode_(std::move(encode)), worker_(&HeldRows::Work, this) {}
+
+HeldRows::~HeldRows() {
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        if (have_open_) {
+            sealed_.push_back(std::move(open_));
+            open_      = HeldBatch();
+            have_open_ = false;
+        }
+        exiting_ = true;
+    }
+    wake_.notify_all();
+    worker_.join();  // (the worker empties sealed_ before it leaves)
+}
+
+int HeldRows::HoldLimit(int grid_columns, size_t sequencer_queue_len) {
+    // the writer holds the first future; behind it the queue must take the other futures of the
+    // batch and one control write (CursorOn) per image
+    const int by_queue = (int)((sequencer_queue_len + 1) / 2);
+    return std::max(1, std::min(grid_columns, by_queue));
+}
+
+std::future<OutBuffer> HeldRows::Hold(int w, int h, const uint8_t *pixels, const timg_hip_blend *pad,
+                                      HeldFrame &&frame, int limit) {
+    std::future<OutBuffer> result = frame.promise.get_future();
+    bool kick                     = false;
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        if (have_open_ && (open_.w != w || open_.h != h)) {
+            sealed_.push_back(std::move(open_));
+            open_      = HeldBatch();
+            have_open_ = false;
+            kick       = true;
+        }
+        if (!have_open_) {
+            open_.w    = w;
+            open_.h    = h;
+            have_open_ = true;
+        }
+        if (pad) open_.pad = *pad;
+        open_.pixels.insert(open_.pixels.end(), pixels, pixels + (size_t)w * h * 4);
+        open_.frames.push_back(std::move(frame));
+        deadline_ = std::chrono::steady_clock::now() + kIdle;
+        if ((int)open_.frames.size() >= limit) {
+            sealed_.push_back(std::move(open_));
+            open_      = HeldBatch();
+            have_open_ = false;
+        }
+        kick = true;  // (the worker also has to learn the new deadline)
+    }
+    if (kick) wake_.notify_all();
+    return result;
+}
+
+void HeldRows::Seal() {
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        if (!have_open_) return;
+        sealed_.push_back(std::move(open_));
+        open_      = HeldBatch();
+        have_open_ = false;
+    }
+    wake_.notify_all();
+}
+
+void HeldRows::Drain() {
+    Seal();
+    std::unique_lock<std::mutex> l(mu_);
+    idle_.wait(l, [this]() { return sealed_.empty() && !busy_; });
+}
+
+void HeldRows::Work() {
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+        if (sealed_.empty()) {
+            if (exiting_) return;
+            if (have_open_) {
+                if (wake_.wait_until(l, deadline_) == std::cv_status::timeout && have_open_ &&
+                    std::chrono::steady_clock::now() >= deadline_) {
+                    sealed_.push_back(std::move(open_));  // nothing arrived for kIdle
+                    open_      = HeldBatch();
+                    have_open_ = false;
+                }
+            } else {
+                wake_.wait(l);
+            }
+            continue;
+        }
+        HeldBatch batch = std::move(sealed_.front());
+        sealed_.pop_front();
+        busy_ = true;
+        l.unlock();
+        encode_(batch);
+        l.lock();
+        busy_ = false;
+        if (sealed_.empty()) idle_.notify_all();
+    }
+}
+
+}  // namespace timg

@@ -23,6 +23,11 @@ static int CellHeight(int pixels, int cell_y_px) {  // src/kitty-canvas.cc:236-2
     return -((-pixels + cell_y_px - 1) / cell_y_px);
 }
 
+// Room for what TerminalCanvas queues in front of a frame (cursor moves, clear screen, the
+// --title line: at most a terminal line of UTF-8); its length cannot be asked for.  (The
+// encoded size is exact, so without it a long title would not fit.)
+static constexpr size_t kPrefixBudget = 16 * 1024;
+
 namespace {
 // What both Sends share after the cursor prefix has been consumed on the calling thread: a copy
 // of the frame (it is only valid during the call), the device encode on the encoder pool, one
@@ -77,7 +82,7 @@ void HipKittyGraphicsCanvas::Send(int x, int dy, const Framebuffer &fb, SeqType 
     }
     timg_hip_ctx *ctx  = ctx_;
     const int flags    = options_.local_alpha_handling ? TIMG_HIP_GFX_RGB24 : 0;
-    const size_t cap   = 64 + timg_hip_gfx_max_bytes(fb.width(), fb.height());
+    const size_t cap   = kPrefixBudget + timg_hip_gfx_max_bytes(fb.width(), fb.height());
     char *const buffer = new char[cap];
     char *const offset = AppendPrefixToBuffer(buffer);  // must happen on this thread
     SendAsync(ctx, executor_, write_sequencer_, fb, buffer, offset, cap, seq_type, end_of_frame,
@@ -104,7 +109,7 @@ void HipITerm2GraphicsCanvas::Send(int x, int dy, const Framebuffer &fb, SeqType
     MoveCursorDX(x / options_.cell_x_px);
     timg_hip_ctx *ctx  = ctx_;
     const int flags    = options_.local_alpha_handling ? TIMG_HIP_GFX_RGB24 : 0;
-    const size_t cap   = 64 + timg_hip_gfx_max_bytes(fb.width(), fb.height());
+    const size_t cap   = kPrefixBudget + timg_hip_gfx_max_bytes(fb.width(), fb.height());
     char *const buffer = new char[cap];
     char *const offset = AppendPrefixToBuffer(buffer);  // must happen on this thread
     SendAsync(ctx, executor_, write_sequencer_, fb, buffer, offset, cap, seq_type, end_of_frame,

@@ -32,52 +32,38 @@ int HipSixelCanvas::cell_height_for_pixels(int pixels) const {  // src/sixel-can
     return -((round_to_sixel(pixels) + options_.cell_y_px - 1) / options_.cell_y_px);
 }
 
-HipSixelCanvas::~HipSixelCanvas() { Flush(); }
+// Room for what TerminalCanvas queues in front of a frame (cursor moves, clear screen, the
+// --title line: at most a terminal line of UTF-8); its length cannot be asked for.
+static constexpr size_t kPrefixBudget = 16 * 1024;
+
+HipSixelCanvas::~HipSixelCanvas() { rows_.reset(); }  // (encodes what is held, joins)
 
 void HipSixelCanvas::SetGridColumns(int columns) {
     Flush();
-    grid_columns_ = columns;
+    hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
+    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows([this](HeldBatch &b) { EncodeBatch(b); }));
 }
 
-// The held-back row: one batched encode on the encoder pool, one future per Send.
 void HipSixelCanvas::Flush() {
-    if (queue_.empty()) return;
-    const size_t n = queue_.size();
-    const std::vector<Pending> items(queue_);
-    const std::shared_ptr<std::vector<uint8_t>> pixels = queued_pixels_;
-    const int w = queued_w_, h = queued_h_;
-    const timg_hip_blend pad = queued_pad_;
-    timg_hip_ctx *ctx = ctx_;
-    const int flags   = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
-    // frames 1.. get their buffers through promises the one task fulfils
-    auto later = std::make_shared<std::vector<std::promise<OutBuffer>>>(n - 1);
-    std::vector<std::future<OutBuffer>> futures;
-    const std::function<OutBuffer()> encode_fun = [=]() {
-        const size_t slot = timg_hip_sixel_max_bytes(w, h) * 2;
-        std::vector<char> bytes(slot * n);
-        std::vector<size_t> lens(n);
-        if (timg_hip_sixel_encode(ctx, pixels->data(), w, h, 0, 0, 0, (int)n, flags, &pad, bytes.data(), slot, 0,
-                                  lens.data(), nullptr) != TIMG_HIP_OK)
-            HipFatal(ctx, "timg_hip_sixel_encode");
-        size_t first_size = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const Pending &p    = items[i];
-            const size_t prefix = (size_t)(p.offset - p.buffer);
-            if (prefix + lens[i] > p.cap) HipFatal(ctx, "sixel frame larger than its buffer");
-            memcpy(p.offset, bytes.data() + i * slot, lens[i]);
-            if (i == 0)
-                first_size = prefix + lens[i];
-            else
-                (*later)[i - 1].set_value(OutBuffer(p.buffer, prefix + lens[i]));
-        }
-        return OutBuffer(items[0].buffer, first_size);
-    };
-    futures.push_back(executor_->ExecAsync(encode_fun));
-    for (size_t i = 1; i < n; ++i) futures.push_back((*later)[i - 1].get_future());
-    for (size_t i = 0; i < n; ++i)
-        write_sequencer_->WriteBuffer(std::move(futures[i]), items[i].seq_type, items[i].end_of_frame);
-    queue_.clear();
-    queued_pixels_.reset();
+    if (rows_) rows_->Drain();
+}
+
+// A held-back row: one batched encode, every future of the row fulfilled (worker thread).
+void HipSixelCanvas::EncodeBatch(HeldBatch &batch) {
+    const size_t n    = batch.frames.size();
+    const size_t slot = timg_hip_sixel_max_bytes(batch.w, batch.h) * 2;
+    std::vector<char> bytes(slot * n);
+    std::vector<size_t> lens(n);
+    const int flags = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
+    if (timg_hip_sixel_encode(ctx_, batch.pixels.data(), batch.w, batch.h, 0, 0, 0, (int)n, flags, &batch.pad,
+                              bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
+        HipFatal(ctx_, "timg_hip_sixel_encode");
+    for (size_t i = 0; i < n; ++i) {
+        HeldFrame &f = batch.frames[i];
+        if (f.prefix + lens[i] > f.cap) HipFatal(ctx_, "sixel frame larger than its buffer");
+        memcpy(f.buffer + f.prefix, bytes.data() + i * slot, lens[i]);
+        f.promise.set_value(OutBuffer(f.buffer, f.prefix + lens[i]));
+    }
 }
 
 void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq_type,
@@ -86,8 +72,7 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     MoveCursorDX(x / options_.cell_x_px);
 
     const int w = fb_orig.width(), h = fb_orig.height();
-    const bool may_hold = grid_columns_ > 1 && seq_type == SeqType::FrameImmediate && !(have_last_x_ && x == last_x_);
-    if (!queue_.empty() && (!may_hold || w != queued_w_ || h != queued_h_)) Flush();
+    const bool may_hold = hold_limit_ > 1 && seq_type == SeqType::FrameImmediate && !(have_last_x_ && x == last_x_);
     have_last_x_ = true;
     last_x_      = x;
 
@@ -104,20 +89,21 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         pad.pattern_h = options_.pattern_size * options_.cell_y_px / 2;
         pad.start_row = h;
     }
-    const size_t cap     = 1024 + timg_hip_sixel_max_bytes(w, h) * 2;
+    const size_t cap     = kPrefixBudget + timg_hip_sixel_max_bytes(w, h) * 2;
     char *const buffer   = new char[cap];
     char *const offset   = AppendPrefixToBuffer(buffer);  // must happen on this thread
     if (may_hold) {
-        if (queue_.empty()) queued_pixels_ = std::make_shared<std::vector<uint8_t>>();
-        queued_w_   = w;
-        queued_h_   = h;
-        queued_pad_ = pad;
-        const uint8_t *src = (const uint8_t *)fb_orig.begin();
-        queued_pixels_->insert(queued_pixels_->end(), src, src + (size_t)w * h * 4);
-        queue_.push_back(Pending{buffer, offset, cap, seq_type, end_of_frame});
-        if ((int)queue_.size() >= grid_columns_) Flush();
+        HeldFrame f;
+        f.buffer = buffer;
+        f.prefix = (size_t)(offset - buffer);
+        f.cap    = cap;
+        f.x      = x;
+        f.dy     = dy;
+        write_sequencer_->WriteBuffer(rows_->Hold(w, h, (const uint8_t *)fb_orig.begin(), &pad, std::move(f), hold_limit_),
+                                      seq_type, end_of_frame);
         return;
     }
+    if (rows_) rows_->Seal();  // (a row in progress ends here; its futures are already queued in front of this one)
     // The framebuffer is only valid during this call: copy before going async.
     auto pixels = std::make_shared<std::vector<uint8_t>>((size_t)w * h * 4);
     memcpy(pixels->data(), fb_orig.begin(), pixels->size());

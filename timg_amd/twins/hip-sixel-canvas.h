@@ -13,6 +13,7 @@
 
 #include "buffered-write-sequencer.h"
 #include "display-options.h"
+#include "held-rows.h"
 #include "term-query.h"
 #include "terminal-canvas.h"
 #include "thread-pool.h"
@@ -33,35 +34,28 @@ public:
 
     // Grid awareness.  The device encodes a BATCH of frames for little more
     // than one (64 frames of 800x450: 1.7 ms; one: 1.8 ms), but MultiColumnRenderer
-    // (src/renderer.cc:81-189) issues one Send per image.  With columns > 1 the canvas holds
-    // the still images of a grid row back -- cursor prefix consumed, frame copied, on the
-    // calling thread as always -- and encodes the row with ONE timg_hip_sixel_encode call on
-    // the encoder pool; the sequencer receives one future per Send, in Send order, and the
-    // bytes per image are those of separate Sends.  Animation frames, a Send at the position
-    // of the previous one or of another size are never held and end the row early.
+    // (src/renderer.cc:81-189) issues one Send per image.  With columns > 1 the still images of
+    // a grid row are encoded by ONE timg_hip_sixel_encode call (held-rows.h): every Send queues
+    // its future at once -- the terminal stream is byte for byte that of separate Sends,
+    // whatever else is written between them -- and the futures of a row are fulfilled together.
+    // Animation frames and a Send at the position of the previous one are encoded on their own.
     // 0 / 1: every Send is encoded on its own (default).
     void SetGridColumns(int columns);
+    // Encodes what is still held (nothing has to call this: an idle row encodes itself).
     void Flush();
 
 private:
-    struct Pending {
-        char *buffer, *offset;  // new char[]: cursor prefix in front, the frame goes to offset
-        size_t cap;
-        SeqType seq_type;
-        Duration end_of_frame;
-    };
+    void EncodeBatch(HeldBatch &batch);
+
     const DisplayOptions &options_;
     const bool full_cell_jump_;
     const bool broken_cursor_;
     ThreadPool *const executor_;
     timg_hip_ctx *const ctx_;
-    int grid_columns_ = 0;
+    int hold_limit_   = 1;
     bool have_last_x_ = false;
     int last_x_       = 0;
-    std::vector<Pending> queue_;
-    std::shared_ptr<std::vector<uint8_t>> queued_pixels_;  // the queue's frames, back to back
-    int queued_w_ = 0, queued_h_ = 0;
-    timg_hip_blend queued_pad_;
+    std::unique_ptr<HeldRows> rows_;  // (last member: its thread uses the ones above)
 };
 
 }  // namespace timg

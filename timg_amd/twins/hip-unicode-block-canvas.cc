@@ -8,6 +8,10 @@
 
 namespace timg {
 
+// Room for what TerminalCanvas queues in front of a frame (cursor moves, clear screen, the
+// --title line: at most a terminal line of UTF-8); its length cannot be asked for.
+static constexpr size_t kPrefixBudget = 16 * 1024;
+
 HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool use_quarter,
                                              bool use_upper_half_block, bool use_256_color)
     : TerminalCanvas(ws),
@@ -19,56 +23,64 @@ HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool us
 }
 
 HipUnicodeBlockCanvas::~HipUnicodeBlockCanvas() {
-    Flush();  // (before ~TerminalCanvas writes a left-over cursor prefix, src/terminal-canvas.cc:45-51)
+    rows_.reset();  // encodes what is held (before ~TerminalCanvas writes a left-over cursor prefix)
     timg_hip_block_canvas_destroy(canvas_);
 }
 
 void HipUnicodeBlockCanvas::SetGridColumns(int columns) {
     Flush();
-    grid_columns_ = columns;
+    hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
+    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows([this](HeldBatch &b) { EncodeBatch(b); }));
+}
+
+void HipUnicodeBlockCanvas::Flush() {
+    if (rows_) rows_->Drain();
 }
 
 // One Send through the stateful device canvas (which decides about the frame difference the
 // way Send does, src/unicode-block-canvas.cc:343-346) and on to the sequencer.
-void HipUnicodeBlockCanvas::SendNow(Pending p, const uint8_t *pixels, int width, int height) {
+void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, int width, int height, SeqType seq_type,
+                                    Duration end_of_frame) {
     size_t len = 0;
     if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, 0, p.buffer + p.prefix,
                                    p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_block_canvas_send");
     // nothing emitted: the reference keeps the buffer size zero, dropping the
     // cursor jump as well (:390-395)
-    write_sequencer_->WriteBuffer(OutBuffer(p.buffer, len ? p.prefix + len : 0), p.seq_type, p.end_of_frame);
+    write_sequencer_->WriteBuffer(OutBuffer(p.buffer, len ? p.prefix + len : 0), seq_type, end_of_frame);
 }
 
-void HipUnicodeBlockCanvas::Flush() {
-    if (queue_.empty()) return;
-    const size_t n = queue_.size(), frame_bytes = (size_t)queued_w_ * 4 * queued_h_;
+// A held-back row (worker thread; the caller's thread waits in Drain() before it touches the
+// device canvas again).
+void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
+    const size_t n = batch.frames.size(), frame_bytes = (size_t)batch.w * 4 * batch.h;
     // all but the last frame of the row: one launch.  They are full encodes by construction
     // (every one of them follows a Send at another x).
     if (n > 1) {
-        const size_t slot = timg_hip_block_max_bytes(queued_w_, queued_h_);
+        const size_t slot = timg_hip_block_max_bytes(batch.w, batch.h);
         std::vector<char> bytes(slot * (n - 1));
         std::vector<size_t> lens(n - 1);
         std::vector<int> xs(n - 1);
-        for (size_t i = 0; i + 1 < n; ++i) xs[i] = queue_[i].x;
-        if (timg_hip_block_encode_grid(ctx_, queued_pixels_.data(), queued_w_, queued_h_, 0, 0, 0, (int)(n - 1),
-                                       flags_, xs.data(), bytes.data(), slot, 0, lens.data(),
-                                       nullptr) != TIMG_HIP_OK)
+        for (size_t i = 0; i + 1 < n; ++i) xs[i] = batch.frames[i].x;
+        if (timg_hip_block_encode_grid(ctx_, batch.pixels.data(), batch.w, batch.h, 0, 0, 0, (int)(n - 1), flags_,
+                                       xs.data(), bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
             HipFatal(ctx_, "timg_hip_block_encode_grid");
         for (size_t i = 0; i + 1 < n; ++i) {
-            Pending &p = queue_[i];
+            HeldFrame &p = batch.frames[i];
             memcpy(p.buffer + p.prefix, bytes.data() + i * slot, lens[i]);
-            write_sequencer_->WriteBuffer(OutBuffer(p.buffer, lens[i] ? p.prefix + lens[i] : 0), p.seq_type,
-                                          p.end_of_frame);
+            p.promise.set_value(OutBuffer(p.buffer, lens[i] ? p.prefix + lens[i] : 0));
         }
     }
     // the last one through the stateful canvas, so that an animation that continues at its
     // place finds it as the previous frame; what the canvas remembers from before the row
     // is not the previous Send any more
     timg_hip_block_canvas_forget(canvas_);
-    SendNow(queue_[n - 1], queued_pixels_.data() + (n - 1) * frame_bytes, queued_w_, queued_h_);
-    queue_.clear();
-    queued_pixels_.clear();
+    HeldFrame &p = batch.frames[n - 1];
+    size_t len   = 0;
+    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, batch.pixels.data() + (n - 1) * frame_bytes, batch.w, batch.h, 0,
+                                   0, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
+        HipFatal(ctx_, "timg_hip_block_canvas_send");
+    p.promise.set_value(OutBuffer(p.buffer, len ? p.prefix + len : 0));
 }
 
 // src/unicode-block-canvas.cc:323-403.  What stays on the host is what has to:
@@ -78,31 +90,25 @@ void HipUnicodeBlockCanvas::Send(int x, int dy, const Framebuffer &fb, SeqType s
                                  Duration end_of_frame) {
     const int width = fb.width(), height = fb.height();
     // a Send at the previous position may be a frame difference: it needs its predecessor encoded
-    const bool may_hold = grid_columns_ > 1 && !(have_last_x_ && x == last_x_);
-    if (!queue_.empty() && (!may_hold || width != queued_w_ || height != queued_h_)) Flush();
+    const bool may_hold = hold_limit_ > 1 && !(have_last_x_ && x == last_x_);
     have_last_x_ = true;
     last_x_      = x;
 
     // RequestBuffers (:405-424) leaves room for the prefix in front of the frame
-    Pending p;
-    p.cap    = timg_hip_block_max_bytes(width, height) + 64;
+    HeldFrame p;
+    p.cap    = timg_hip_block_max_bytes(width, height) + kPrefixBudget;
     p.buffer = new char[p.cap];
     if (dy < 0) MoveCursorDY(cell_height_for_pixels(dy));
-    p.prefix       = (size_t)(AppendPrefixToBuffer(p.buffer) - p.buffer);
-    p.x            = x;
-    p.dy           = dy;
-    p.seq_type     = seq_type;
-    p.end_of_frame = end_of_frame;
+    p.prefix = (size_t)(AppendPrefixToBuffer(p.buffer) - p.buffer);
+    p.x      = x;
+    p.dy     = dy;
     if (!may_hold) {
-        SendNow(p, (const uint8_t *)fb.begin(), width, height);
+        if (rows_) rows_->Drain();  // (the device canvas has to have seen the row's last frame)
+        SendNow(p, (const uint8_t *)fb.begin(), width, height, seq_type, end_of_frame);
         return;
     }
-    queued_w_ = width;
-    queued_h_ = height;
-    queue_.push_back(p);
-    const uint8_t *pixels = (const uint8_t *)fb.begin();
-    queued_pixels_.insert(queued_pixels_.end(), pixels, pixels + (size_t)width * 4 * height);
-    if ((int)queue_.size() >= grid_columns_) Flush();
+    write_sequencer_->WriteBuffer(rows_->Hold(width, height, (const uint8_t *)fb.begin(), nullptr, std::move(p), hold_limit_),
+                                  seq_type, end_of_frame);
 }
 
 }  // namespace timg

@@ -7,9 +7,11 @@
 #define TIMG_AMD_TWINS_HIP_UNICODE_BLOCK_CANVAS_H
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "buffered-write-sequencer.h"
+#include "held-rows.h"
 #include "terminal-canvas.h"
 #include "timg_hip.h"
 
@@ -29,36 +31,29 @@ public:
               Duration end_of_frame) override;
 
     // Grid awareness.  MultiColumnRenderer (src/renderer.cc:81-189)
-    // issues one Send per image, each at its column's x.  With columns > 1 the canvas
-    // holds such Sends back -- cursor prefix consumed, frame copied, on the calling
-    // thread as always -- until a grid row is complete, encodes the row with ONE device
-    // call (timg_hip_block_encode_grid) and hands the buffers to the sequencer in Send
-    // order: the bytes per image are those of separate Sends.  A Send at the position of
-    // the previous one (an animation inside a cell, which needs the frame difference) or of
-    // another size ends the row early.  0 / 1: every Send is encoded at once (default).
+    // issues one Send per image, each at its column's x.  With columns > 1 the Sends of a grid
+    // row are encoded by ONE device call (timg_hip_block_encode_grid; held-rows.h): every Send
+    // queues a future at once, so the terminal stream is byte for byte that of separate Sends
+    // -- whatever else reaches the sequencer between them (CursorOn after every image) -- and
+    // the futures of a row are fulfilled together.  A Send at the position of the previous one
+    // (an animation inside a cell, which needs the frame difference) is encoded on its own.
+    // 0 / 1: every Send is encoded at once (default).
     void SetGridColumns(int columns);
-    // Encodes and hands over what is held back (also done by the destructor).
+    // Encodes what is still held (nothing has to call this: an idle row encodes itself).
     void Flush();
 
 private:
-    struct Pending {
-        char *buffer;   // new char[]: cursor prefix in front, room for the frame behind it
-        size_t prefix, cap;
-        int x, dy;
-        SeqType seq_type;
-        Duration end_of_frame;
-    };
-    void SendNow(Pending p, const uint8_t *pixels, int width, int height);
+    void SendNow(HeldFrame &p, const uint8_t *pixels, int width, int height, SeqType seq_type,
+                 Duration end_of_frame);
+    void EncodeBatch(HeldBatch &batch);
 
     timg_hip_ctx *const ctx_;
     const int flags_;
     timg_hip_block_canvas *canvas_ = nullptr;
-    int grid_columns_ = 0;
+    int hold_limit_   = 1;
     bool have_last_x_ = false;
     int last_x_       = 0;  // x of the previous Send
-    std::vector<Pending> queue_;
-    std::vector<uint8_t> queued_pixels_;  // the queue's frames, back to back
-    int queued_w_ = 0, queued_h_ = 0;
+    std::unique_ptr<HeldRows> rows_;  // (last member: its thread uses the ones above)
 };
 
 }  // namespace timg

@@ -28,6 +28,8 @@
 #include "iterm2-canvas.h"
 #include "kitty-canvas.h"
 #include "renderer.h"
+#include "sixel-canvas.h"
+#include "sixel.h"
 #include "thread-pool.h"
 #include "unicode-block-canvas.h"
 
@@ -214,71 +216,108 @@ static void CheckGridRenderer() {
     fflush(stdout);
 }
 
+// The REAL SixelCanvas (src/sixel-canvas.cc compiled against oracle/stub/sixel.h, whose libsixel
+// calls land in the oracle's restatement with the lookup the device implements) beside the twin:
+// everything the class does itself -- pad rows and their background, cursor strings, prefix,
+// one future per Send -- is the reference's own code.
 static void CheckSixelCanvas(const char *dump_path) {
-    volatile sig_atomic_t intr = 0;
-    const int fd = memfd_create("six", 0);
-    {
-        // the pool must outlive the sequencer: ~ThreadPool drops queued work, and the
-        // sequencer's final flush would wait for those futures forever (timg.cc keeps the
-        // same order: the encoder pool is deleted after the sequencer has been flushed)
-        ThreadPool pool(2);
-        BufferedWriteSequencer seq(fd, false, 4, true, intr);
-        DisplayOptions opts;
-        opts.cell_x_px      = 9;
-        opts.cell_y_px      = 18;
-        opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
-        SixelOptions so;
-        HipSixelCanvas canvas(&seq, &pool, so, opts);
-        Framebuffer fb(200, 113);  // pads to 114 rows
-        Fill(&fb, 2);
-        canvas.Send(0, 0, fb, SeqType::FrameImmediate, {});
-        canvas.Send(18, -113, fb, SeqType::FrameImmediate, {});
+    timg_stub_sixel_set_lookup_mode(1);
+    std::string hip_stream;
+    for (int variant = 0; variant < 4; ++variant) {
+        std::string streams[2];
+        for (int twin = 0; twin < 2; ++twin) {
+            rng_state = 99 + variant;
+            volatile sig_atomic_t intr = 0;
+            const int fd = memfd_create("six", 0);
+            {
+                // the pool must outlive the sequencer: ~ThreadPool drops queued work, and the
+                // sequencer's final flush would wait for those futures forever (timg.cc keeps the
+                // same order: the encoder pool is deleted after the sequencer has been flushed)
+                ThreadPool pool(2);
+                BufferedWriteSequencer seq(fd, false, 4, true, intr);
+                DisplayOptions opts;
+                opts.cell_x_px      = 9;
+                opts.cell_y_px      = 18;
+                opts.pattern_size   = 1 + variant % 2;
+                opts.bg_pattern_color.r = 200; opts.bg_pattern_color.g = 190; opts.bg_pattern_color.b = 180;
+                opts.bg_pattern_color.a = variant >= 2 ? 255 : 0;
+                if (variant != 3)
+                    opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+                SixelOptions so;
+                so.known_broken_cursor_placement = variant == 1;
+                so.full_cell_jump                = variant == 2;
+                std::unique_ptr<TerminalCanvas> canvas;
+                if (twin) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
+                else canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
+                const int sizes[][2] = {{200, 113}, {64, 36}, {90, 50}, {33, 7}};  // 113, 50, 7: pad rows
+                int i = 0;
+                for (const auto &wh : sizes) {
+                    Framebuffer fb(wh[0], wh[1]);
+                    Fill(&fb, 2);
+                    canvas->Send(18 * i, i ? -wh[1] : 0, fb, SeqType::FrameImmediate, {});
+                    if (i == 1) {  // an animation at its place
+                        canvas->Send(18 * i, -wh[1], fb, SeqType::StartOfAnimation, {});
+                        rgba_t c; c.r = 250; c.g = 10; c.b = 20; c.a = 255;
+                        for (int x = 3; x < 30; ++x) fb.SetPixel(x, 5, c);
+                        canvas->Send(18 * i, -wh[1], fb, SeqType::AnimationFrame, {});
+                    }
+                    ++i;
+                }
+                canvas.reset();
+            }
+            streams[twin] = Slurp(fd);
+            close(fd);
+        }
+        CHECK(streams[0] == streams[1] && streams[0].size() > 1000 && streams[0].find("\033P") != std::string::npos,
+              "sixel canvas variant %d: %zu (reference class) vs %zu bytes", variant, streams[0].size(),
+              streams[1].size());
+        if (variant == 0) hip_stream = streams[1];
     }
-    const std::string s = Slurp(fd);
-    CHECK(s.size() > 1000 && s.find("\033P") != std::string::npos && s.find("\033\\") != std::string::npos,
-          "sixel canvas output malformed (%zu bytes)", s.size());
     if (dump_path) {
         FILE *f = fopen(dump_path, "wb");
         if (f) {
-            fwrite(s.data(), 1, s.size(), f);
+            fwrite(hip_stream.data(), 1, hip_stream.size(), f);
             fclose(f);
         }
     }
-    close(fd);
-    printf("sixel canvas twin: %zu bytes\n", s.size());
+    printf("sixel canvas twin: identical to the reference class (%zu bytes)\n", hip_stream.size());
+    fflush(stdout);
 }
 
-// No reference class to compare with (libsixel is absent), so the sixel twin's grid mode is
-// checked against the twin itself: the reference's MultiColumnRenderer drives one canvas that
-// encodes every Send on its own and one that holds grid rows back; the streams must be equal.
-static void CheckSixelGrid() {
-    std::string streams[2];
-    for (int mode = 0; mode < 2; ++mode) {
-        rng_state = 777;
-        volatile sig_atomic_t intr = 0;
-        const int fd = memfd_create("six", 0);
+// The grid as src/timg.cc drives it (PresentImages, :311-396): the reference's MultiColumnRenderer,
+// CursorOff before and CursorOn after every image, a last row that stays incomplete,
+// sequencer->Flush() while the canvas is still alive, then renderer, canvas and the encoder pool
+// destroyed in that order.  The reference canvas encodes every Send on its own; the twin holds
+// grid rows back (SetGridColumns) -- the two terminal streams must not differ in a byte.
+template <class MakeCanvas>
+static std::string RunGridLikeTimg(int fd, size_t queue_len, int columns, bool sixel, MakeCanvas make) {
+    rng_state = 777;
+    volatile sig_atomic_t intr = 0;
+    {
+        BufferedWriteSequencer seq(fd, false, queue_len, true, intr);
+        std::unique_ptr<ThreadPool> pool(new ThreadPool(queue_len + 1));  // (src/timg.cc:321-337)
+        DisplayOptions opts;
+        opts.cell_x_px      = sixel ? 9 : 1;
+        opts.cell_y_px      = sixel ? 18 : 2;
+        opts.width          = sixel ? 126 : 104;  // the column's width in pixels
+        opts.height         = sixel ? 90 : 60;
+        opts.show_title     = true;
+        opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+        std::unique_ptr<TerminalCanvas> canvas(make(&seq, pool.get(), opts));
         {
-            ThreadPool pool(2);  // (outlives the sequencer, see above)
-            BufferedWriteSequencer seq(fd, false, 4, true, intr);
-            DisplayOptions opts;
-            opts.cell_x_px      = 9;
-            opts.cell_y_px      = 18;
-            opts.width          = 126;  // the column's width in pixels
-            opts.height         = 90;
-            opts.show_title     = true;
-            opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
-            SixelOptions so;
-            HipSixelCanvas canvas(&seq, &pool, so, opts);
-            const int columns = 3;
-            if (mode == 1) canvas.SetGridColumns(columns);
-            auto renderer = Renderer::Create(&canvas, opts, columns, 3, Duration(), Duration());
-            for (int i = 0; i < 8; ++i) {
-                const int w = i == 4 ? 90 : 120, h = i == 4 ? 50 : 85;  // (85 pads to 90 rows)
+            auto renderer = Renderer::Create(canvas.get(), opts, columns, 3, Duration(), Duration());
+            const int n_images = 2 * columns + columns / 2 + 1;  // the last row stays incomplete
+            for (int i = 0; i < n_images; ++i) {
+                const bool small = i == columns + 1;
+                const int w = sixel ? (small ? 90 : 120) : (small ? 61 : 100);
+                const int h = sixel ? (small ? 50 : 85) : (small ? 39 : 56);
                 Framebuffer fb(w, h);
                 Fill(&fb, i % 3);
+                canvas->CursorOff();  // before_image_show
                 auto cb = renderer->render_cb("image " + std::to_string(i));
-                cb(0, 0, fb, i == 6 ? SeqType::StartOfAnimation : SeqType::FrameImmediate, {});
-                if (i == 6) {
+                const bool animation = i == 2;
+                cb(0, 0, fb, animation ? SeqType::StartOfAnimation : SeqType::FrameImmediate, {});
+                if (animation) {
                     for (int f = 0; f < 2; ++f) {
                         rgba_t c;
                         c.r = 250; c.g = (uint8_t)(90 * f); c.b = 20; c.a = 255;
@@ -286,14 +325,52 @@ static void CheckSixelGrid() {
                         cb(0, -h, fb, SeqType::AnimationFrame, {});
                     }
                 }
+                canvas->CursorOn();  // after_image_show
             }
+            seq.Flush();  // src/timg.cc:392 -- the canvas is still alive
+        }                 // renderer
+        canvas.reset();   // canvas
+        pool.reset();     // compression_pool: its destructor drops work that is still queued
+    }                     // (the sequencer belongs to main(): it outlives all of them)
+    return Slurp(fd);
+}
+
+static void CheckGridLikeTimg() {
+    timg_stub_sixel_set_lookup_mode(1);
+    for (int kind = 0; kind < 2; ++kind) {      // 0: block canvases, 1: sixel canvases
+        for (size_t queue_len : {4, 9, 2}) {    // 4: src/timg.cc:972; 9: a whole row of four
+            const int columns = 4;
+            std::string streams[2];
+            for (int twin = 0; twin < 2; ++twin) {
+                const int fd = memfd_create("grid", 0);
+                streams[twin] = RunGridLikeTimg(
+                    fd, queue_len, columns, kind == 1,
+                    [&](BufferedWriteSequencer *seq, ThreadPool *pool, const DisplayOptions &opts) -> TerminalCanvas * {
+                        static SixelOptions so;
+                        if (kind == 0 && !twin) return new UnicodeBlockCanvas(seq, true, false, false);
+                        if (kind == 1 && !twin) return new SixelCanvas(seq, pool, so, opts);
+                        if (kind == 0) {
+                            auto *c = new HipUnicodeBlockCanvas(seq, true, false, false);
+                            c->SetGridColumns(columns);
+                            return c;
+                        }
+                        auto *c = new HipSixelCanvas(seq, pool, so, opts);
+                        c->SetGridColumns(columns);
+                        return c;
+                    });
+                close(fd);
+            }
+            CHECK(streams[0] == streams[1] && streams[0].size() > 10000,
+                  "grid like timg.cc, %s canvases, queue %zu: %zu (reference) vs %zu bytes", kind ? "sixel" : "block",
+                  queue_len, streams[0].size(), streams[1].size());
+            // the cursor is switched on again at the very end
+            CHECK(streams[1].size() > 6 && streams[1].rfind("\033[?25h") != std::string::npos &&
+                      streams[1].rfind("\033[?25h") > streams[1].rfind("\033[?25l"),
+                  "cursor left off");
         }
-        streams[mode] = Slurp(fd);
-        close(fd);
     }
-    CHECK(streams[0] == streams[1] && streams[0].size() > 10000, "sixel grid mode: %zu vs %zu bytes",
-          streams[0].size(), streams[1].size());
-    printf("grid renderer over the sixel canvas twin: checked (%zu bytes)\n", streams[0].size());
+    printf("grid as src/timg.cc drives it (cursor writes between Sends, partial last row, Flush before the canvas "
+           "goes): twins identical to the reference canvases\n");
     fflush(stdout);
 }
 
@@ -363,7 +440,7 @@ static void CheckGraphicsCanvases() {
 }
 
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|sixelgrid|graphics] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -373,7 +450,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "block") CheckBlockCanvas();
     if (what == "all" || what == "grid") CheckGridRenderer();
     if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
-    if (what == "all" || what == "sixelgrid") CheckSixelGrid();
+    if (what == "all" || what == "sixelgrid" || what == "timggrid") CheckGridLikeTimg();
     if (what == "all" || what == "graphics") CheckGraphicsCanvases();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);

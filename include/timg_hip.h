@@ -57,6 +57,22 @@ int timg_hip_free(timg_hip_ctx *ctx, void *dev_ptr);
 int timg_hip_memcpy_h2d(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream);
 int timg_hip_memcpy_d2h(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream);
 int timg_hip_sync(timg_hip_ctx *ctx, void *stream);
+int timg_hip_memcpy_d2d(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream);
+
+/* ---- synthetic frames (the measurement plan's inputs) ---------------
+ * Not a reference interface: hzeller/timg has no frame generator.  These are the S-noise /
+ * S-photo / S-alpha RGBA8 frames the BASELINE configurations are defined on, generated in
+ * device memory (n_frames frames frame_stride bytes apart, 0 = packed; frame index
+ * first_frame + i enters the hash) so that a 2 GB batch never crosses PCIe.  Every byte is an
+ * integer function of (kind, seed, frame, x, y); timg_amd/synth.py: hash_frame is the same
+ * function on the host, so parity tests run on the benchmark's own frames.  HipRawRGBASource
+ * (timg_amd/twins) serves them to the reference's renderer under the name
+ * "synth:<kind>:<w>x<h>:<seed>[:<frame>]". */
+#define TIMG_HIP_SYNTH_NOISE 0
+#define TIMG_HIP_SYNTH_PHOTO 1
+#define TIMG_HIP_SYNTH_ALPHA 2
+int timg_hip_synth_frames(timg_hip_ctx *ctx, int kind, int w, int h, uint32_t seed, int first_frame,
+                          int n_frames, uint8_t *dst, size_t frame_stride, int dst_on_device, void *stream);
 
 /* ---- scaler: timg::ImageScaler ------------------------------------------
  * Replaces ImageScaler::Create (src/image-scaler.h:33-35, src/image-scaler.cc:

@@ -527,3 +527,25 @@ def test_gfx_golden_vectors_from_the_real_reference(hip):
         assert hip.gfx_encode("kitty", fb, w, h, rgb24=not with_alpha,
                               image_ids=[int(g[f"id{i}"])])[0] == g[f"kitty{i}"].tobytes(), i
         assert hip.gfx_encode("iterm2", fb, w, h, rgb24=not with_alpha)[0] == g[f"iterm{i}"].tobytes(), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["noise", "photo", "alpha"])
+def test_synthetic_frames_device_equals_host(hip, kind):
+    """timg_hip_synth_frames (what bench.py and HipRawRGBASource's synth: names run on) is the same
+    integer function of (kind, seed, frame, x, y) as timg_amd.synth.hash_frame."""
+    for w, h, seed, first, n in [(64, 48, 0, 0, 3), (333, 77, 9, 5, 2), (1, 1, 3, 0, 1), (3840, 2160, 1, 63, 1)]:
+        got = hip.synth_frames(kind, w, h, seed, first, n)
+        for i in range(n):
+            assert np.array_equal(got[i], synth.hash_frame(kind, w, h, seed, first + i)), (kind, w, h, seed, first + i)
+    # device-resident destination with a frame stride
+    w, h = 100, 40
+    stride = w * h * 4 + 256
+    d = hip.malloc(stride * 2)
+    hip.synth_frames(kind, w, h, 4, 10, 2, dst=d, frame_stride=stride)
+    hip.sync()
+    raw = hip.download(d, stride * 2)
+    hip.free(d)
+    for i in range(2):
+        frame = raw[i * stride:i * stride + w * h * 4].reshape(h, w, 4)
+        assert np.array_equal(frame, synth.hash_frame(kind, w, h, 4, 10 + i))

@@ -43,6 +43,9 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     # sequencer->Flush() before the canvas goes, the encoder pool destroyed last -- block and sixel
     # twins in grid mode against the reference canvases, queue lengths 4 (timg's), 9 and 2
     assert "grid as src/timg.cc drives it" in r.stdout
+    # the device-resident ImageSource twin: same pixels through QOIImageSource + reference scaler + reference
+    # canvas and through HipRawRGBASource (scaled, composed and encoded in device memory)
+    assert "device-resident image source: 6 pipelines identical" in r.stdout
     # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
     assert "kitty / iTerm2 canvas twins at --compress=0: checked" in r.stdout
     # the sixel twin's stream (variant 0): five frames, the first decodable to a 200x114 raster

@@ -133,6 +133,12 @@ int timg_hip_memcpy_d2h(timg_hip_ctx *ctx, void *dst, const void *src, size_t n,
     return TIMG_HIP_OK;
 }
 
+int timg_hip_memcpy_d2d(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream) {
+    if (!ctx) return TIMG_HIP_ERR_ARG;
+    TIMG_HIP_TRY(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, ctx->Stream(stream)));
+    return TIMG_HIP_OK;  // (asynchronous on the stream, like a kernel)
+}
+
 int timg_hip_sync(timg_hip_ctx *ctx, void *stream) {
     if (!ctx) return TIMG_HIP_ERR_ARG;
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(ctx->Stream(stream)));

@@ -70,6 +70,8 @@ def load_library():
     L.timg_hip_memcpy_h2d.argtypes = [vp, vp, vp, c_size_t, vp]
     L.timg_hip_memcpy_d2h.argtypes = [vp, vp, vp, c_size_t, vp]
     L.timg_hip_sync.argtypes = [vp, vp]
+    L.timg_hip_memcpy_d2d.argtypes = [vp, vp, vp, c_size_t, vp]
+    L.timg_hip_synth_frames.argtypes = [vp, c_int, c_int, c_int, c_uint32, c_int, c_int, vp, c_size_t, c_int, vp]
     L.timg_hip_scaler_create.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(vp)]
     L.timg_hip_scaler_destroy.argtypes = [vp]
     L.timg_hip_scaler_destroy.restype = None
@@ -223,6 +225,21 @@ class TimgHip:
 
     def sync(self, stream=None):
         self._check(self.L.timg_hip_sync(self.ctx, c_void_p(stream) if stream else None))
+
+    def synth_frames(self, kind: str, w: int, h: int, seed: int = 0, first_frame: int = 0, n_frames: int = 1,
+                     dst: int | None = None, frame_stride: int = 0, stream=None):
+        """The benchmark's synthetic frames (timg_hip_synth_frames).  dst: a device pointer (frames
+        are written there) or None (frames come back as a numpy array)."""
+        from .synth import HASH_KINDS
+        if dst is not None:
+            self._check(self.L.timg_hip_synth_frames(self.ctx, HASH_KINDS[kind], w, h, seed, first_frame, n_frames,
+                                                     c_void_p(dst), frame_stride, 1,
+                                                     c_void_p(stream) if stream else None))
+            return None
+        out = np.empty((n_frames, h, w, 4), np.uint8)
+        self._check(self.L.timg_hip_synth_frames(self.ctx, HASH_KINDS[kind], w, h, seed, first_frame, n_frames,
+                                                 c_void_p(out.ctypes.data), 0, 0, None))
+        return out
 
     # -- scaler --------------------------------------------------------------
     def scaler(self, in_w, in_h, out_w, out_h, in_fmt=0, filter=0) -> Scaler:

@@ -1,14 +1,21 @@
 #include "held-rows.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 namespace timg {
 
 constexpr std::chrono::milliseconds HeldRows::kIdle;
 
-HeldRows::HeldRows(std::function<void(HeldBatch &)> encode)
-    : encode_(std::move(encode)), worker_(&HeldRows::Work, this) {}
+HeldRows::HeldRows(timg_hip_ctx *ctx, std::function<void(HeldBatch &)> encode)
+    : ctx_(ctx), encode_(std::move(encode)), worker_(&HeldRows::Work, this) {}
+
+void HeldRows::SealLocked() {
+    sealed_.push_back(std::move(open_));
+    open_      = HeldBatch();
+    have_open_ = false;
+}
 
 HeldRows::~HeldRows() {
     {
@@ -31,35 +38,38 @@ int HeldRows::HoldLimit(int grid_columns, size_t sequencer_queue_len) {
     return std::max(1, std::min(grid_columns, by_queue));
 }
 
-std::future<OutBuffer> HeldRows::Hold(int w, int h, const uint8_t *pixels, const timg_hip_blend *pad,
+std::future<OutBuffer> HeldRows::Hold(int w, int h, const uint8_t *pixels, bool on_device, const timg_hip_blend *pad,
                                       HeldFrame &&frame, int limit) {
     std::future<OutBuffer> result = frame.promise.get_future();
-    bool kick                     = false;
+    const size_t frame_bytes      = (size_t)w * h * 4;
     {
         std::lock_guard<std::mutex> l(mu_);
-        if (have_open_ && (open_.w != w || open_.h != h)) {
-            sealed_.push_back(std::move(open_));
-            open_      = HeldBatch();
-            have_open_ = false;
-            kick       = true;
-        }
+        if (have_open_ && (open_.w != w || open_.h != h || open_.on_device != on_device)) SealLocked();
         if (!have_open_) {
-            open_.w    = w;
-            open_.h    = h;
-            have_open_ = true;
+            open_.w         = w;
+            open_.h         = h;
+            open_.on_device = on_device;
+            have_open_      = true;
+            if (on_device) {
+                void *p = nullptr;
+                if (timg_hip_malloc(ctx_, frame_bytes * (size_t)limit, &p) != TIMG_HIP_OK) abort();
+                open_.dev_pixels = (uint8_t *)p;
+            }
         }
         if (pad) open_.pad = *pad;
-        open_.pixels.insert(open_.pixels.end(), pixels, pixels + (size_t)w * h * 4);
+        if (on_device) {
+            // (on the context's stream: ordered before the encode and before the source's free)
+            if (timg_hip_memcpy_d2d(ctx_, open_.dev_pixels + open_.frames.size() * frame_bytes, pixels, frame_bytes,
+                                    nullptr) != TIMG_HIP_OK)
+                abort();
+        } else {
+            open_.pixels.insert(open_.pixels.end(), pixels, pixels + frame_bytes);
+        }
         open_.frames.push_back(std::move(frame));
         deadline_ = std::chrono::steady_clock::now() + kIdle;
-        if ((int)open_.frames.size() >= limit) {
-            sealed_.push_back(std::move(open_));
-            open_      = HeldBatch();
-            have_open_ = false;
-        }
-        kick = true;  // (the worker also has to learn the new deadline)
+        if ((int)open_.frames.size() >= limit) SealLocked();
     }
-    if (kick) wake_.notify_all();
+    wake_.notify_all();  // (the worker also has to learn the new deadline)
     return result;
 }
 
@@ -102,6 +112,7 @@ void HeldRows::Work() {
         busy_ = true;
         l.unlock();
         encode_(batch);
+        if (batch.dev_pixels) (void)timg_hip_free(ctx_, batch.dev_pixels);
         l.lock();
         busy_ = false;
         if (sealed_.empty()) idle_.notify_all();

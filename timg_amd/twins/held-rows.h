@@ -51,14 +51,19 @@ struct HeldFrame {
 struct HeldBatch {
     int w = 0, h = 0;
     timg_hip_blend pad{};          // (sixel: background of the pad rows)
-    std::vector<uint8_t> pixels;   // the frames, back to back
+    std::vector<uint8_t> pixels;   // the frames, back to back (host frames)
+    // frames that came from a device-resident source (hip-device-frames.h) are gathered back to
+    // back in device memory instead -- at once: the source may be gone when the row is encoded
+    uint8_t *dev_pixels = nullptr;
+    bool on_device      = false;
     std::vector<HeldFrame> frames;
+    const uint8_t *data() const { return on_device ? dev_pixels : pixels.data(); }
 };
 
 class HeldRows {
 public:
     // encode: runs on the worker thread; must fulfil every promise of the batch.
-    explicit HeldRows(std::function<void(HeldBatch &)> encode);
+    HeldRows(timg_hip_ctx *ctx, std::function<void(HeldBatch &)> encode);
     ~HeldRows();  // encodes what is held, then joins the worker
 
     // Largest number of Sends one device call may cover.
@@ -66,7 +71,8 @@ public:
 
     // Adds a frame to the open batch (sealing an open batch of another size first) and returns
     // the future the caller hands to the sequencer.  Seals the batch when it reaches `limit`.
-    std::future<OutBuffer> Hold(int w, int h, const uint8_t *pixels, const timg_hip_blend *pad,
+    // pixels: host memory, or device memory when on_device.
+    std::future<OutBuffer> Hold(int w, int h, const uint8_t *pixels, bool on_device, const timg_hip_blend *pad,
                                 HeldFrame &&frame, int limit);
     void Seal();   // the open batch goes to the worker now
     void Drain();  // Seal() and wait until everything handed over has been encoded
@@ -75,6 +81,8 @@ private:
     static constexpr std::chrono::milliseconds kIdle{3};
     void Work();
 
+    void SealLocked();
+    timg_hip_ctx *const ctx_;
     const std::function<void(HeldBatch &)> encode_;
     std::mutex mu_;
     std::condition_variable wake_, idle_;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "hip-context.h"
+#include "hip-device-frames.h"
 
 namespace timg {
 
@@ -23,6 +24,7 @@ HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_po
       broken_cursor_(sixel_options.known_broken_cursor_placement), executor_(thread_pool),
       ctx_(SharedHipContext()) {
     if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
+    DeviceFrameConsumerCreated();
 }
 
 int HipSixelCanvas::cell_height_for_pixels(int pixels) const {  // src/sixel-canvas.cc:157-172
@@ -36,12 +38,15 @@ int HipSixelCanvas::cell_height_for_pixels(int pixels) const {  // src/sixel-can
 // --title line: at most a terminal line of UTF-8); its length cannot be asked for.
 static constexpr size_t kPrefixBudget = 16 * 1024;
 
-HipSixelCanvas::~HipSixelCanvas() { rows_.reset(); }  // (encodes what is held, joins)
+HipSixelCanvas::~HipSixelCanvas() {
+    rows_.reset();  // (encodes what is held, joins)
+    DeviceFrameConsumerDestroyed();
+}
 
 void HipSixelCanvas::SetGridColumns(int columns) {
     Flush();
     hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
-    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows([this](HeldBatch &b) { EncodeBatch(b); }));
+    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
 }
 
 void HipSixelCanvas::Flush() {
@@ -55,7 +60,7 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch) {
     std::vector<char> bytes(slot * n);
     std::vector<size_t> lens(n);
     const int flags = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
-    if (timg_hip_sixel_encode(ctx_, batch.pixels.data(), batch.w, batch.h, 0, 0, 0, (int)n, flags, &batch.pad,
+    if (timg_hip_sixel_encode(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
                               bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_sixel_encode");
     for (size_t i = 0; i < n; ++i) {
@@ -92,6 +97,8 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     const size_t cap     = kPrefixBudget + timg_hip_sixel_max_bytes(w, h) * 2;
     char *const buffer   = new char[cap];
     char *const offset   = AppendPrefixToBuffer(buffer);  // must happen on this thread
+    // a frame of a device-resident source is encoded where it is (hip-device-frames.h)
+    const uint8_t *const device = DevicePixels(fb_orig);
     if (may_hold) {
         HeldFrame f;
         f.buffer = buffer;
@@ -99,22 +106,33 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         f.cap    = cap;
         f.x      = x;
         f.dy     = dy;
-        write_sequencer_->WriteBuffer(rows_->Hold(w, h, (const uint8_t *)fb_orig.begin(), &pad, std::move(f), hold_limit_),
+        write_sequencer_->WriteBuffer(rows_->Hold(w, h, device ? device : (const uint8_t *)fb_orig.begin(), device != nullptr,
+                                                  &pad, std::move(f), hold_limit_),
                                       seq_type, end_of_frame);
         return;
     }
     if (rows_) rows_->Seal();  // (a row in progress ends here; its futures are already queued in front of this one)
-    // The framebuffer is only valid during this call: copy before going async.
-    auto pixels = std::make_shared<std::vector<uint8_t>>((size_t)w * h * 4);
-    memcpy(pixels->data(), fb_orig.begin(), pixels->size());
-    timg_hip_ctx *ctx    = ctx_;
-    const int flags      = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
+    // The framebuffer is only valid during this call: copy before going async (device frames:
+    // a device-to-device copy on the context's stream, ordered before whatever the source does next).
+    const size_t frame_bytes = (size_t)w * h * 4;
+    auto pixels              = std::make_shared<std::vector<uint8_t>>(device ? 0 : frame_bytes);
+    uint8_t *device_copy     = nullptr;
+    timg_hip_ctx *ctx        = ctx_;
+    if (device) {
+        if (timg_hip_malloc(ctx, frame_bytes, (void **)&device_copy) != TIMG_HIP_OK ||
+            timg_hip_memcpy_d2d(ctx, device_copy, device, frame_bytes, nullptr) != TIMG_HIP_OK)
+            HipFatal(ctx, "HipSixelCanvas::Send");
+    } else {
+        memcpy(pixels->data(), fb_orig.begin(), frame_bytes);
+    }
+    const int flags = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
     const std::function<OutBuffer()> encode_fun = [=]() {
         OutBuffer out(buffer, offset - buffer);
         size_t len = 0;
-        if (timg_hip_sixel_encode(ctx, pixels->data(), w, h, 0, 0, 0, 1, flags, &pad, offset,
-                                  cap - (size_t)(offset - buffer), 0, &len, nullptr) != TIMG_HIP_OK)
+        if (timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr, 1,
+                                  flags, &pad, offset, cap - (size_t)(offset - buffer), 0, &len, nullptr) != TIMG_HIP_OK)
             HipFatal(ctx, "timg_hip_sixel_encode");
+        if (device_copy) (void)timg_hip_free(ctx, device_copy);
         out.size += len;
         return out;
     };

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "hip-context.h"
+#include "hip-device-frames.h"
 
 namespace timg {
 
@@ -20,17 +21,19 @@ HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool us
              (use_256_color ? TIMG_HIP_BLOCK_COLOR256 : 0)) {
     if (!ctx_ || timg_hip_block_canvas_create(ctx_, flags_, &canvas_) != TIMG_HIP_OK)
         HipFatal(ctx_, "HipUnicodeBlockCanvas");
+    DeviceFrameConsumerCreated();
 }
 
 HipUnicodeBlockCanvas::~HipUnicodeBlockCanvas() {
     rows_.reset();  // encodes what is held (before ~TerminalCanvas writes a left-over cursor prefix)
+    DeviceFrameConsumerDestroyed();
     timg_hip_block_canvas_destroy(canvas_);
 }
 
 void HipUnicodeBlockCanvas::SetGridColumns(int columns) {
     Flush();
     hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
-    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows([this](HeldBatch &b) { EncodeBatch(b); }));
+    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
 }
 
 void HipUnicodeBlockCanvas::Flush() {
@@ -39,10 +42,10 @@ void HipUnicodeBlockCanvas::Flush() {
 
 // One Send through the stateful device canvas (which decides about the frame difference the
 // way Send does, src/unicode-block-canvas.cc:343-346) and on to the sequencer.
-void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, int width, int height, SeqType seq_type,
-                                    Duration end_of_frame) {
+void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height,
+                                    SeqType seq_type, Duration end_of_frame) {
     size_t len = 0;
-    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, 0, p.buffer + p.prefix,
+    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, on_device, p.buffer + p.prefix,
                                    p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_block_canvas_send");
     // nothing emitted: the reference keeps the buffer size zero, dropping the
@@ -62,7 +65,7 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
         std::vector<size_t> lens(n - 1);
         std::vector<int> xs(n - 1);
         for (size_t i = 0; i + 1 < n; ++i) xs[i] = batch.frames[i].x;
-        if (timg_hip_block_encode_grid(ctx_, batch.pixels.data(), batch.w, batch.h, 0, 0, 0, (int)(n - 1), flags_,
+        if (timg_hip_block_encode_grid(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)(n - 1), flags_,
                                        xs.data(), bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
             HipFatal(ctx_, "timg_hip_block_encode_grid");
         for (size_t i = 0; i + 1 < n; ++i) {
@@ -77,8 +80,8 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
     timg_hip_block_canvas_forget(canvas_);
     HeldFrame &p = batch.frames[n - 1];
     size_t len   = 0;
-    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, batch.pixels.data() + (n - 1) * frame_bytes, batch.w, batch.h, 0,
-                                   0, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
+    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, batch.data() + (n - 1) * frame_bytes, batch.w, batch.h, 0,
+                                   batch.on_device, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_block_canvas_send");
     p.promise.set_value(OutBuffer(p.buffer, len ? p.prefix + len : 0));
 }
@@ -102,12 +105,15 @@ void HipUnicodeBlockCanvas::Send(int x, int dy, const Framebuffer &fb, SeqType s
     p.prefix = (size_t)(AppendPrefixToBuffer(p.buffer) - p.buffer);
     p.x      = x;
     p.dy     = dy;
+    // a frame of a device-resident source is encoded where it is (hip-device-frames.h)
+    const uint8_t *const device = DevicePixels(fb);
+    const uint8_t *const pixels = device ? device : (const uint8_t *)fb.begin();
     if (!may_hold) {
         if (rows_) rows_->Drain();  // (the device canvas has to have seen the row's last frame)
-        SendNow(p, (const uint8_t *)fb.begin(), width, height, seq_type, end_of_frame);
+        SendNow(p, pixels, device != nullptr, width, height, seq_type, end_of_frame);
         return;
     }
-    write_sequencer_->WriteBuffer(rows_->Hold(width, height, (const uint8_t *)fb.begin(), nullptr, std::move(p), hold_limit_),
+    write_sequencer_->WriteBuffer(rows_->Hold(width, height, pixels, device != nullptr, nullptr, std::move(p), hold_limit_),
                                   seq_type, end_of_frame);
 }
 

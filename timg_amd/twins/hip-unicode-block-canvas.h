@@ -43,7 +43,7 @@ public:
     void Flush();
 
 private:
-    void SendNow(HeldFrame &p, const uint8_t *pixels, int width, int height, SeqType seq_type,
+    void SendNow(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height, SeqType seq_type,
                  Duration end_of_frame);
     void EncodeBatch(HeldBatch &batch);
 

@@ -22,9 +22,11 @@
 #include "hip-context.h"
 #include "hip-graphics-canvas.h"
 #include "hip-image-scaler.h"
+#include "hip-raw-rgba-source.h"
 #include "hip-sixel-canvas.h"
 #include "hip-unicode-block-canvas.h"
 #include "image-scaler.h"
+#include "image-source.h"
 #include "iterm2-canvas.h"
 #include "kitty-canvas.h"
 #include "renderer.h"
@@ -32,6 +34,7 @@
 #include "sixel.h"
 #include "thread-pool.h"
 #include "unicode-block-canvas.h"
+#include "qoi.h"
 
 using namespace timg;
 
@@ -439,8 +442,114 @@ static void CheckGraphicsCanvases() {
     fflush(stdout);
 }
 
+// The device-resident ImageSource against the reference's own loader: the same
+// pixels as a .qoi file through ImageSource::Create -> QOIImageSource (memcpy, STB scaler,
+// AlphaComposeBackground on the host; src/qoi-image-source.cc:42-77) and as a .rgba file through
+// HipRawRGBASource (upload, scale + compose on the device, framebuffer handed over in device
+// memory), both through the reference's Renderer into a canvas.
+static void CheckImageSource() {
+    timg_stub_sixel_set_lookup_mode(1);
+    char dir_template[] = "/tmp/twin_src_XXXXXX";
+    const char *dir = mkdtemp(dir_template);
+    CHECK(dir != nullptr, "mkdtemp");
+    if (!dir) return;
+    int n = 0;
+    for (int mode = 0; mode < 3; ++mode) {
+        const int sw = mode == 2 ? 333 : 640, sh = mode == 2 ? 250 : 480;
+        Framebuffer src(sw, sh);
+        rng_state = 31 + mode;
+        Fill(&src, mode);
+        const std::string qoi_name = std::string(dir) + "/f" + std::to_string(mode) + ".qoi";
+        const std::string raw_name = std::string(dir) + "/f" + std::to_string(mode) + ".rgba";
+        qoi_desc desc;
+        desc.width = sw; desc.height = sh; desc.channels = 4; desc.colorspace = QOI_SRGB;
+        CHECK(qoi_write(qoi_name.c_str(), src.begin(), &desc) > 0, "qoi_write");
+        {
+            FILE *f = fopen(raw_name.c_str(), "wb");
+            const uint32_t dims[2] = {(uint32_t)sw, (uint32_t)sh};
+            fwrite("TIMGRGBA", 1, 8, f);
+            fwrite(dims, 4, 2, f);
+            fwrite(src.begin(), 4, (size_t)sw * sh, f);
+            fclose(f);
+        }
+        for (int canvas_kind = 0; canvas_kind < 2; ++canvas_kind) {  // 0: quarter blocks, 1: sixel
+            // 0: reference loader + reference canvas; 1: device source + Hip canvas (pixels stay on the
+            // device); 2: device source + reference canvas (pixels copied back for it)
+            std::string streams[3];
+            for (int path = 0; path < 3; ++path) {
+                volatile sig_atomic_t intr = 0;
+                const int fd = memfd_create("src", 0);
+                {
+                    BufferedWriteSequencer seq(fd, false, 4, true, intr);
+                    ThreadPool pool(2);
+                    DisplayOptions opts;
+                    opts.cell_x_px        = canvas_kind ? 9 : 2;
+                    opts.cell_y_px        = canvas_kind ? 18 : 2;
+                    opts.width            = canvas_kind ? 200 : 160;
+                    opts.height           = canvas_kind ? 126 : 90;
+                    opts.width_stretch    = canvas_kind ? 1.0f : 2.0f;
+                    opts.pattern_size     = 2;
+                    opts.bg_pattern_color.r = 200; opts.bg_pattern_color.g = 190; opts.bg_pattern_color.b = 180;
+                    opts.bg_pattern_color.a = 255;
+                    opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+                    static SixelOptions so;
+                    std::unique_ptr<TerminalCanvas> canvas;
+                    const bool hip_canvas = path == 1;
+                    if (canvas_kind == 0 && hip_canvas) canvas.reset(new HipUnicodeBlockCanvas(&seq, true, false, false));
+                    if (canvas_kind == 0 && !hip_canvas) canvas.reset(new UnicodeBlockCanvas(&seq, true, false, false));
+                    if (canvas_kind == 1 && hip_canvas) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
+                    if (canvas_kind == 1 && !hip_canvas) canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
+                    {
+                        auto renderer = Renderer::Create(canvas.get(), opts, 1, 1, Duration(), Duration());
+                        std::string error;
+                        std::unique_ptr<ImageSource> source(
+                            path == 0 ? ImageSource::Create(qoi_name, opts, 0, 1, true, false, &error)
+                                      : HipRawRGBASource::TryCreate(raw_name, opts, 0, 1));
+                        CHECK(source != nullptr, "image source %d for %s: %s", path, raw_name.c_str(), error.c_str());
+                        if (source) source->SendFrames(Duration(), 1, intr, renderer->render_cb(""));
+                        seq.Flush();
+                    }
+                    canvas.reset();
+                }
+                streams[path] = Slurp(fd);
+                close(fd);
+            }
+            CHECK(streams[0] == streams[1] && streams[0].size() > 1000,
+                  "device-resident source + Hip canvas, mode %d canvas %d: %zu (reference) vs %zu bytes", mode,
+                  canvas_kind, streams[0].size(), streams[1].size());
+            CHECK(streams[0] == streams[2], "device-resident source + reference canvas, mode %d canvas %d: %zu vs %zu bytes",
+                  mode, canvas_kind, streams[0].size(), streams[2].size());
+            ++n;
+        }
+        unlink(qoi_name.c_str());
+        unlink(raw_name.c_str());
+    }
+    {   // the measurement plan's frames by name: generated on the device, never on the host
+        volatile sig_atomic_t intr = 0;
+        const int fd = memfd_create("src", 0);
+        {
+            BufferedWriteSequencer seq(fd, false, 4, true, intr);
+            DisplayOptions opts;
+            opts.cell_x_px = 2; opts.cell_y_px = 2; opts.width = 160; opts.height = 90; opts.width_stretch = 2.0f;
+            HipUnicodeBlockCanvas canvas(&seq, true, false, false);
+            auto renderer = Renderer::Create(&canvas, opts, 1, 1, Duration(), Duration());
+            std::unique_ptr<ImageSource> source(HipRawRGBASource::TryCreate("synth:photo:1920x1080:5:2", opts, 0, 1));
+            CHECK(source != nullptr, "synth: source");
+            if (source) source->SendFrames(Duration(), 1, intr, renderer->render_cb(""));
+            CHECK(HipRawRGBASource::TryCreate("/no/such/file.png", opts, 0, 1) == nullptr, "foreign names are refused");
+            seq.Flush();
+        }
+        const std::string s = Slurp(fd);
+        CHECK(s.size() > 1000, "synth: source wrote %zu bytes", s.size());
+        close(fd);
+    }
+    rmdir(dir);
+    printf("device-resident image source: %d pipelines identical to QOIImageSource + reference scaler + reference canvas\n", n);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -452,6 +561,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
     if (what == "all" || what == "sixelgrid" || what == "timggrid") CheckGridLikeTimg();
     if (what == "all" || what == "graphics") CheckGraphicsCanvases();
+    if (what == "all" || what == "source") CheckImageSource();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);
         return 1;

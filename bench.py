@@ -4,17 +4,22 @@
     Mpixels/s scale+sixel-encode, 4K -> 800 px, grid = 8x8
     (+ achieved HBM GB/s of the scale+blend kernel)
 
-One "step" = one pass of the hot path over one batch of 64 synthetic 3840x2160
-RGBA frames that are already resident in HBM: scale(+alpha-compose) each to
-800x450, sixel-encode each, lengths back on the host; with N>1 ranks every
-rank runs its own 64-frame batch (weak scaling, frames are independent) and
-the variable-length outputs are gathered to rank 0 over RCCL for ordered
-emission -- the only exchange step the path has.
+One "step" = one pass of the hot path over one batch of synthetic RGBA frames that are
+already resident in HBM (generated there by timg_hip_synth_frames; timg_amd.synth.hash_frame
+is the same function on the host): scale(+alpha-compose) every frame, encode every frame,
+lengths back on the host.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 64] [--kind photo]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config metric|c2|c3|c4|c5]
 
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte
-accounting behind `roofline`.
+  metric (default)  64x 3840x2160 S-photo per GPU -> 800x450 -> sixel      weak scaling
+  c2                1x  3840x2160 -> 800x450 -> sixel                       (BASELINE config 2)
+  c3                64x 3840x2160 -> 200x56 -> quarter blocks, grid 8x8     (config 3)
+  c4                600-frame 4K stream -> sixel, frames round-robin over the GPUs, strong scaling (config 4)
+  c5                256x 7680x4320 S-alpha, checkerboard -> 800x450 -> sixel, contiguous blocks, strong (config 5)
+
+With N > 1 ranks the variable-length outputs are gathered to rank 0 over RCCL for ordered
+emission -- the only exchange step the path has.  Prints ONE JSON line (rank 0).  See DESIGN.md
+"Measurement" for the byte accounting behind `roofline`.
 """
 from __future__ import annotations
 
@@ -30,13 +35,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
+CONFIGS = {
+    # name: (frames in total or per GPU, in_w, in_h, out_w, out_h, mode, kind, scaling, round_robin, checker)
+    "metric": dict(frames=64, per_gpu=True, in_w=3840, in_h=2160, out_w=800, out_h=450, mode="sixel", kind="photo"),
+    "c2": dict(frames=1, per_gpu=True, in_w=3840, in_h=2160, out_w=800, out_h=450, mode="sixel", kind="photo"),
+    "c3": dict(frames=64, per_gpu=True, in_w=3840, in_h=2160, out_w=200, out_h=56, mode="quarter", kind="photo"),
+    "c4": dict(frames=600, per_gpu=False, round_robin=True, in_w=3840, in_h=2160, out_w=800, out_h=450,
+               mode="sixel", kind="photo"),
+    "c5": dict(frames=256, per_gpu=False, round_robin=False, in_w=7680, in_h=4320, out_w=800, out_h=450,
+               mode="sixel", kind="alpha", checker=True),
+}
+BG = (0x1E, 0x1E, 0x2E, 0xFF)
+PATTERN = (0x45, 0x47, 0x5A, 0xFF)
 
-def cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, frames, target_seconds=12.0):
-    """The reference's CPU path on the host cores, on a bounded sample of the
-    same workload: the REAL reference (oracle/_ref, hzeller/timg sources) for
-    scale + alpha-compose where it was built, the oracle's restatement for the
-    sixel encode (libsixel is not in the reference tree).  Checker code used as
-    a yardstick only."""
+
+def cpu_baseline(in_w, in_h, out_w, out_h, blend_args, cores, frames, target_seconds=12.0):
+    """The reference's CPU path on the host cores, on a bounded sample of the same workload:
+    the REAL reference (oracle/_ref, hzeller/timg sources) for scale + alpha-compose where it
+    was built, the oracle's restatement for the sixel encode (libsixel is not in the reference
+    tree).  Checker code used as a yardstick only.
+
+    `value` = end-to-end on all cores.  `stages` = the three stages timed separately on ONE
+    thread (ms per frame), `sixel_only` = the sixel stage alone on 1 / 5 (the reference's
+    encoder pool, src/timg.cc:333) / all threads, so that "x host sixel encode" can be read."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib
@@ -45,34 +66,56 @@ def cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, frames, target_seconds=12.
     cores = max(1, cores)
     distinct = [np.ascontiguousarray(f) for f in frames]  # a few of the GPU's own input frames
     scaler = ref if ref is not None else orc
+    bg, pattern, pw, ph = blend_args
 
     def work(idx_list):
         for i in idx_list:
             fb = scaler.scale(distinct[i % len(distinct)], out_w, out_h)
-            fb, _ = scaler.alpha_compose(fb, bg)
-            orc.sixel_encode(fb, bg=bg, lookup_mode=0)
+            fb, _ = scaler.alpha_compose(fb, bg, pattern, pw, ph)
+            orc.sixel_encode(fb, bg, pattern, pw, ph, lookup_mode=0)
 
-    work([0])  # warm-up
-    t1 = time.perf_counter()
-    work([0, 1])  # two frames on ONE thread: the per-core rate, for context
-    single = 2 * in_w * in_h / 1e6 / (time.perf_counter() - t1)
-
-    def run(n):
-        shards = [list(range(t, n, cores)) for t in range(cores)]
-        threads = [threading.Thread(target=work, args=(s,)) for s in shards]
+    # -- one thread, stage by stage (also the warm-up)
+    stage = {"scale": 0.0, "blend": 0.0, "sixel": 0.0}
+    scaled = []
+    n1 = 2
+    for i in range(n1):
         t0 = time.perf_counter()
-        for t in threads:
+        fb = scaler.scale(distinct[i % len(distinct)], out_w, out_h)
+        t1 = time.perf_counter()
+        fb, _ = scaler.alpha_compose(fb, bg, pattern, pw, ph)
+        t2 = time.perf_counter()
+        orc.sixel_encode(fb, bg, pattern, pw, ph, lookup_mode=0)
+        t3 = time.perf_counter()
+        stage["scale"] += t1 - t0
+        stage["blend"] += t2 - t1
+        stage["sixel"] += t3 - t2
+        scaled.append(fb)
+    single = n1 * in_w * in_h / 1e6 / sum(stage.values())
+
+    def run(fn, n, threads):
+        shards = [list(range(t, n, threads)) for t in range(threads)]
+        ts = [threading.Thread(target=fn, args=(s,)) for s in shards]
+        t0 = time.perf_counter()
+        for t in ts:
             t.start()
-        for t in threads:
+        for t in ts:
             t.join()
         return time.perf_counter() - t0
 
-    # bounded sample: one calibration round, then enough frames for ~12 s of wall time
-    # on these cores (at most 40 rounds)
-    t_round = run(cores)
+    def sixel_only(idx_list):
+        for i in idx_list:
+            orc.sixel_encode(scaled[i % len(scaled)], bg, pattern, pw, ph, lookup_mode=0)
+
+    sixel_rates = {"1": round(n1 * in_w * in_h / 1e6 / stage["sixel"], 1)}
+    for threads in sorted({min(5, cores), cores}):
+        n = threads * max(1, min(8, int(2.0 / max(stage["sixel"] / n1, 1e-3))))
+        sixel_rates[str(threads)] = round(n * in_w * in_h / 1e6 / run(sixel_only, n, threads), 1)
+
+    # bounded sample: one calibration round, then enough frames for ~target_seconds of wall time
+    t_round = run(work, cores, cores)
     rounds = max(1, min(40, int(target_seconds / max(t_round, 1e-3))))
     n_sample_frames = cores * rounds
-    dt = run(n_sample_frames)
+    dt = run(work, n_sample_frames, cores)
     mpx = n_sample_frames * in_w * in_h / 1e6 / dt
     return {
         "value": round(mpx, 2), "unit": "Mpixels/s", "cores": cores,
@@ -82,6 +125,8 @@ def cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, frames, target_seconds=12.
                    "sixel = oracle restatement of libsixel (parity unpinned)"),
         "seconds": round(dt, 3),
         "single_thread_value": round(single, 2),
+        "stages_ms_per_frame_1_thread": {k: round(v / n1 * 1e3, 2) for k, v in stage.items()},
+        "sixel_only_source_mpx_per_s_by_threads": sixel_rates,
     }
 
 
@@ -90,28 +135,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="metric", choices=sorted(CONFIGS),
+                    help="metric = BASELINE.json's metric configuration (default); c2..c5 = BASELINE configs 2..5")
     ap.add_argument("--pipelines", type=int, default=1,
                     help="independent batched streams per GPU in the timed region (1 = one batch at a time: "
                          "kernel durations are undisturbed, which the roofline object needs)")
     ap.add_argument("--batched-streams", type=int, default=3,
                     help="after the timed region, time the same K steps again on this many concurrent batched "
-                         "streams and report it as `batched_streams` (0 = skip)")
-    ap.add_argument("--frames", type=int, default=64, help="frames per rank per step (grid 8x8)")
-    ap.add_argument("--kind", default="photo", choices=["photo", "noise", "alpha"])
-    ap.add_argument("--mode", default="sixel", choices=["sixel", "quarter", "half", "kitty", "iterm2", "png"],
-                    help="canvas: sixel (the BASELINE metric), half/quarter blocks, or a graphics protocol at "
-                         "--compress=0 (kitty, iterm2; png = png::Encode alone)")
+                         "streams and report it as `batched_streams` (0 = skip; metric configuration only)")
+    ap.add_argument("--frames", type=int, default=0, help="override the configuration's frame count")
+    ap.add_argument("--chunk", type=int, default=64, help="frames per batched launch (c4, c5)")
+    ap.add_argument("--kind", default="", choices=["", "photo", "noise", "alpha"])
+    ap.add_argument("--mode", default="", choices=["", "sixel", "quarter", "half", "kitty", "iterm2", "png"],
+                    help="canvas override: sixel, half/quarter blocks, or a graphics protocol at --compress=0")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_alpha / d2h / batched_streams")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the CPU sample")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import timg_amd
-    from timg_amd.gather import gather_frames_to_root
-    from timg_amd.pipeline import GridPipeline, run_batched_streams, synth_frames_on_device
+    from timg_amd.gather import gather_frames_to_root, shard_frames
+    from timg_amd.pipeline import GridPipeline, run_batched_streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -123,27 +171,59 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    in_w, in_h, out_w, out_h = 3840, 2160, 800, 450
-    if args.mode in ("quarter", "half"):
-        out_w, out_h = 200, 56  # BASELINE config 3: grid cell of an 800-cell canvas
-    bg = (0x1E, 0x1E, 0x2E, 0xFF)
-    blend = timg_amd.Blend.make(bg)
-    # P independent batched streams ("1x MI355X batched streams", BASELINE config 3): every
-    # stream owns a context (scratch), a HIP stream and one 64-frame batch in flight; step k
-    # runs on stream k % P, driven by its own host thread.  The serial stages of the sixel
-    # canvas keep only a few dozen CUs busy, so consecutive batches overlap on the chip.
-    n_pipes = max(1, args.pipelines)
-    n_extra = max(0, args.batched_streams)
-    hips = [timg_amd.TimgHip(local_rank) for _ in range(max(n_pipes, n_extra))]
-    pipes = [GridPipeline(h, args.frames, in_w, in_h, out_w, out_h, args.mode, blend) for h in hips]
+    cfg = dict(CONFIGS[args.config])
+    if args.frames:
+        cfg["frames"] = args.frames
+    if args.kind:
+        cfg["kind"] = args.kind
+    if args.mode:
+        cfg["mode"] = args.mode
+        if args.mode in ("quarter", "half"):
+            cfg["out_w"], cfg["out_h"] = 200, 56  # grid cell of an 800-cell canvas
+    in_w, in_h, out_w, out_h, mode, kind = (cfg[k] for k in ("in_w", "in_h", "out_w", "out_h", "mode", "kind"))
+    strong = not cfg["per_gpu"]
+    # frames this rank owns (global indices: they enter the frame hash, so every frame of a
+    # sharded stream is the frame a single GPU would have produced)
+    if strong:
+        mine = shard_frames(cfg["frames"], world, rank, round_robin=cfg.get("round_robin", False))
+    else:
+        mine = list(range(rank * cfg["frames"], (rank + 1) * cfg["frames"]))
+    n_mine = len(mine)
+    chunk = n_mine if not strong else max(1, min(args.chunk, n_mine))
+    pw, ph = (18, 18) if cfg.get("checker") else (0, 0)  # -B pattern: pattern_size * cell px (9 x 18 cells)
+    blend = timg_amd.Blend.make(BG, PATTERN if cfg.get("checker") else (0, 0, 0, 0), pw, ph)
+
+    n_pipes = max(1, args.pipelines) if not strong else 1
+    n_extra = 0 if (strong or args.no_extras or args.config != "metric") else max(0, args.batched_streams)
+    hips = [timg_amd.TimgHip(local_rank) for _ in range(max(n_pipes, n_extra, 1))]
+    pipes = [GridPipeline(h, chunk, in_w, in_h, out_w, out_h, mode, blend) for h in hips]
     if args.kernel:
         for p in pipes:
             p.scaler.set_kernel(args.kernel)
     pipe = pipes[0]
-    src = synth_frames_on_device(args.frames, in_w, in_h, args.kind, seed=rank)
+
+    def make_frames(kind, indices):
+        t = torch.empty((len(indices), in_h, in_w, 4), dtype=torch.uint8, device="cuda")
+        runs, start = [], 0  # runs of consecutive frame indices -> one generator call each
+        for i in range(1, len(indices) + 1):
+            if i == len(indices) or indices[i] != indices[i - 1] + 1:
+                runs.append((start, i))
+                start = i
+        for a, b in runs:
+            hips[0].synth_frames(kind, in_w, in_h, seed=0, first_frame=indices[a], n_frames=b - a,
+                                 dst=t[a].data_ptr())
+        hips[0].sync()
+        return t
+
+    src = make_frames(kind, mine)
     torch.cuda.synchronize()
     for p in pipes:
         p.stream.wait_stream(torch.cuda.current_stream())
+    chunks = [src[i:i + chunk] for i in range(0, n_mine, chunk)]
+    if chunks and chunks[-1].shape[0] != chunk:  # a ragged tail gets its own pipeline
+        tail_pipe = GridPipeline(hips[0], chunks[-1].shape[0], in_w, in_h, out_w, out_h, mode, blend)
+    else:
+        tail_pipe = None
 
     def record(stream):
         # HIP events on the stream the kernels are launched on
@@ -152,9 +232,24 @@ def main():
         return e
 
     def run_steps(n_steps, timed_events=None, n_pipes=n_pipes):
-        """n_steps passes of the hot path, step k on stream k % P; with several ranks the
-        outputs are gathered to rank 0 in step order by this (the main) thread."""
-        run_batched_streams(pipes, src, n_steps, n_pipes, world, gather_frames_to_root, timed_events, record)
+        """n_steps passes of the hot path; with several ranks the outputs are gathered to rank 0
+        in step order by this (the main) thread."""
+        if not strong:
+            run_batched_streams(pipes, src, n_steps, n_pipes, world, gather_frames_to_root, timed_events, record)
+            return
+        for _ in range(n_steps):  # a step = the whole sharded stream, chunk by chunk
+            for c in chunks:
+                p = tail_pipe if (tail_pipe is not None and c.shape[0] != chunk) else pipe
+                e0 = record(p.stream)
+                p.scale(c)
+                e1 = record(p.stream)
+                p.encode()
+                e2 = record(p.stream)
+                if timed_events is not None:
+                    timed_events.append((e0, e1, e2))
+                if world > 1:
+                    payload, lens = p.packed_output()
+                    gather_frames_to_root(payload, lens)
 
     def timed(n_steps, n_pipes, timed_events=None):
         torch.cuda.synchronize()
@@ -176,21 +271,24 @@ def main():
     events = []
     elapsed = timed(args.steps, n_pipes, events)  # THE timed region: exactly K steps
 
+    launches_per_step = len(chunks) if strong else 1
     scale_ms = [a.elapsed_time(b) for a, b, _ in events]
     encode_ms = [b.elapsed_time(c) for _, b, c in events]
-    scale_avg_ms = sum(scale_ms) / len(scale_ms)
-    alg_bytes = pipe.scaler.algorithmic_bytes() * args.frames  # per launch (one batch)
+    sizes = [c.shape[0] for c in chunks] * args.steps if strong else [chunk] * len(events)
+    full = [s for s, n in zip(scale_ms, sizes) if n == chunk]  # (a ragged tail launch is not the roofline's launch)
+    scale_avg_ms = sum(full) / max(1, len(full))
+    alg_bytes = pipe.scaler.algorithmic_bytes() * chunk  # per launch (one full batch)
     achieved = alg_bytes / (scale_avg_ms * 1e-3) / 1e9
-    total_px = world * args.frames * in_w * in_h * args.steps
+    frames_total = cfg["frames"] if strong else world * cfg["frames"]
+    total_px = frames_total * in_w * in_h * args.steps
     value = total_px / 1e6 / elapsed
     info = pipe.scaler.info()
     out_bytes = sum(pipe.lengths)
 
+    canvas_name = {"sixel": "sixel", "quarter": "quarter-block", "half": "half-block"}.get(mode, mode + " (--compress=0)")
     result = {
-        "metric": "Mpixels/s scale+sixel-encode, 4K->800px grid=8x8" if args.mode == "sixel"
-                  else (f"Mpixels/s scale+{args.mode}-encode (--compress=0), 4K->800px grid=8x8"
-                        if args.mode in ("kitty", "iterm2", "png")
-                        else f"Mpixels/s scale+{args.mode}-block-encode, 4K->200x56 grid=8x8"),
+        "metric": "Mpixels/s scale+sixel-encode, 4K->800px grid=8x8" if args.config == "metric" and mode == "sixel"
+                  else f"Mpixels/s scale+{canvas_name}-encode, {in_w}x{in_h}->{out_w}x{out_h} ({args.config})",
         "value": round(value, 1),
         "unit": "Mpixels/s",
         "n_gpus": world,
@@ -198,24 +296,29 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": (f"{args.frames}x {in_w}x{in_h} RGBA8 S-{args.kind} frames per GPU, resident in HBM "
-                         f"-> scale+alpha-compose to {out_w}x{out_h} -> {args.mode} encode "
-                         "(BASELINE metric config: 4K->800px grid=8x8)"),
-            "frames_per_gpu": args.frames,
-            "parallelism": (f"frames sharded {world} way(s), RCCL gather of output bytes to rank 0"
-                            if world > 1 else "single GPU, batched launches") +
-                           f"; {n_pipes} batch(es) in flight per GPU",
+            "workload": (f"{args.config}: {cfg['frames']}x {in_w}x{in_h} RGBA8 S-{kind} frames "
+                         f"{'in total' if strong else 'per GPU'}, generated and resident in HBM -> scale+alpha-compose"
+                         f"{' over a checkerboard' if cfg.get('checker') else ''} to {out_w}x{out_h} -> {canvas_name} encode"
+                         + (" (BASELINE metric config: 4K->800px grid=8x8)" if args.config == "metric" else "")),
+            "frames_per_gpu": n_mine,
+            "frames_per_launch": chunk,
+            "parallelism": ((f"frames sharded {world} way(s) "
+                             f"({'round-robin' if cfg.get('round_robin') else 'contiguous blocks'}), "
+                             "RCCL gather of output bytes to rank 0" if world > 1 else "single GPU, batched launches")
+                            + f"; {n_pipes} batch(es) in flight per GPU"),
             "pipelines": n_pipes,
             "scale_kernel": "streaming" if (info["streaming_ok"] and args.kernel != 1) else "generic",
             "pass_order": "vertical-first" if info["vertical_first"] else "horizontal-first",
         },
         "roofline": {
-            "kernel": "scale+alpha-compose (reads every source byte once)",
+            "kernel": "scale+alpha-compose (reads every source byte once); "
+                      + ("all-opaque frames: the compose epilogue finds nothing to blend" if kind == "photo"
+                         else "frames with alpha: every output pixel is composed"),
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
@@ -224,19 +327,63 @@ def main():
             "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(scale_avg_ms, 4),
+            "limiter": "instruction issue (profiles/r2: SQ counters), not HBM",
         },
-        "stages_ms": {"scale_blend": round(scale_avg_ms, 3),
-                      "encode": round(sum(encode_ms) / len(encode_ms), 3)},
-        "output_bytes_per_step": out_bytes,
+        "stages_ms": {"scale_blend": round(sum(scale_ms) / args.steps, 3),
+                      "encode": round(sum(encode_ms) / args.steps, 3)},
+        "output_bytes_per_step": out_bytes * (launches_per_step if strong else 1),
     }
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(traffic_file):
         try:
             t = json.load(open(traffic_file))
-            if t.get("workload_frames") == args.frames and t.get("kernel") == result["config"]["scale_kernel"]:
+            if (t.get("workload_frames") == chunk and t.get("kernel") == result["config"]["scale_kernel"]
+                    and t.get("config", "metric") == args.config):
                 result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / "
+                                                        "WRITE_SIZE of this command in a separate run")
         except Exception:
             pass
+
+    if not args.no_extras and args.config == "metric":
+        # -- the same kernel with alpha actually present (S-alpha frames, composed over the background):
+        # its own roofline object, measured in this run
+        n_alpha = min(8, cfg["frames"])
+        src_alpha = make_frames("alpha", list(range(rank * n_alpha, (rank + 1) * n_alpha)))
+        src_alpha = src_alpha.repeat((chunk + n_alpha - 1) // n_alpha, 1, 1, 1)[:chunk].contiguous()
+        pipe.stream.wait_stream(torch.cuda.current_stream())
+        for _ in range(2):
+            pipe.scale(src_alpha)
+        evs = []
+        for _ in range(max(3, args.steps // 2)):
+            e0 = record(pipe.stream)
+            pipe.scale(src_alpha)
+            evs.append((e0, record(pipe.stream)))
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        result["roofline_alpha"] = {
+            "kernel": "scale+alpha-compose on S-alpha frames (radial alpha ramp, transparent border, 10 % special "
+                      "alphas), composed over the background",
+            "bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4),
+        }
+        del src_alpha
+
+    if not args.no_extras and not strong and mode == "sixel":
+        # -- what the timed region leaves in HBM: the escape bytes.  Ordered emission needs them on the
+        # host: the same K steps with every frame's bytes copied into pinned host memory by the encode
+        # call itself (out_on_device = 0: one copy of `length` bytes per frame, not overlapped).
+        pinned = torch.empty(pipe.cap * chunk, dtype=torch.uint8).pin_memory()
+        host_out = pinned.numpy()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            pipe.scale(src)
+            hips[0].sixel_encode(pipe.scaled.data_ptr(), out_w, out_h, pad_blend=blend, n_frames=chunk,
+                                 out=host_out, out_cap=pipe.cap, stream=pipe.stream_ptr())
+        torch.cuda.synchronize()
+        result["ms_per_step_with_d2h"] = round((time.perf_counter() - t0) / args.steps * 1e3, 3)
 
     if n_extra > 1:
         # Same K steps on n_extra concurrent batched streams (extra information, outside the
@@ -248,19 +395,26 @@ def main():
         dt = timed(k_extra, n_extra)
         result["batched_streams"] = {
             "streams": n_extra, "steps": k_extra, "ms_per_step": round(dt / k_extra * 1e3, 3),
-            "value": round(world * args.frames * in_w * in_h * k_extra / 1e6 / dt, 1), "unit": "Mpixels/s",
+            "value": round(world * cfg["frames"] * in_w * in_h * k_extra / 1e6 / dt, 1), "unit": "Mpixels/s",
             "note": "same workload, batches on independent streams overlap; not the contract's timed region",
         }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and mode == "sixel":
         cores = args.cpu_threads or (os.cpu_count() or 1)
-        host_frames = src[:min(4, args.frames)].cpu().numpy()
-        result["cpu_baseline"] = cpu_baseline(in_w, in_h, out_w, out_h, bg, cores, host_frames,
-                                              args.cpu_seconds) if args.mode == "sixel" else None
+        host_frames = src[:min(4, n_mine)].cpu().numpy()
+        result["cpu_baseline"] = cpu_baseline(in_w, in_h, out_w, out_h, (BG, PATTERN if cfg.get("checker") else (0, 0, 0, 0), pw, ph),
+                                              cores, host_frames, args.cpu_seconds)
+        cb = result["cpu_baseline"]
+        gpu_sixel_mpx = chunk * in_w * in_h / 1e6 / (sum(encode_ms) / len(encode_ms) * 1e-3)
+        cb["gpu_sixel_stage_source_mpx_per_s"] = round(gpu_sixel_mpx, 1)
+        cb["gpu_over_host_sixel_encode"] = {k: round(gpu_sixel_mpx / v, 1) for k, v in
+                                            cb["sixel_only_source_mpx_per_s_by_threads"].items()}
     if rank == 0:
         print(json.dumps(result), flush=True)
     for p in pipes:
         p.close()
+    if tail_pipe is not None:
+        tail_pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

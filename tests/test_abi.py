@@ -26,6 +26,31 @@ def test_every_declared_symbol_is_exported():
         assert hasattr(lib, n), f"{n} declared in include/timg_hip.h but not exported"
 
 
+def test_comm_library_exports_its_header_and_shards_like_the_python_path():
+    """include/timg_hip_comm.h (the RCCL gather, its own library): every declared symbol is exported;
+    the frame -> (rank, index) arithmetic the C++ writer uses is the inverse of shard_frames."""
+    from timg_amd import comm
+    from timg_amd.gather import shard_frames
+    text = open(os.path.join(ROOT, "include", "timg_hip_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(timg_hip_[a-z0-9_]+)\s*\(", text)))
+    lib = comm.load_comm_library()
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(lib, n), n
+    for n_total, world in [(600, 8), (256, 8), (12, 4), (7, 3), (5, 8), (1, 1), (64, 2)]:
+        for rr in (False, True):
+            owned = [shard_frames(n_total, world, r, round_robin=rr) for r in range(world)]
+            for r in range(world):
+                assert comm.shard_count(n_total, world, rr, r) == len(owned[r])
+            for f in range(n_total):
+                r, i = comm.shard_locate(n_total, world, rr, f)
+                assert owned[r][i] == f, (n_total, world, rr, f)
+    # no communicator without a usable device / peer: errors are reported, nothing crashes
+    assert lib.timg_hip_comm_create(0, 0, 0, None, None) == -1
+    lib.timg_hip_comm_destroy(None)
+
+
 def test_version_and_buffer_size_rules(oracle):
     lib = timg_amd.load_library()
     assert lib.timg_hip_version() >> 16 == 1
@@ -71,6 +96,27 @@ def test_header_is_valid_c99():
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I",
                         os.path.join(ROOT, "include"), "-x", "c", "-"], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_gather_through_the_c_abi_world_1(hip):
+    """timg_hip_gather_to_root with one rank (all this box has): the same calls a multi-GPU job makes --
+    ncclCommInitRank, ncclAllGather of the lengths, the payload hand-over -- in a process that also holds
+    torch's HIP runtime."""
+    import numpy as np
+    from timg_amd import comm
+    c = comm.Comm(0, 1, 0, comm.Comm.unique_id())
+    rng = np.random.default_rng(5)
+    lens = rng.integers(1, 5000, 9)
+    data = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+    src = hip.upload(data)
+    dst = hip.malloc(int(lens.sum()) + 64)
+    all_len, total = c.gather_to_root(src, lens, n_frames_max=12, recv_ptr=dst, recv_cap=int(lens.sum()) + 64)
+    assert total == lens.sum() and (all_len[0, :9] == lens).all() and (all_len[0, 9:] == 0).all()
+    assert np.array_equal(hip.download(dst, total), data)
+    hip.free(src)
+    hip.free(dst)
+    c.close()
 
 
 @pytest.mark.gpu

@@ -30,7 +30,7 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     if not os.path.exists(BIN):
         pytest.skip("timg_amd/twins/build/twin_check not built (needs /root/reference at build time)")
     dump = tmp_path / "sixel.bin"
-    r = subprocess.run([BIN, "all", str(dump)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([BIN, "all", str(dump)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all twins match" in r.stdout
     # (includes MultiColumnRenderer from the reference driving the block canvas twin in its
@@ -46,6 +46,8 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     # the device-resident ImageSource twin: same pixels through QOIImageSource + reference scaler + reference
     # canvas and through HipRawRGBASource (scaled, composed and encoded in device memory)
     assert "device-resident image source: 6 pipelines identical" in r.stdout
+    # the RCCL gather behind its C-ABI + the C++ writer that feeds BufferedWriteSequencer in frame order
+    assert "RCCL gather to the root + ordered hand-over to the write sequencer (world 1): checked" in r.stdout
     # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
     assert "kitty / iTerm2 canvas twins at --compress=0: checked" in r.stdout
     # the sixel twin's stream (variant 0): five frames, the first decodable to a 200x114 raster

@@ -20,6 +20,7 @@
 #include "display-options.h"
 #include "framebuffer.h"
 #include "hip-context.h"
+#include "hip-gather-writer.h"
 #include "hip-graphics-canvas.h"
 #include "hip-image-scaler.h"
 #include "hip-raw-rgba-source.h"
@@ -548,8 +549,72 @@ static void CheckImageSource() {
     fflush(stdout);
 }
 
+// The multi-GPU exchange step through its C-ABI (include/timg_hip_comm.h) and its C++ caller: the
+// frames a rank encoded, gathered over RCCL and handed to the reference's sequencer in frame order.
+// One GPU is all this box has: world = 1 (the gather to oneself runs the same calls; the frame-order
+// arithmetic for several ranks is checked on the CPU in tests/test_abi.py).
+static void CheckGatherWriter() {
+    timg_hip_ctx *ctx = SharedHipContext();
+    uint8_t id[TIMG_HIP_COMM_ID_BYTES];
+    timg_hip_comm *comm = nullptr;
+    CHECK(timg_hip_comm_unique_id(id) == 0, "unique id: %s", timg_hip_comm_last_error(nullptr));
+    CHECK(timg_hip_comm_create(0, 1, 0, id, &comm) == 0, "comm create: %s", timg_hip_comm_last_error(nullptr));
+    if (!comm) return;
+    const int n = 7, w = 100, h = 56;
+    std::vector<uint8_t> frames((size_t)n * w * h * 4);
+    rng_state = 4711;
+    for (int i = 0; i < n; ++i) {
+        Framebuffer fb(w, h);
+        Fill(&fb, i % 3);
+        memcpy(&frames[(size_t)i * w * h * 4], fb.begin(), (size_t)w * h * 4);
+    }
+    // encode on the device, leave the bytes there, pack them back to back
+    const size_t slot = timg_hip_block_max_bytes(w, h);
+    uint8_t *dev_out = nullptr, *packed = nullptr;
+    CHECK(timg_hip_malloc(ctx, slot * n, (void **)&dev_out) == TIMG_HIP_OK &&
+              timg_hip_malloc(ctx, slot * n, (void **)&packed) == TIMG_HIP_OK, "device buffers");
+    std::vector<size_t> lens(n);
+    std::vector<int> xs(n, 0);
+    CHECK(timg_hip_block_encode_grid(ctx, frames.data(), w, h, 0, 0, 0, n, TIMG_HIP_BLOCK_QUARTER, xs.data(),
+                                     (char *)dev_out, slot, 1, lens.data(), nullptr) == TIMG_HIP_OK, "encode: %s",
+          timg_hip_last_error(ctx));
+    std::vector<uint64_t> lens64(n);
+    size_t at = 0;
+    for (int i = 0; i < n; ++i) {
+        timg_hip_memcpy_d2d(ctx, packed + at, dev_out + (size_t)i * slot, lens[i], nullptr);
+        lens64[i] = lens[i];
+        at += lens[i];
+    }
+    timg_hip_sync(ctx, nullptr);
+    // what must arrive: the same frames encoded to host memory, one after the other
+    std::vector<char> host(slot * n);
+    std::vector<size_t> hl(n);
+    timg_hip_block_encode_grid(ctx, frames.data(), w, h, 0, 0, 0, n, TIMG_HIP_BLOCK_QUARTER, xs.data(), host.data(), slot, 0,
+                               hl.data(), nullptr);
+    std::string want;
+    for (int i = 0; i < n; ++i) want.append(host.data() + (size_t)i * slot, hl[i]);
+    for (int round_robin = 0; round_robin < 2; ++round_robin) {
+        volatile sig_atomic_t intr = 0;
+        const int fd = memfd_create("gather", 0);
+        {
+            BufferedWriteSequencer seq(fd, false, 4, true, intr);
+            HipGatherWriter writer(ctx, comm, 1, 0, &seq);
+            CHECK(writer.GatherAndWrite(packed, lens64.data(), n, n, round_robin != 0), "GatherAndWrite");
+            seq.Flush();
+        }
+        const std::string got = Slurp(fd);
+        CHECK(got == want && !got.empty(), "gathered stream: %zu vs %zu bytes", got.size(), want.size());
+        close(fd);
+    }
+    timg_hip_free(ctx, dev_out);
+    timg_hip_free(ctx, packed);
+    timg_hip_comm_destroy(comm);
+    printf("RCCL gather to the root + ordered hand-over to the write sequencer (world 1): checked\n");
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|gather] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -562,6 +627,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "sixelgrid" || what == "timggrid") CheckGridLikeTimg();
     if (what == "all" || what == "graphics") CheckGraphicsCanvases();
     if (what == "all" || what == "source") CheckImageSource();
+    if (what == "all" || what == "gather") CheckGatherWriter();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);
         return 1;

@@ -189,7 +189,7 @@ def main():
     else:
         mine = list(range(rank * cfg["frames"], (rank + 1) * cfg["frames"]))
     n_mine = len(mine)
-    chunk = n_mine if not strong else max(1, min(args.chunk, n_mine))
+    chunk = n_mine if not strong else max(1, min(args.chunk, (cfg["frames"] + world - 1) // world))
     pw, ph = (18, 18) if cfg.get("checker") else (0, 0)  # -B pattern: pattern_size * cell px (9 x 18 cells)
     blend = timg_amd.Blend.make(BG, PATTERN if cfg.get("checker") else (0, 0, 0, 0), pw, ph)
 
@@ -220,6 +220,9 @@ def main():
     for p in pipes:
         p.stream.wait_stream(torch.cuda.current_stream())
     chunks = [src[i:i + chunk] for i in range(0, n_mine, chunk)]
+    counts = ([len(shard_frames(cfg["frames"], world, r, round_robin=cfg.get("round_robin", False))) for r in range(world)]
+              if strong else [n_mine] * world)
+    n_launches_max = max((n + chunk - 1) // chunk for n in counts) if strong else 1
     if chunks and chunks[-1].shape[0] != chunk:  # a ragged tail gets its own pipeline
         tail_pipe = GridPipeline(hips[0], chunks[-1].shape[0], in_w, in_h, out_w, out_h, mode, blend)
     else:
@@ -238,17 +241,28 @@ def main():
             run_batched_streams(pipes, src, n_steps, n_pipes, world, gather_frames_to_root, timed_events, record)
             return
         for _ in range(n_steps):  # a step = the whole sharded stream, chunk by chunk
-            for c in chunks:
-                p = tail_pipe if (tail_pipe is not None and c.shape[0] != chunk) else pipe
-                e0 = record(p.stream)
-                p.scale(c)
-                e1 = record(p.stream)
-                p.encode()
-                e2 = record(p.stream)
-                if timed_events is not None:
-                    timed_events.append((e0, e1, e2))
+            for k in range(n_launches_max):
+                c = chunks[k] if k < len(chunks) else None
+                if c is not None:
+                    p = tail_pipe if (tail_pipe is not None and c.shape[0] != chunk) else pipe
+                    e0 = record(p.stream)
+                    p.scale(c)
+                    e1 = record(p.stream)
+                    p.encode()
+                    e2 = record(p.stream)
+                    if timed_events is not None:
+                        timed_events.append((e0, e1, e2))
                 if world > 1:
-                    payload, lens = p.packed_output()
+                    # every rank takes part in every gather; ranks that own fewer frames pad their
+                    # lengths with zeros (the gather wants the same frame count everywhere)
+                    if c is not None:
+                        payload, lens = p.packed_output()
+                    else:
+                        payload = torch.empty(0, dtype=torch.uint8, device="cuda")
+                        lens = torch.empty(0, dtype=torch.int64, device="cuda")
+                    want = max(min(chunk, max(0, n_r - k * chunk)) for n_r in counts)
+                    if lens.numel() < want:
+                        lens = torch.cat([lens, torch.zeros(want - lens.numel(), dtype=torch.int64, device="cuda")])
                     gather_frames_to_root(payload, lens)
 
     def timed(n_steps, n_pipes, timed_events=None):

@@ -224,8 +224,8 @@ def _plan_dump(fn, lead, dw, dh, filter, sw, sh):
 
 def product_plan_dump(sw, sh, dw, dh, filter=0, in_fmt=0):
     """The product's independently built tables (host-only debug export)."""
-    import timg_amd
-    L = timg_amd.load_library()
+    # (a test-only library next to the product: libtimg_hip.so itself carries no debug entry points)
+    L = ctypes.CDLL(os.path.join(ROOT, "timg_amd", "libtimg_hip_debug.so"))
     return _plan_dump(L.timg_hip_debug_plan_dump, (sw, sh, in_fmt), dw, dh, filter, sw, sh)
 
 

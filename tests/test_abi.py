@@ -89,6 +89,12 @@ def test_product_does_not_reference_the_oracle():
                 assert "libtimg_oracle" not in body and "oracle_lib" not in body, f
 
 
+def test_product_library_has_no_debug_entry_points():
+    """Host-side emulations used by the CPU tests live in libtimg_hip_debug.so, not in the product."""
+    syms = os.popen(f"nm -D --defined-only {timg_amd.lib_path()} 2>/dev/null").read()
+    assert "timg_hip_init" in syms and "timg_hip_debug" not in syms
+
+
 def test_header_is_valid_c99():
     """The drop-in boundary is a C header: it must compile as C, not only as C++."""
     import subprocess

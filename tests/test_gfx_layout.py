@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def emulate():
-    L = ctypes.CDLL(os.path.join(ROOT, "timg_amd", "libtimg_hip.so"))
+    L = ctypes.CDLL(os.path.join(ROOT, "timg_amd", "libtimg_hip_debug.so"))  # test-only library
     f = L.timg_hip_debug_gfx_emulate
     f.restype = ctypes.c_long
     f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,

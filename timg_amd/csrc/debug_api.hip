@@ -1,6 +1,6 @@
-// timg_amd/csrc/debug_api.hip -- host-only introspection used by the CPU test
-// suite (no GPU needed): dumps the resample plan in a normalised form.  Not
-// part of the public ABI (not declared in include/timg_hip.h).
+// timg_amd/csrc/debug_api.hip -- TEST-ONLY library (libtimg_hip_debug.so): host-only
+// introspection used by the CPU test suite (no GPU needed).  Not part of the public ABI
+// (not declared in include/timg_hip.h) and not linked into libtimg_hip.so.
 #include <cstring>
 
 #include <vector>

@@ -142,7 +142,9 @@ static int GfxEncode(int kind, timg_hip_ctx *ctx, const uint8_t *fb, int w, int 
                      size_t out_cap, int out_on_device, size_t *out_len, void *stream) {
     if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0) return TIMG_HIP_ERR_ARG;
     if (kind == kGfxKitty && !image_ids) return TIMG_HIP_ERR_ARG;
-    if ((unsigned long long)w * h > 250000000ull)  // 32-bit byte offsets inside a frame
+    // 64 Mpixels: the Adler-32 B sum (sum over (n - j) * byte, at most 255 n^2 / 2 for n raw bytes)
+    // stays below 2^64, so it can be reduced mod 65521 once at the end; 32-bit byte offsets hold too
+    if ((unsigned long long)w * h > 64ull * 1024 * 1024)
         return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "frame of %d x %d pixels is too large", w, h);
     if (stride == 0) stride = w * 4;
     if (stride < w * 4) return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride");

@@ -148,12 +148,14 @@ int timg_hip_alpha_compose(timg_hip_ctx *ctx, uint8_t *fb, int w, int h,
                            int *any_transparent_or_null, void *stream);
 
 /* ---- auto-crop bounding box ----------------------------------------------
- * The reduction behind --auto-crop (GraphicsMagick img.trim() in
- * src/graphics-magick-source.cc:238-240; "parity unpinned"):
- * bounding box of pixels that differ (RGBA, fuzz 0) from the top-left corner
- * pixel after removing crop_border pixels on every side.  out_xywh is a host
- * int[4] per frame {x, y, w, h} in source coordinates; an all-border frame
- * yields w=h=0. */
+ * The reduction behind --auto-crop / --crop-border (GraphicsMagick img.crop() + img.trim() in
+ * src/graphics-magick-source.cc:231-241, applied BEFORE scaling; "parity unpinned", SURVEY.md
+ * a6): crop_border pixels are removed on every side first; then, at fuzz 0, the left and top
+ * edges move in while pixels equal the top-left corner pixel, the right edge while they equal
+ * the top-right corner, the bottom edge while they equal the bottom-left corner (trim()'s
+ * published algorithm).  out_xywh is a host int[4] per frame {x, y, w, h} in source
+ * coordinates; w = h = 0: nothing but border.  To apply it, create the scaler for w x h and
+ * pass src + y * stride + x * 4 with the same stride: the crop costs no copy. */
 int timg_hip_autocrop_bbox(timg_hip_ctx *ctx, const uint8_t *src, int w, int h,
                            int stride, size_t frame_stride, int on_device,
                            int n_frames, int crop_border, int *out_xywh,

@@ -204,6 +204,10 @@ static void diffuse_add(unsigned char *data, long pos, int error, int num) {
     data[pos * 3] = (unsigned char)c;
 }
 
+/* trace (may be NULL): the value every pixel had when it was looked up (after the errors of its
+ * predecessors had been added), 3 bytes per pixel -- for the per-pixel bound of tests/test_sixel_oracle.py */
+static unsigned char *g_trace = NULL;
+
 static void apply_palette(unsigned char *rgb, int w, int h,
                           const unsigned char *pal, int ncolors, int dither,
                           int lookup_mode, unsigned char *index) {
@@ -230,6 +234,7 @@ static void apply_palette(unsigned char *rgb, int w, int h,
                 cache[hsh] = (unsigned short)(ci + 1);
             }
             index[pos] = (unsigned char)ci;
+            if (g_trace) memcpy(g_trace + pos * 3, px, 3);
             if (!dither) continue;
             for (int n = 0; n < 3; n++) {
                 int err = px[n] - pal[ci * 3 + n];
@@ -434,6 +439,23 @@ long oracle_libsixel_encode(const uint8_t *rgba, int w, int h, int lookup_mode, 
     free(index);
     free(rgb);
     return o.overflow ? -1 : o.pos;
+}
+
+/* Quantisation alone, with a trace: palette (ncolors * 3 bytes), the index of every pixel and the
+ * value it had when it was looked up.  Returns ncolors; *dithered says whether errors were diffused. */
+int oracle_sixel_quantize_trace(const uint8_t *rgba, int w, int h, int lookup_mode, uint8_t *pal_rgb,
+                                uint8_t *index, uint8_t *looked_up_rgb, int *dithered) {
+    unsigned char *rgb = (unsigned char *)malloc((size_t)w * h * 3 + 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) memcpy(rgb + i * 3, rgba + i * 4, 3);
+    int orig    = 0;
+    int ncolors = make_palette(rgb, w, h, pal_rgb, &orig);
+    int dither  = !(orig <= ncolors);
+    g_trace     = looked_up_rgb;
+    apply_palette(rgb, w, h, pal_rgb, ncolors, dither, lookup_mode, index);
+    g_trace = NULL;
+    if (dithered) *dithered = dither;
+    free(rgb);
+    return ncolors;
 }
 
 long oracle_sixel_encode(const uint8_t *fb, int w, int h, int has_getter,

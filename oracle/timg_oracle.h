@@ -67,6 +67,10 @@ size_t oracle_block_max_bytes(int w, int h);
 
 uint8_t oracle_as_256_term_color(uint32_t c); /* src/framebuffer.h:37-52 */
 
+/* --auto-crop / --crop-border (parity unpinned: GraphicsMagick trim(), see oracle/autocrop.c):
+ * {x, y, w, h} of what remains, in source coordinates; w = h = 0: nothing but border. */
+void oracle_autocrop_bbox(const uint8_t *rgba, int w, int h, int stride, int crop_border, int xywh[4]);
+
 /* ---- sixel (parity unpinned; see oracle/README.md) ------------------------
  * Restates SixelCanvas::Send's call contract (src/sixel-canvas.cc:100-155):
  * pad to a multiple of 6 rows, blend only the pad rows, 256-colour adaptive
@@ -82,6 +86,10 @@ long oracle_sixel_encode(const uint8_t *fb, int w, int h, int has_getter,
 /* The libsixel part alone (sixel_dither_initialize + sixel_encode of an RGBA8888 frame whose
  * height is a multiple of 6): DCS q ... ST.  Used by oracle/stub/sixel.h. */
 long oracle_libsixel_encode(const uint8_t *rgba, int w, int h, int lookup_mode, char *out, long cap);
+/* Quantisation with a trace (not thread safe): palette, index per pixel, and the value every pixel
+ * had when it was looked up (3 bytes per pixel).  Returns ncolors. */
+int oracle_sixel_quantize_trace(const uint8_t *rgba, int w, int h, int lookup_mode, uint8_t *pal_rgb,
+                                uint8_t *index, uint8_t *looked_up_rgb, int *dithered);
 /* Palette only (<=256 entries r,g,b); returns ncolors. dither_off set to 1 if
  * the image had <= 256 distinct 15-bit colours. */
 int oracle_sixel_palette(const uint8_t *rgba, int w, int h, uint8_t *pal_rgb,

@@ -84,6 +84,24 @@ class Oracle:
     def as_256(self, c):
         return int(self.L.oracle_as_256_term_color(c_uint32(pack(c)))) & 0xFF
 
+    def sixel_quantize_trace(self, fb, lookup_mode):
+        """(palette[n,3], index[h,w], looked_up[h,w,3], dithered)"""
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        pal = np.zeros((256, 3), np.uint8)
+        idx = np.zeros((h, w), np.uint8)
+        val = np.zeros((h, w, 3), np.uint8)
+        d = c_int(0)
+        n = self.L.oracle_sixel_quantize_trace(_d(fb), w, h, lookup_mode, _d(pal), _d(idx), _d(val), ctypes.byref(d))
+        return pal[:n], idx, val, bool(d.value)
+
+    def autocrop_bbox(self, fb, crop_border=0):
+        fb = np.ascontiguousarray(fb)
+        h, w = fb.shape[:2]
+        out = (ctypes.c_int * 4)()
+        self.L.oracle_autocrop_bbox(_d(fb), w, h, w * 4, crop_border, out)
+        return list(out)
+
     # sixel
     def sixel_encode(self, fb, bg=(0, 0, 0, 0), pattern=(0, 0, 0, 0), pw=0, ph=0, has_getter=True,
                      broken_cursor=False, lookup_mode=1) -> bytes:

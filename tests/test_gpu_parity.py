@@ -183,7 +183,7 @@ def test_block_output_too_small_is_reported(hip):
     assert e.value.code == -4
 
 
-def test_autocrop_bbox(hip):
+def test_autocrop_bbox(hip, oracle):
     fb = np.zeros((90, 160, 4), np.uint8)
     fb[...] = (10, 20, 30, 255)
     fb[17:60, 33:120] = (200, 0, 0, 255)
@@ -191,6 +191,48 @@ def test_autocrop_bbox(hip):
     assert hip.autocrop_bbox(fb, 160, 90, crop_border=40).tolist() == [[0, 0, 0, 0]]
     blank = np.zeros((20, 30, 4), np.uint8)
     assert hip.autocrop_bbox(blank, 30, 20).tolist() == [[0, 0, 0, 0]]
+    # random frames against the restatement of trim(): differently coloured borders per side,
+    # content touching an edge, a crop_border that cuts into the content, batches
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        fb = np.empty((h, w, 4), np.uint8)
+        fb[...] = rng.integers(0, 256, 4)
+        if rng.random() < 0.5:   # right / bottom margins of another colour than the top-left one
+            fb[:, w - int(rng.integers(0, w // 2 + 1)):] = rng.integers(0, 256, 4)
+            fb[h - int(rng.integers(0, h // 2 + 1)):, :] = rng.integers(0, 256, 4)
+        if rng.random() < 0.85:
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            x1, y1 = int(rng.integers(x0, w)) + 1, int(rng.integers(y0, h)) + 1
+            fb[y0:y1, x0:x1] = rng.integers(0, 256, (y1 - y0, x1 - x0, 4))
+        border = int(rng.integers(0, 6)) if rng.random() < 0.5 else 0
+        assert hip.autocrop_bbox(fb, w, h, crop_border=border).tolist()[0] == oracle.autocrop_bbox(fb, border), (w, h, border)
+    batch = np.stack([synth.make("alpha", 64, 40, seed=s) for s in range(5)])
+    got = hip.autocrop_bbox(batch, 64, 40, n_frames=5)
+    assert got.tolist() == [oracle.autocrop_bbox(batch[i]) for i in range(5)]
+
+
+def test_autocrop_then_scale_reads_the_window_in_place(hip, oracle):
+    """--crop-border + --auto-crop as the reference applies them (before scaling,
+    src/graphics-magick-source.cc:231-254): the box comes from the reduction, the scaler is created for
+    the cropped size and reads the window through pointer offset + stride -- no cropped copy."""
+    w, h = 640, 360
+    frame = np.empty((h, w, 4), np.uint8)
+    frame[...] = (12, 12, 12, 255)
+    frame[40:300, 100:580] = synth.make("photo", 480, 260, seed=4)
+    x, y, cw, ch = hip.autocrop_bbox(frame, w, h, crop_border=8).tolist()[0]
+    assert (x, y, cw, ch) == tuple(oracle.autocrop_bbox(frame, 8)) and cw < w - 16 and ch < h - 16
+    dw, dh = 120, 65
+    sc = hip.scaler(cw, ch, dw, dh)
+    dev = hip.upload(frame)
+    out = hip.malloc(dw * dh * 4)
+    hip.scale_blend(sc, dev + y * w * 4 + x * 4, out, 1, src_stride=w * 4)
+    hip.sync()
+    got = hip.download(out, dw * dh * 4).reshape(dh, dw, 4)
+    hip.free(dev)
+    hip.free(out)
+    sc.close()
+    assert np.array_equal(got, oracle.scale(np.ascontiguousarray(frame[y:y + ch, x:x + cw]), dw, dh))
 
 
 # ---- sixel: the HIP path implements oracle lookup_mode 1 byte for byte -------

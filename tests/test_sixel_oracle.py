@@ -93,3 +93,44 @@ def test_broken_cursor_variant_and_pad_pattern(oracle):
     for x in (0, 10, 20):
         want = BG if ((x // 9) + 2) % 2 == 0 else (200, 10, 10)
         assert np.abs(img[21, x, :3].astype(int) - np.array(want[:3])).max() <= 12
+
+
+# ---- per-pixel tolerance of the lookup -------------------------------------------------
+# libsixel looks a pixel up through a 15-bit (5:5:5) cache: the FIRST pixel that lands in a cell decides the
+# palette entry of every later pixel of that cell (lookup_mode 0, raster order -- inherently serial).  The
+# device computes the same 15-bit granularity order-free: a cell's entry is the palette colour nearest to
+# the cell's CENTRE (lookup_mode 1).  Both are approximations of "nearest palette colour to this pixel",
+# with these provable per-pixel bounds (v: the value looked up, p*: its exact nearest entry, euclidean RGB):
+#     mode 0:  |v - p| <= |v - p*| + 2 * 7 * sqrt(3)   (v and the cell's first pixel differ by <= 7 per channel)
+#     mode 1:  |v - p| <= |v - p*| + 2 * 4 * sqrt(3)   (v and the cell's centre differ by <= 4 per channel)
+# i.e. the device's choice is never further from the exact nearest colour than libsixel's own cache allows
+# itself to be -- the bound is tighter.  Tested on every pixel below.
+BOUND = {0: 2 * 7 * 3 ** 0.5, 1: 2 * 4 * 3 ** 0.5}
+
+
+@pytest.mark.parametrize("kind,w,h", [("photo", 800, 450), ("alpha", 320, 203), ("noise", 200, 100), ("photo", 97, 31)])
+def test_per_pixel_lookup_bound(oracle, kind, w, h):
+    fb = synth.make(kind, w, h, 2)
+    excess = {}
+    for mode in (0, 1):
+        pal, idx, val, dithered = oracle.sixel_quantize_trace(fb, mode)
+        v = val.astype(np.float64).reshape(-1, 3)
+        p = pal.astype(np.float64)
+        chosen = np.linalg.norm(v - p[idx.reshape(-1)], axis=1)
+        best = np.full(len(v), np.inf)
+        for lo in range(0, len(v), 1 << 16):  # exact nearest entry of every looked-up value
+            d = np.linalg.norm(v[lo:lo + (1 << 16), None, :] - p[None, :, :], axis=2)
+            best[lo:lo + (1 << 16)] = d.min(axis=1)
+        excess[mode] = chosen - best
+        assert (excess[mode] >= -1e-9).all()
+        assert excess[mode].max() <= BOUND[mode] + 1e-9, (mode, excess[mode].max())
+    # and in practice the order-free lookup is the closer one on average
+    assert excess[1].mean() <= excess[0].mean() + 0.5
+
+
+def test_hip_lookup_is_the_traced_mode_1():
+    """(GPU side of the statement above: tests/test_gpu_parity.py::test_sixel_bytes_match_oracle pins the
+    device's stream to lookup_mode 1 byte for byte, so the traced bound is the device's bound.)"""
+    import os
+    body = open(os.path.join(os.path.dirname(__file__), "test_gpu_parity.py")).read()
+    assert "lookup_mode=1" in body and "def test_sixel_bytes_match_oracle" in body

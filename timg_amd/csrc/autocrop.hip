@@ -1,10 +1,13 @@
 // timg_amd/csrc/autocrop.hip -- bounding-box reduction behind --auto-crop.
 //
-// The reference delegates this to GraphicsMagick's Image::trim()
-// (src/graphics-magick-source.cc:231-241), which is outside the reference tree
-// ("parity unpinned").  Defined here as: after removing
-// crop_border pixels on each side, the bounding box of all pixels whose RGBA
-// value differs from the (cropped) top-left corner pixel.
+// The reference delegates this to GraphicsMagick (src/graphics-magick-source.cc:231-241:
+// img.crop() by crop_border first, then img.trim(), both BEFORE the image is scaled), which
+// is outside the reference tree ("parity unpinned").  This follows the
+// published algorithm of trim() at fuzz 0 (GetImageBoundingBox): after removing crop_border
+// pixels on each side, the left and top edges are measured against the top-left corner pixel,
+// the right edge against the top-right corner, the bottom edge against the bottom-left one.
+// One streaming read of the frame (16 B per lane); the crop itself costs nothing -- the
+// scaler is created for the cropped size and reads the window through pointer + stride.
 #include "context.h"
 
 namespace timg_amd {
@@ -16,8 +19,9 @@ BBoxKernel(const uint8_t *src, int w, int h, size_t stride, size_t frame_stride,
     const int f          = blockIdx.z;
     const uint8_t *frame = src + (size_t)f * frame_stride;
     const int x0 = border, y0 = border, x1 = w - border, y1 = h - border;
-    const uint32_t ref =
-        *reinterpret_cast<const uint32_t *>(frame + (size_t)y0 * stride + (size_t)x0 * 4);
+    const uint32_t tl = *reinterpret_cast<const uint32_t *>(frame + (size_t)y0 * stride + (size_t)x0 * 4);
+    const uint32_t tr = *reinterpret_cast<const uint32_t *>(frame + (size_t)y0 * stride + (size_t)(x1 - 1) * 4);
+    const uint32_t bl = *reinterpret_cast<const uint32_t *>(frame + (size_t)(y1 - 1) * stride + (size_t)x0 * 4);
     int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -1, maxy = -1;
     // grid-stride over rows; a workgroup row-slice reads 16 B per lane
     for (int y = y0 + blockIdx.y; y < y1; y += gridDim.y) {
@@ -34,12 +38,12 @@ BBoxKernel(const uint8_t *src, int w, int h, size_t stride, size_t frame_stride,
                     px[i] = *reinterpret_cast<const uint32_t *>(row + (size_t)(x + i) * 4);
             }
             for (int i = 0; i < n; ++i) {
-                if (px[i] != ref) {
+                if (px[i] != tl) {
                     minx = min(minx, x + i);
-                    maxx = max(maxx, x + i);
                     miny = min(miny, y);
-                    maxy = max(maxy, y);
                 }
+                if (px[i] != tr) maxx = max(maxx, x + i);
+                if (px[i] != bl) maxy = max(maxy, y);
             }
         }
     }
@@ -51,11 +55,11 @@ BBoxKernel(const uint8_t *src, int w, int h, size_t stride, size_t frame_stride,
         maxx = max(maxx, __shfl_xor(maxx, d));
         maxy = max(maxy, __shfl_xor(maxy, d));
     }
-    if ((threadIdx.x & 63) == 0 && maxx >= 0) {
-        atomicMin(&boxes[f * 4 + 0], minx);
-        atomicMin(&boxes[f * 4 + 1], miny);
-        atomicMax(&boxes[f * 4 + 2], maxx);
-        atomicMax(&boxes[f * 4 + 3], maxy);
+    if ((threadIdx.x & 63) == 0) {
+        if (minx != 0x7fffffff) atomicMin(&boxes[f * 4 + 0], minx);
+        if (miny != 0x7fffffff) atomicMin(&boxes[f * 4 + 1], miny);
+        if (maxx >= 0) atomicMax(&boxes[f * 4 + 2], maxx);
+        if (maxy >= 0) atomicMax(&boxes[f * 4 + 3], maxy);
     }
 }
 
@@ -113,7 +117,7 @@ extern "C" int timg_hip_autocrop_bbox(timg_hip_ctx *ctx, const uint8_t *src, int
     TIMG_HIP_TRY(ctx, hipMemcpyAsync(hb, boxes, sizeof(int) * 4 * n_frames, hipMemcpyDeviceToHost, st));
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     for (int i = 0; i < n_frames; ++i) {
-        if (hb[i * 4 + 2] < 0) {
+        if (hb[i * 4 + 2] < hb[i * 4 + 0] || hb[i * 4 + 3] < hb[i * 4 + 1]) {  // nothing but border
             out_xywh[i * 4 + 0] = out_xywh[i * 4 + 1] = 0;
             out_xywh[i * 4 + 2] = out_xywh[i * 4 + 3] = 0;
         } else {

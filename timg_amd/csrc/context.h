@@ -83,16 +83,23 @@ struct timg_hip_ctx {
     timg_hip_ctx() {
         for (auto &p : pin) p.pinned = true;
     }
+    std::mutex err_mu;  // last_error is written from whichever thread fails (entry points that
+                        // work on device memory only do not hold `mu`)
     int Fail(int code, const char *fmt, ...) {
         char buf[512];
         va_list ap;
         va_start(ap, fmt);
         vsnprintf(buf, sizeof(buf), fmt, ap);
         va_end(ap);
+        std::lock_guard<std::mutex> l(err_mu);
         last_error = buf;
         return code;
     }
+    // A device call failed, possibly after copies and kernels on this context's scratch memory
+    // were enqueued: nothing may still be in flight when the caller's lock on `mu` is released
+    // and the next caller reuses (or re-allocates) that scratch.
     int FailHip(hipError_t e, const char *what) {
+        (void)hipDeviceSynchronize();
         return Fail(TIMG_HIP_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
     }
     hipStream_t Stream(void *s) { return s ? (hipStream_t)s : stream; }

@@ -511,9 +511,12 @@ struct RowCtl {
     int done_y;
     float alpha_sum;  // vertical sum of an all-opaque alpha column of the completing row
 };
+struct RowRec {  // 32 bytes: one s_load_dwordx8 per source row, from a pointer that just advances
+    RowW w;
+    RowCtl ctl;
+};
 struct MTables {
-    const RowW *w;      // indexed like StreamTables::sched (BandInfo::sched + row - r0)
-    const RowCtl *ctl;
+    const RowRec *rec;  // indexed like StreamTables::sched (BandInfo::sched + row - r0)
 };
 
 // Horizontal pass of a completed row, every lane its own output column(s): weights as
@@ -597,8 +600,12 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
     }
 }
 
-template <int M>
-__global__ void __launch_bounds__(kThreads, 3)
+// kOvf: the plan can have five live output rows (overflow row compiled in); most shrink ratios
+// never have more than four.
+// (waves per SIMD pinned to exactly 3 -- LDS allows no more: the compiler then uses the 168 registers
+// it may have instead of squeezing into 128 for an occupancy the kernel cannot reach)
+template <int M, bool kOvf>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
                    int *tile_state, int hrow, int hgroups) {
     static_assert(M == kOpaque || M == kPremult, "three or four channels");
@@ -645,7 +652,8 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     // (lanes straddling or past the end of the row: see RunTile)
     const int over          = col0 + kPix - plan.in_w;
     const int shift         = (col0 < plan.in_w && over > 0) ? over : 0;
-    const bool any_shift    = (plan.in_w & 3) != 0 && si.cx0 + kStripCols > plan.in_w;  // uniform
+    // (through readfirstlane: in a scalar register, so the per-row test is a scalar branch)
+    const int any_shift_s = __builtin_amdgcn_readfirstlane((plan.in_w & 3) != 0 && si.cx0 + kStripCols > plan.in_w);
     const uint32_t lane_off = (uint32_t)min(col0, plan.in_w - kPix) * 4u;
     const uint8_t *frame    = batch.src + (size_t)f * batch.src_frame_stride;
     int *flag               = batch.transparent_flags ? batch.transparent_flags + f : nullptr;
@@ -653,9 +661,25 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     const int r_last        = min(r1, plan.in_h - 1);
     // straight RGB of pixels with (nearly) no alpha only shows when they are not composed
     const bool need_straight = !(blend.enabled && blend.start_row <= bi.oy0);
-    auto load_row = [&](int r) -> uint4 {
-        const uint8_t *row = frame + (size_t)min(r, r_last) * batch.src_stride;  // uniform
-        return *reinterpret_cast<const uint4 *>(row + lane_off);
+    // Source rows are fetched in order through a byte offset that just advances (rows past the
+    // image's last one -- virtual rows of the schedule -- re-read the last row): no 64-bit
+    // multiply per row.  (Frames are far below 4 GB.)
+    const uint8_t *frame_lane = frame + lane_off;
+    uint32_t next_off         = (uint32_t)((size_t)min(bi.r0, r_last) * batch.src_stride);
+    const uint32_t last_off   = (uint32_t)((size_t)r_last * batch.src_stride);
+    const uint32_t row_step_b = (uint32_t)batch.src_stride;
+    // The loads are inline assembly with hand-placed waits.  Left to the compiler, the waits in front of
+    // a ring slot came out as vmcnt(1) where vmcnt(3) is what the ring allows: its count of what is in
+    // flight merges pessimistically where the completion path (which issues stores) rejoins, and the
+    // prefetch collapsed to one or two rows -- memory time and compute time simply added up (0.40 ms of
+    // loads + 0.32 ms of arithmetic = 0.72 ms).  Memory operations complete in order, so "at most
+    // kDepth - 1 operations outstanding" means the oldest load of the ring has arrived (stores issued in
+    // between only make the wait more conservative).
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    auto issue_next_row = [&](u4v &q) __attribute__((always_inline)) {
+        const uint8_t *p = frame_lane + next_off;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q) : "v"(p) : "memory");
+        next_off = min(next_off + row_step_b, last_off);  // uniform
     };
 
     f2v acc[kPix][kCh][2];  // the four matrix slots as pairs (0,1) (2,3): packed adds
@@ -672,31 +696,35 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     int ev        = 0;
     int wa        = 0;  // A operand: lanes 0..3 hold the four slot weights (rewritten every row)
 
-    const RowW *wtab     = mt.w + bi.sched;
-    const RowCtl *ctab   = mt.ctl + bi.sched;
-    RowW w_next          = LoadConstant(wtab);
-    RowCtl ctl_next      = LoadConstant(ctab);
+    const RowRec *rec_ptr = mt.rec + bi.sched;
+    RowRec rec_next       = LoadConstant(rec_ptr);
     auto row_step = [&](const uint4 &q_in, int r) __attribute__((always_inline)) -> bool {
         uint4 q = q_in;
-        if (any_shift && shift) {  // (one lane of the last strip of an image whose width is not a multiple of 4)
-            if (shift == 1) q = make_uint4(q.y, q.z, q.w, q.w);
-            else if (shift == 2) q = make_uint4(q.z, q.w, q.w, q.w);
-            else q = make_uint4(q.w, q.w, q.w, q.w);
+        if (any_shift_s) {  // scalar branch (last strip of an image whose width is not a multiple of 4); selects inside
+            const uint32_t a = q.x, b2 = q.y, c = q.z, d2 = q.w;
+            q.x = shift == 0 ? a : shift == 1 ? b2 : shift == 2 ? c : d2;
+            q.y = shift == 0 ? b2 : shift == 1 ? c : d2;
+            q.z = shift == 0 ? c : d2;
         }
-        const RowW rw    = w_next;
-        const RowCtl ctl = ctl_next;
-        asm volatile("" ::"s"(ctl.flags), "s"(rw.w[0]));  // both are complete here ...
+        const RowW rw    = rec_next.w;
+        const RowCtl ctl = rec_next.ctl;
+        asm volatile("" ::"s"(ctl.flags), "s"(rw.w[0]));  // the record is complete here ...
         __builtin_amdgcn_sched_barrier(0);
-        w_next   = LoadConstant(wtab + (r + 1 - bi.r0));  // ... before the next requests go out
-        ctl_next = LoadConstant(ctab + (r + 1 - bi.r0));
+        rec_next = LoadConstant(++rec_ptr);  // ... before the next request goes out
         asm volatile("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\t"
                      "v_writelane_b32 %0, %4, 3\n\ts_nop 3"  // (the compiler does not see this VALU write -> MFMA read hazard)
                      : "+v"(wa)
-                     : "s"(rw.w[0]), "s"(rw.w[1]), "s"(rw.w[2]), "s"(rw.w[3]));
+                     : "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[0]))),
+                       "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[1]))),
+                       "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[2]))),
+                       "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[3]))));  // (uniform: folds away)
         if (M == kOpaque) amin = min(min(amin, min(q.x, q.y)), min(q.z, q.w));
         // (fully transparent pixels announce filtered alphas of zero: see RunTile)
         if (M == kPremult && need_straight)
             ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
+#if defined(TIMG_MABL) && TIMG_MABL == 3
+        return true;  // (ablation: the loads and the alpha minimum alone)
+#endif
         const f4v zero  = {0.0f, 0.0f, 0.0f, 0.0f};
         const float waf = __int_as_float(wa);
         const uint32_t qs[kPix] = {q.x, q.y, q.z, q.w};
@@ -707,31 +735,63 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         for (int p0 = 0; p0 < kPix; p0 += kBatch) {
             if (p0) __builtin_amdgcn_sched_barrier(0);
             float d[kBatch][kCh];
+            if (M == kOpaque) {
+                // u8 * (1/255) for the six colour bytes of two pixels as three packed multiplies
+                static_assert(M != kOpaque || kBatch == 2, "pairs");
+                const uint32_t pa = qs[p0], pb = qs[p0 + (kBatch > 1 ? 1 : 0)];
+                const f2v k2 = {1.0f / 255.0f, 1.0f / 255.0f};
+                const f2v m0 = f2v{(float)(pa & 0xffu), (float)((pa >> 8) & 0xffu)} * k2;
+                const f2v m1 = f2v{(float)((pa >> 16) & 0xffu), (float)(pb & 0xffu)} * k2;
+                const f2v m2 = f2v{(float)((pb >> 8) & 0xffu), (float)((pb >> 16) & 0xffu)} * k2;
+                d[0][0] = m0.x;
+                d[0][1] = m0.y;
+                d[0][kCh > 2 ? 2 : 0] = m1.x;
+                d[kBatch > 1 ? 1 : 0][0] = m1.y;
+                d[kBatch > 1 ? 1 : 0][1] = m2.x;
+                d[kBatch > 1 ? 1 : 0][kCh > 2 ? 2 : 0] = m2.y;
+            } else {
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) DecodeMode<M>(qs[p0 + b], d[b]);
+                for (int b = 0; b < kBatch; ++b) DecodeMode<M>(qs[p0 + b], d[b]);
+            }
+#if defined(TIMG_MABL) && TIMG_MABL >= 2
+            if (p0 == 0) acc[0][0][0] = acc[0][0][0] + f2v{d[0][0], d[0][1]};  // (ablation: keep the decode alive)
+            continue;
+#endif
+            // the batch's MFMAs back to back, then its sums: a sum issued right behind its MFMA
+            // would wait for it in s_nop states (the scheduler likes to pair them up)
+            f4v prod[kBatch][kCh];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)
+#pragma unroll
+                for (int ch = 0; ch < kCh; ++ch)  // (w0 d, w1 d, w2 d, w3 d), each the correctly rounded product
+                    prod[b][ch] = __builtin_amdgcn_mfma_f32_4x4x1f32(waf, d[b][ch], zero, 4, 0, 0);
+#ifndef TIMG_M_NOSPLIT
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int b = 0; b < kBatch; ++b)
 #pragma unroll
                 for (int ch = 0; ch < kCh; ++ch) {
-                    // (w0 d, w1 d, w2 d, w3 d), each the correctly rounded product
-                    const f4v prod    = __builtin_amdgcn_mfma_f32_4x4x1f32(waf, d[b][ch], zero, 4, 0, 0);
-                    acc[p0 + b][ch][0] = acc[p0 + b][ch][0] + f2v{prod.x, prod.y};
-                    acc[p0 + b][ch][1] = acc[p0 + b][ch][1] + f2v{prod.z, prod.w};
+                    acc[p0 + b][ch][0] = acc[p0 + b][ch][0] + f2v{prod[b][ch].x, prod[b][ch].y};
+                    acc[p0 + b][ch][1] = acc[p0 + b][ch][1] + f2v{prod[b][ch].z, prod[b][ch].w};
                 }
-            if (ctl.flags & 1) {  // wave-uniform: the overflow row
+            if (kOvf && (ctl.flags & 1)) {  // wave-uniform: the overflow row
 #pragma unroll
                 for (int b = 0; b < kBatch; ++b)
 #pragma unroll
                     for (int ch = 0; ch < kCh; ++ch) ovf[p0 + b][ch] = ovf[p0 + b][ch] + d[b][ch] * ctl.ovf_w;
             }
         }
+#if defined(TIMG_MABL) && TIMG_MABL == 4
+        return true;  // (ablation: loads + decode, no completion handling)
+#endif
         const int code = (ctl.flags >> 4) & 7;
         if (code == 0) return true;  // wave- and block-uniform
 
         // an output row is complete: its column sums go to a staging row
         float *row = stage + (size_t)(ev & 1) * stage_cols * 4;
         float4 *dst = reinterpret_cast<float4 *>(row + (size_t)tid * kPix * 4);
-        const bool move = (ctl.flags & 0x80) != 0;
+        const bool move = kOvf && (ctl.flags & 0x80) != 0;
         auto finish_slot = [&](auto comp_tag) {
             constexpr int C = decltype(comp_tag)::value;
 #pragma unroll
@@ -761,7 +821,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         if (code == 1) finish_slot(std::integral_constant<int, 0>());
         else if (code == 2) finish_slot(std::integral_constant<int, 1>());
         else if (code == 3) finish_slot(std::integral_constant<int, 2>());
-        else if (code == 4) finish_slot(std::integral_constant<int, 3>());
+        else if (code == 4 || !kOvf) finish_slot(std::integral_constant<int, 3>());
         else {
 #pragma unroll
             for (int p = 0; p < kPix; ++p) {
@@ -779,26 +839,56 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         if (__any(!ok) && (tid & 63) == 0) fail = 1;
         BlockSync();
         if (fail) return false;
+#if !defined(TIMG_MABL) || TIMG_MABL < 1
         HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
+#endif
         ++ev;
         return true;
     };
 
     static_assert(kPrefetch == 4, "the register ring below is written out for 4 rows");
-    uint4 q0 = load_row(bi.r0), q1 = load_row(bi.r0 + 1), q2 = load_row(bi.r0 + 2), q3 = load_row(bi.r0 + 3);
-    for (int r = bi.r0; r <= r1; r += kPrefetch) {
-        if (!row_step(q0, r)) return;
-        q0 = load_row(r + 4);
-        if (r + 1 > r1) break;
-        if (!row_step(q1, r + 1)) return;
-        q1 = load_row(r + 5);
-        if (r + 2 > r1) break;
-        if (!row_step(q2, r + 2)) return;
-        q2 = load_row(r + 6);
-        if (r + 3 > r1) break;
-        if (!row_step(q3, r + 3)) return;
-        q3 = load_row(r + 7);
+    // kDepth source rows in flight per lane (the register ring is unrolled: "rotating" it is register
+    // naming, not moves).  Steady-state ablations (TIMG_MABL, profiles/r2/ablation_matrix_kernel.txt):
+    // the loads alone 0.40 ms (HBM-bound: 6.1 TB/s of traffic), + decode 0.40, + staging and barrier
+    // 0.43, + vertical products and sums 0.56, + horizontal pass 0.72.
+    // (8 rows in flight measure the same as 4 -- 0.722 vs 0.727 ms -- so the smaller code stays the default)
+#ifdef TIMG_M_DEPTH
+    constexpr int kDepth = TIMG_M_DEPTH;
+#else
+    constexpr int kDepth = 4;
+#endif
+    static_assert(kDepth == 4 || kDepth == 8, "ring written out for 4 or 8 rows");
+    u4v q0, q1, q2, q3, q4 = {0, 0, 0, 0}, q5 = q4, q6 = q4, q7 = q4;
+    issue_next_row(q0);
+    issue_next_row(q1);
+    issue_next_row(q2);
+    issue_next_row(q3);
+    if (kDepth == 8) {
+        issue_next_row(q4);
+        issue_next_row(q5);
+        issue_next_row(q6);
+        issue_next_row(q7);
     }
+#define TIMG_M_STEP(Q, K)                                                              \
+    if (left < K + 1) break;                                                           \
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q) : "n"(kDepth - 1) : "memory");        \
+    if (!row_step(make_uint4(Q.x, Q.y, Q.z, Q.w), 0)) return;                          \
+    issue_next_row(Q);
+    for (int left = r1 - bi.r0 + 1; left > 0; left -= kDepth) {  // (rows still to do)
+        TIMG_M_STEP(q0, 0)
+        TIMG_M_STEP(q1, 1)
+        TIMG_M_STEP(q2, 2)
+        TIMG_M_STEP(q3, 3)
+        if (kDepth == 8) {
+            TIMG_M_STEP(q4, 4)
+            TIMG_M_STEP(q5, 5)
+            TIMG_M_STEP(q6, 6)
+            TIMG_M_STEP(q7, 7)
+        }
+    }
+    // (loads still in flight must land before their registers mean anything else)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : : "memory");
+#undef TIMG_M_STEP
     if (M == kOpaque) ok = ok && (amin >> 24) == 0xffu;
     if (__any(!ok) && (tid & 63) == 0) fail = 1;
     BlockSync();
@@ -1067,6 +1157,7 @@ struct StreamVariant {
     StreamTables t = {};
     MTables m      = {};     // matrix-slot schedule (ScaleStreamMKernel), same indexing as t.sched
     bool m_ok      = false;  // ... exists for this plan
+    bool m_ovf     = false;  // ... and ever uses the overflow row
     int band_rows  = 0;
 };
 
@@ -1088,7 +1179,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     std::vector<RowSched> sched;
     std::vector<RowW> wrows;    // matrix-slot schedule, indexed like sched
     std::vector<RowCtl> crows;
-    bool m_ok = p.vertical_first;
+    bool m_ok = p.vertical_first, uses_ovf = false;
     for (int oy = 0; oy < p.out_h; oy += band_rows) {
         BandInfo b;
         memset(&b, 0, sizeof(b));
@@ -1174,6 +1265,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
                     } else {
                         ce.ovf_w = w;
                         ce.flags |= 1;
+                        uses_ovf = true;
                     }
                 }
                 for (int k = 0; k <= kMSlots && m_ok; ++k) {
@@ -1221,15 +1313,18 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     const size_t o_strips = 0;
     const size_t o_bands  = align(o_strips + strips.size() * sizeof(StripInfo));
     const size_t o_sched  = align(o_bands + bands.size() * sizeof(BandInfo));
-    const size_t o_wrows  = align(o_sched + sched.size() * sizeof(RowSched));
-    const size_t o_crows  = align(o_wrows + wrows.size() * sizeof(RowW));
-    const size_t total    = align(o_crows + crows.size() * sizeof(RowCtl));
+    std::vector<RowRec> recs(wrows.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+        recs[i].w   = wrows[i];
+        recs[i].ctl = crows[i];
+    }
+    const size_t o_recs   = align(o_sched + sched.size() * sizeof(RowSched));
+    const size_t total    = align(o_recs + recs.size() * sizeof(RowRec));
     std::vector<char> host(total, 0);
     memcpy(&host[o_strips], strips.data(), strips.size() * sizeof(StripInfo));
     memcpy(&host[o_bands], bands.data(), bands.size() * sizeof(BandInfo));
     memcpy(&host[o_sched], sched.data(), sched.size() * sizeof(RowSched));
-    memcpy(&host[o_wrows], wrows.data(), wrows.size() * sizeof(RowW));
-    memcpy(&host[o_crows], crows.data(), crows.size() * sizeof(RowCtl));
+    memcpy(&host[o_recs], recs.data(), recs.size() * sizeof(RowRec));
     void *dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) return false;
     if (hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1242,9 +1337,9 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     out->t.sched    = (const RowSched *)((char *)dev + o_sched);
     out->t.n_strips = (int)strips.size();
     out->t.n_bands  = (int)bands.size();
-    out->m.w        = (const RowW *)((char *)dev + o_wrows);
-    out->m.ctl      = (const RowCtl *)((char *)dev + o_crows);
+    out->m.rec      = (const RowRec *)((char *)dev + o_recs);
     out->m_ok       = m_ok && wrows.size() == sched.size();
+    out->m_ovf      = uses_ovf;
     out->band_rows  = band_rows;
     return true;
 }
@@ -1382,23 +1477,30 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
     return hipGetLastError();
 }
 
-template <int M>
-static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
-                              const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+template <int M, bool kOvf>
+static hipError_t LaunchModeMO(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
     const int hgroups = (s->plan.h_width + 3) / 4;
     const size_t lds  = ((size_t)2 * (kStripCols + 4 * hgroups) * 4 + (size_t)hgroups * ss->hrow * 4) * sizeof(float) +
                        (size_t)ss->hrow * sizeof(int);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamMKernel<M>,
+        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamMKernel<M, kOvf>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
-    hipLaunchKernelGGL(ScaleStreamMKernel<M>, grid, dim3(kThreads), lds, stream, s->dev, v.t, v.m, blend, batch,
+    hipLaunchKernelGGL((ScaleStreamMKernel<M, kOvf>), grid, dim3(kThreads), lds, stream, s->dev, v.t, v.m, blend, batch,
                        ss->tile_state, ss->hrow, hgroups);
     return hipGetLastError();
+}
+
+template <int M>
+static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                              const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    return v.m_ovf ? LaunchModeMO<M, true>(s, ss, v, blend, batch, stream)
+                   : LaunchModeMO<M, false>(s, ss, v, blend, batch, stream);
 }
 
 template <int M, int TAPS>

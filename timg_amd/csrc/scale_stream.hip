@@ -434,17 +434,18 @@ __device__ bool RunTile(const TileCtx &c) {
 }
 
 // One kernel per channel set (each gets its own register budget).  They run
-// back to back on the stream; tile_state[tile] says which tiles are still open:
+// back to back on the stream; tile_state[tile] says which tiles are still open (it holds the
+// generation number of the scale call that completed the tile: no memset per call):
 // 0 = not produced yet, 1 = done.  A kernel skips tiles that are done and marks
 // the ones it completes.
 template <int M>
 __global__ void __launch_bounds__(kThreads, M == kFull ? 2 : (M == kOpaque ? TIMG_OPAQUE_WAVES : 3))
 ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch,
-                  int *tile_state, int hrow) {
+                  int *tile_state, int gen, int hrow) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int fail;
     const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (tile_state[tile] != 0) return;  // uniform: whole workgroup leaves
+    if (tile_state[tile] == gen) return;  // done by an earlier kernel of this call (uniform: whole workgroup leaves)
     TileCtx c;
     c.plan       = &plan;
     c.blend      = &blend;
@@ -472,7 +473,7 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
     }
     if (threadIdx.x == 0) fail = 0;
     BlockSync();
-    if (RunTile<M>(c) && threadIdx.x == 0) tile_state[tile] = 1;
+    if (RunTile<M>(c) && threadIdx.x == 0) tile_state[tile] = gen;
 }
 
 
@@ -607,13 +608,13 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
 template <int M, bool kOvf>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
-                   int *tile_state, int hrow, int hgroups) {
+                   int *tile_state, int gen, int hrow, int hgroups) {
     static_assert(M == kOpaque || M == kPremult, "three or four channels");
     constexpr int kCh = M == kOpaque ? 3 : 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int fail;
     const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (tile_state[tile] != 0) return;  // uniform: whole workgroup leaves
+    if (tile_state[tile] == gen) return;  // done by an earlier kernel of this call (uniform: whole workgroup leaves)
     const StripInfo si = LoadConstant(tab.strips + blockIdx.x);
     const BandInfo bi  = LoadConstant(tab.bands + blockIdx.y);
     const int f        = blockIdx.z;
@@ -892,7 +893,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     if (M == kOpaque) ok = ok && (amin >> 24) == 0xffu;
     if (__any(!ok) && (tid & 63) == 0) fail = 1;
     BlockSync();
-    if (fail == 0 && tid == 0) tile_state[tile] = 1;
+    if (fail == 0 && tid == 0) tile_state[tile] = gen;
 }
 
 // ===================================================================================
@@ -944,7 +945,7 @@ __device__ __forceinline__ float FromPartner(float v) {
 template <int M, int TAPS>
 __global__ void __launch_bounds__(kThreadsH)
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
-                   int win, int w4) {
+                   int gen, int win, int w4) {
     // One row buffer of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at
     // index n >> 2.  The decoder's lanes hold 4 consecutive pixels each, so plane q is written
     // by consecutive lanes at consecutive 16-byte slots (no bank conflicts; a linear layout
@@ -955,7 +956,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     constexpr int kHc     = M == kFull ? 7 : 4;   // channels of the horizontal gather
     constexpr int kVc     = M == kFull ? 4 : 2;   // channels a lane carries through the vertical pass
     const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (tile_state[tile] != 0) return;  // uniform: whole workgroup leaves
+    if (tile_state[tile] == gen) return;  // done by an earlier kernel of this call (uniform: whole workgroup leaves)
     const StripInfo si    = LoadConstant(tab.strips + blockIdx.x);
     const BandInfo bi     = LoadConstant(tab.bands + blockIdx.y);
     const RowSched *sched = tab.sched + bi.sched;
@@ -1146,7 +1147,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     }
     if (!good) return;
     if (M != kFull && __any(!ok)) return;
-    if (tid == 0) tile_state[tile] = 1;
+    if (tid == 0) tile_state[tile] = gen;
 }
 
 }  // namespace
@@ -1169,6 +1170,7 @@ struct StreamSchedule {
     bool hfirst     = false;    // horizontal-first plan: ScaleStreamHKernel
     int hwin        = 0;        // ... widest source window of a strip (multiple of 4)
     int *tile_state = nullptr;  // device, grown on demand
+    int gen         = 0;        // generation of the current scale call (tile_state holds generations)
     size_t tile_cap = 0;
 };
 
@@ -1473,7 +1475,7 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
     }
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL(ScaleStreamKernel<M>, grid, dim3(kThreads), lds, stream, s->dev, v.t, blend,
-                       batch, ss->tile_state, ss->hrow);
+                       batch, ss->tile_state, ss->gen, ss->hrow);
     return hipGetLastError();
 }
 
@@ -1492,7 +1494,7 @@ static hipError_t LaunchModeMO(const timg_hip_scaler *s, const StreamSchedule *s
     }
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL((ScaleStreamMKernel<M, kOvf>), grid, dim3(kThreads), lds, stream, s->dev, v.t, v.m, blend, batch,
-                       ss->tile_state, ss->hrow, hgroups);
+                       ss->tile_state, ss->gen, ss->hrow, hgroups);
     return hipGetLastError();
 }
 
@@ -1519,7 +1521,7 @@ static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *s
     }
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
-                       batch, ss->tile_state, ss->hwin, w4);
+                       batch, ss->tile_state, ss->gen, ss->hwin, w4);
     return hipGetLastError();
 }
 
@@ -1552,10 +1554,18 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
         ss->tile_cap   = 0;
         hipError_t e   = hipMalloc((void **)&ss->tile_state, tiles * sizeof(int));
         if (e != hipSuccess) return e;
+        // (once per allocation, ordered in front of the kernels on this stream)
+        if ((e = hipMemsetAsync(ss->tile_state, 0, tiles * sizeof(int), stream)) != hipSuccess) return e;
         ss->tile_cap = tiles;
+        ss->gen      = 0;
     }
-    hipError_t e = hipMemsetAsync(ss->tile_state, 0, tiles * sizeof(int), stream);
-    if (e != hipSuccess) return e;
+    // a tile is done when it carries this call's generation: nothing to clear per call
+    if (++ss->gen == 0x7fffffff) {
+        hipError_t e0 = hipMemsetAsync(ss->tile_state, 0, ss->tile_cap * sizeof(int), stream);
+        if (e0 != hipSuccess) return e0;
+        ss->gen = 1;
+    }
+    hipError_t e = hipSuccess;
     // cheapest channel set first; tiles whose data breaks its assumption stay
     // open for the next kernel (stream_cfg[3] can skip the optimistic passes)
     const int first_mode = s->stream_cfg[3];

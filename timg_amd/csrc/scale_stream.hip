@@ -512,8 +512,9 @@ struct RowCtl {
     int done_y;
     float alpha_sum;  // vertical sum of an all-opaque alpha column of the completing row
 };
-struct RowRec {  // 32 bytes: one s_load_dwordx8 per source row, from a pointer that just advances
+struct RowRec {  // 48 bytes through the scalar cache per source row, from a pointer that just advances
     RowW w;
+    float keep[kMSlots];  // 0 on the source row that STARTS an output row in the slot, else 1 (see the sums)
     RowCtl ctl;
 };
 struct MTables {
@@ -683,14 +684,15 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         next_off = min(next_off + row_step_b, last_off);  // uniform
     };
 
-    f2v acc[kPix][kCh][2];  // the four matrix slots as pairs (0,1) (2,3): packed adds
+    float acc[kPix][kCh][kMSlots];  // the four matrix slots; updated as pairs (0,1) (2,3) by packed fmas
     float ovf[kPix][kCh];   // the overflow row
 #pragma unroll
     for (int p = 0; p < kPix; ++p)
 #pragma unroll
         for (int ch = 0; ch < kCh; ++ch) {
-            acc[p][ch][0] = acc[p][ch][1] = f2v{0.0f, 0.0f};
-            ovf[p][ch]                    = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMSlots; ++k) acc[p][ch][k] = 0.0f;
+            ovf[p][ch] = 0.0f;
         }
     uint32_t amin = 0xffffffffu;  // kOpaque: minimum over the pixels seen (alpha is the top byte)
     bool ok       = true;
@@ -709,6 +711,8 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         }
         const RowW rw    = rec_next.w;
         const RowCtl ctl = rec_next.ctl;
+        // (keep0, keep1) (keep2, keep3) as scalar register pairs
+        const f2v keep_lo = {rec_next.keep[0], rec_next.keep[1]}, keep_hi = {rec_next.keep[2], rec_next.keep[3]};
         asm volatile("" ::"s"(ctl.flags), "s"(rw.w[0]));  // the record is complete here ...
         __builtin_amdgcn_sched_barrier(0);
         rec_next = LoadConstant(++rec_ptr);  // ... before the next request goes out
@@ -731,14 +735,18 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         const uint32_t qs[kPix] = {q.x, q.y, q.z, q.w};
         // kBatch pixels at a time: decode, products, sums (the products' registers are the
         // kernel's peak, so only one batch of them is in flight)
+#ifdef TIMG_M_BATCH
+        constexpr int kBatch = M == kOpaque ? TIMG_M_BATCH : 1;
+#else
         constexpr int kBatch = M == kOpaque ? 2 : 1;
+#endif
 #pragma unroll
         for (int p0 = 0; p0 < kPix; p0 += kBatch) {
             if (p0) __builtin_amdgcn_sched_barrier(0);
             float d[kBatch][kCh];
             if (M == kOpaque) {
                 // u8 * (1/255) for the six colour bytes of two pixels as three packed multiplies
-                static_assert(M != kOpaque || kBatch == 2, "pairs");
+                static_assert(M != kOpaque || kBatch <= 2, "one or two pixels");
                 const uint32_t pa = qs[p0], pb = qs[p0 + (kBatch > 1 ? 1 : 0)];
                 const f2v k2 = {1.0f / 255.0f, 1.0f / 255.0f};
                 const f2v m0 = f2v{(float)(pa & 0xffu), (float)((pa >> 8) & 0xffu)} * k2;
@@ -769,12 +777,25 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #ifndef TIMG_M_NOSPLIT
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            // acc = acc * keep + prod as ONE packed fma per accumulator pair.
+            // keep is 1 (acc * 1 is exact, so this is the separately rounded acc + prod of the chain) or,
+            // on the source row that starts a new output row in the slot, 0: the sum restarts as 0 + prod
+            // == prod.  So a completed slot is never cleared and nothing on the completion path writes an
+            // accumulator -- written as C++ adds plus per-slot clearing, the sums landed in fresh
+            // registers and the (hot) path without a completed row copied all 24 accumulator pairs back,
+            // 24 v_mov_b64 per source row.
 #pragma unroll
             for (int b = 0; b < kBatch; ++b)
 #pragma unroll
                 for (int ch = 0; ch < kCh; ++ch) {
-                    acc[p0 + b][ch][0] = acc[p0 + b][ch][0] + f2v{prod[b][ch].x, prod[b][ch].y};
-                    acc[p0 + b][ch][1] = acc[p0 + b][ch][1] + f2v{prod[b][ch].z, prod[b][ch].w};
+                    const f2v lo = {prod[b][ch].x, prod[b][ch].y}, hi = {prod[b][ch].z, prod[b][ch].w};
+                    float *a      = acc[p0 + b][ch];
+                    const f2v n01 = __builtin_elementwise_fma(f2v{a[0], a[1]}, keep_lo, lo);
+                    const f2v n23 = __builtin_elementwise_fma(f2v{a[2], a[3]}, keep_hi, hi);
+                    a[0] = n01.x;
+                    a[1] = n01.y;
+                    a[2] = n23.x;
+                    a[3] = n23.y;
                 }
             if (kOvf && (ctl.flags & 1)) {  // wave-uniform: the overflow row
 #pragma unroll
@@ -798,10 +819,10 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #pragma unroll
             for (int p = 0; p < kPix; ++p) {
                 float4 v;
-                v.x = acc[p][0][C >> 1][C & 1];
-                v.y = acc[p][1][C >> 1][C & 1];
-                v.z = acc[p][2][C >> 1][C & 1];
-                v.w = kCh > 3 ? acc[p][kCh > 3 ? 3 : 0][C >> 1][C & 1] : ctl.alpha_sum;
+                v.x = acc[p][0][C];
+                v.y = acc[p][1][C];
+                v.z = acc[p][2][C];
+                v.w = kCh > 3 ? acc[p][kCh > 3 ? 3 : 0][C] : ctl.alpha_sum;
                 dst[p] = v;
             }
             if (move) {  // the overflow row continues in the slot that has just been freed
@@ -809,20 +830,36 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
                 for (int p = 0; p < kPix; ++p)
 #pragma unroll
                     for (int ch = 0; ch < kCh; ++ch) {
-                        acc[p][ch][C >> 1][C & 1] = ovf[p][ch];
+                        acc[p][ch][C] = ovf[p][ch];
                         ovf[p][ch]                = 0.0f;
                     }
-            } else {
+            } else if (kOvf) {  // (without an overflow row nothing is cleared: the next row in this slot starts with keep == 0)
 #pragma unroll
                 for (int p = 0; p < kPix; ++p)
 #pragma unroll
-                    for (int ch = 0; ch < kCh; ++ch) acc[p][ch][C >> 1][C & 1] = 0.0f;
+                    for (int ch = 0; ch < kCh; ++ch) acc[p][ch][C] = 0.0f;
             }
         };
-        if (code == 1) finish_slot(std::integral_constant<int, 0>());
+        if (!kOvf) {
+            // No overflow row: the completed slot is only READ here (it restarts through keep == 0), and it
+            // is read through selects on the uniform slot number -- one code path.  (Four specialised
+            // paths that only read get merged by the compiler into ONE path indexing a copy of the
+            // accumulators in scratch memory, with a store behind every update in the hot loop.)
+            const bool s0 = code == 1, s1 = code == 2, s2 = code == 3;
+            auto pick = [&](const float a[kMSlots]) { return s0 ? a[0] : s1 ? a[1] : s2 ? a[2] : a[3]; };
+#pragma unroll
+            for (int p = 0; p < kPix; ++p) {
+                float4 v;
+                v.x = pick(acc[p][0]);
+                v.y = pick(acc[p][1]);
+                v.z = pick(acc[p][2]);
+                v.w = kCh > 3 ? pick(acc[p][kCh > 3 ? 3 : 0]) : ctl.alpha_sum;
+                dst[p] = v;
+            }
+        } else if (code == 1) finish_slot(std::integral_constant<int, 0>());
         else if (code == 2) finish_slot(std::integral_constant<int, 1>());
         else if (code == 3) finish_slot(std::integral_constant<int, 2>());
-        else if (code == 4 || !kOvf) finish_slot(std::integral_constant<int, 3>());
+        else if (code == 4) finish_slot(std::integral_constant<int, 3>());
         else {
 #pragma unroll
             for (int p = 0; p < kPix; ++p) {
@@ -1181,6 +1218,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     std::vector<RowSched> sched;
     std::vector<RowW> wrows;    // matrix-slot schedule, indexed like sched
     std::vector<RowCtl> crows;
+    std::vector<float> keeps;  // [row][kMSlots]
     bool m_ok = p.vertical_first, uses_ovf = false;
     for (int oy = 0; oy < p.out_h; oy += band_rows) {
         BandInfo b;
@@ -1240,6 +1278,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
             const size_t base = wrows.size();
             wrows.resize(base + (size_t)(b.r1 - b.r0 + 1), wblank);
             crows.resize(base + (size_t)(b.r1 - b.r0 + 1), cblank);
+            keeps.resize((base + (size_t)(b.r1 - b.r0 + 1)) * kMSlots, 1.0f);
             int slot_y[kMSlots + 1];
             for (int &v : slot_y) v = -1;
             int next_y = b.oy0;
@@ -1253,6 +1292,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
                         m_ok = false;
                         break;
                     }
+                    if (k < kMSlots) keeps[(base + (size_t)(r - b.r0)) * kMSlots + k] = 0.0f;  // the sum restarts here
                     slot_y[k] = next_y++;
                 }
                 for (int k = 0; k <= kMSlots && m_ok; ++k) {
@@ -1310,6 +1350,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
         memset(&cblank, 0, sizeof(cblank));
         wrows.push_back(wblank);
         crows.push_back(cblank);
+        keeps.resize(keeps.size() + kMSlots, 1.0f);
     }
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_strips = 0;
@@ -1319,6 +1360,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     for (size_t i = 0; i < recs.size(); ++i) {
         recs[i].w   = wrows[i];
         recs[i].ctl = crows[i];
+        for (int k = 0; k < kMSlots; ++k) recs[i].keep[k] = keeps[i * kMSlots + k];
     }
     const size_t o_recs   = align(o_sched + sched.size() * sizeof(RowSched));
     const size_t total    = align(o_recs + recs.size() * sizeof(RowRec));

@@ -372,6 +372,38 @@ def test_horizontal_first_streaming_kernel(hip, oracle, kind, sw, sh, dw, dh):
     sc.close()
 
 
+def test_all_four_matrix_kernel_instantiations(hip, oracle):
+    """ScaleStreamMKernel<opaque | premultiplied, without | with the overflow row>: each of the four is
+    a separately compiled kernel with its own register budget and its own ring of rows in flight
+    (check_ring_isa.py proves the ring on the assembly; this proves the bytes).  The shapes are picked
+    by what the scaler reports, so the test fails if none of them reaches an instantiation."""
+    shapes = [(1280, 720, 800, 450), (640, 480, 600, 450), (1000, 1000, 990, 999), (1000, 1000, 700, 700),
+              (1000, 1000, 800, 800), (1000, 1000, 900, 900), (300, 300, 290, 290), (1000, 1000, 600, 600),
+              (900, 700, 640, 500), (1024, 1024, 1000, 1000), (777, 555, 500, 400),
+              # (ratios whose plans have five output rows live at once)
+              (400, 400, 57, 57), (480, 480, 70, 70), (1000, 1000, 160, 160), (720, 720, 110, 110),
+              (1366, 768, 200, 112), (2000, 1400, 300, 200)]
+    seen = set()
+    for sw, sh, dw, dh in shapes:
+        sc = hip.scaler(sw, sh, dw, dh)
+        info = sc.info()
+        if not (info["streaming_ok"] and info["matrix_kernel"]):
+            sc.close()
+            continue
+        sc.set_kernel(2)
+        for kind in ("photo", "alpha"):
+            if (kind, info["matrix_overflow_row"]) in seen and sw > 1000:
+                continue
+            src = synth.make(kind, sw, sh, seed=sw + dh)
+            got = np.empty((dh, dw, 4), np.uint8)
+            hip.scale_blend(sc, src, got)
+            want = oracle.scale(src, dw, dh)
+            assert np.array_equal(got, want), (sw, sh, dw, dh, kind, info, int(np.count_nonzero(got != want)))
+            seen.add((kind, info["matrix_overflow_row"]))
+        sc.close()
+    assert seen == {("photo", 0), ("photo", 1), ("alpha", 0), ("alpha", 1)}, seen
+
+
 @pytest.mark.parametrize("sw,sh,dw,dh", [(1366, 768, 200, 112), (1366, 768, 455, 256), (999, 1333, 333, 444),
                                          (1023, 767, 341, 255), (6, 1000, 3, 100), (5, 500, 2, 100),  # vertical-first
                                          (1001, 999, 100, 100), (1275, 1650, 150, 194), (2561, 1441, 320, 180),

@@ -1,0 +1,94 @@
+"""The matrix scale kernel keeps source rows in flight in registers the compiler believes are already
+loaded (timg_amd/csrc/scale_stream.hip, issue_next_row).  timg_amd/csrc/check_ring_isa.py proves on the
+generated assembly that nothing touches such a register between its load and its wait; the Makefile runs
+it on every build.  Here: the checker itself catches the failure modes seen in round 2, and the
+assembly of the library that was actually built passes."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "timg_amd", "csrc", "check_ring_isa.py")
+BUILT = os.path.join(ROOT, "timg_amd", "csrc", "build", "scale_stream-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+HEAD = """\
+_Z6kernelv:
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[2:5], v[20:21], off
+\t;;#ASMEND
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[6:9], v[20:21], off
+\t;;#ASMEND
+.LBB0_1:
+"""
+TAIL = """\
+\ts_cbranch_scc1 .LBB0_1
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0) ; ring all
+\t;;#ASMEND
+\tv_mov_b32_e32 v30, v6
+\ts_endpgm
+.Lfunc_end0:
+"""
+STEP = """\
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(1) ; ring v[{a}:{b}]
+\t;;#ASMEND
+\tv_cvt_f32_ubyte0_e32 v40, v{a}
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[{a}:{b}], v[20:21], off
+\t;;#ASMEND
+"""
+
+
+def run(tmp_path, body):
+    path = tmp_path / "k.s"
+    path.write_text(HEAD + textwrap.dedent(body) + TAIL)
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    return r.returncode, r.stdout
+
+
+def test_clean_ring_passes(tmp_path):
+    rc, out = run(tmp_path, STEP.format(a=2, b=5) + STEP.format(a=6, b=9))
+    assert rc == 0, out
+
+
+def test_copy_before_the_wait_is_caught(tmp_path):
+    # (what a tied asm operand compiled into: the set is copied, THEN waited for)
+    rc, out = run(tmp_path, "\tv_mov_b64_e32 v[30:31], v[2:3]\n" + STEP.format(a=2, b=5) + STEP.format(a=6, b=9))
+    assert rc == 1 and "v[2:5]" in out
+
+
+def test_back_edge_copy_is_caught(tmp_path):
+    # (a fifth register set: the reloaded set is copied into another one at the end of the loop body)
+    rc, out = run(tmp_path, STEP.format(a=2, b=5) + STEP.format(a=6, b=9) + "\tv_mov_b64_e32 v[10:11], v[6:7]\n")
+    assert rc == 1 and "v[6:9]" in out
+
+
+def test_spill_of_a_set_in_flight_is_caught(tmp_path):
+    rc, out = run(tmp_path, STEP.format(a=2, b=5) + "\tscratch_store_dwordx4 off, v[2:5], off offset:56\n" + STEP.format(a=6, b=9))
+    assert rc == 1 and "scratch_store" in out
+
+
+def test_clobber_on_a_side_path_is_caught(tmp_path):
+    body = STEP.format(a=2, b=5) + "\ts_cbranch_vccz .LBB0_9\n\tv_mov_b32_e32 v3, 0\n.LBB0_9:\n" + STEP.format(a=6, b=9)
+    rc, out = run(tmp_path, body)
+    assert rc == 1 and "v_mov_b32_e32 v3, 0" in out
+
+
+def test_loads_without_ring_markers_fail(tmp_path):
+    path = tmp_path / "k.s"
+    path.write_text(HEAD + "\ts_endpgm\n.Lfunc_end0:\n")
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no ring waits" in r.stdout
+
+
+def test_built_library_passes():
+    if not os.path.exists(BUILT):
+        pytest.skip("no kept assembly (library built elsewhere)")
+    r = subprocess.run([sys.executable, CHECK, BUILT], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "4 kernels" in r.stdout

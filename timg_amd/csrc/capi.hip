@@ -17,6 +17,7 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream);
 bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not);
 void ReleaseStreamSchedule(timg_hip_scaler *s);
+int StreamShapeBits(const timg_hip_scaler *s);
 }  // namespace timg_amd
 
 DevBlend MakeDevBlend(const timg_hip_blend *b) {
@@ -230,7 +231,7 @@ int timg_hip_scaler_info(const timg_hip_scaler *s, int info[8]) {
     info[3] = s->plan.v_widest;
     info[4] = s->plan.h_filter;
     info[5] = s->plan.v_filter;
-    info[6] = s->streaming_ok;
+    info[6] = s->streaming_ok ? 1 | (timg_amd::StreamShapeBits(s) << 1) : 0;
     info[7] = s->plan.max_active_rows;
     return TIMG_HIP_OK;
 }

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""check_ring_isa.py <device assembly of scale_stream.hip>
+
+ScaleStreamMKernel keeps source rows in flight in a ring of register sets that are loaded by inline
+asm (`global_load_dwordx4`) and released by an inline-asm `s_waitcnt vmcnt(n) ; ring v[a:b]`.  The
+compiler does not know that such a load completes later: this script proves, on the generated code,
+that on no path between a set's load and its wait an instruction outside the asm statements names one
+of its registers (a copy for a tied operand, a live-range split, a back-edge copy into another register
+set would read data that has not arrived, or be overwritten when it does).
+
+Method: basic blocks from labels and branches, forward may-analysis of "sets in flight" (union over
+predecessors, to a fixed point), then every instruction is checked against the sets in flight before it.
+
+Exit status 0: every kernel that uses the ring is clean.  1: a violation (printed)."""
+import re
+import sys
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+LOAD = re.compile(r"global_load_dwordx4 v\[(\d+):(\d+)\]")
+WAIT = re.compile(r"s_waitcnt vmcnt\(\d+\) ; ring (.*)")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+class Block:
+    def __init__(self, label):
+        self.label, self.ops, self.succ_labels, self.falls = label, [], [], True
+        self.succ, self.entry = [], frozenset()
+
+
+def parse_blocks(lines):
+    """ops: (line number, kind, payload) with kind in load / wait / waitall / instr."""
+    blocks = [Block(None)]
+    in_asm = False
+    for no, line in lines:
+        code = line.strip()
+        if code.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if code.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if in_asm:
+            m = LOAD.match(code)
+            if m:
+                blocks[-1].ops.append((no, "load", (int(m.group(1)), int(m.group(2)))))
+            m = WAIT.match(code)
+            if m:
+                what = m.group(1).strip()
+                blocks[-1].ops.append((no, "waitall", None) if what == "all" else (no, "wait", regs_of(what)))
+            continue
+        m = re.match(r"^([.\w$]+):", code)
+        if m:
+            blocks.append(Block(m.group(1)))
+            continue
+        if not code or code[0] in ";.":
+            continue
+        instr = code.split(";")[0].strip()
+        op = instr.split()[0]
+        if op == "s_branch":
+            blocks[-1].succ_labels.append(instr.split()[1])
+            blocks[-1].falls = False
+            blocks.append(Block(None))
+        elif op.startswith("s_cbranch"):
+            blocks[-1].succ_labels.append(instr.split()[1])
+            blocks.append(Block(None))
+        elif op == "s_endpgm":
+            blocks[-1].falls = False
+            blocks.append(Block(None))
+        else:
+            blocks[-1].ops.append((no, "instr", instr))
+    by_label = {b.label: b for b in blocks if b.label}
+    for i, b in enumerate(blocks):
+        b.succ = [by_label[l] for l in b.succ_labels if l in by_label]
+        if b.falls and i + 1 < len(blocks):
+            b.succ.append(blocks[i + 1])
+    return blocks
+
+
+def transfer(state, op, report=None):
+    no, kind, payload = op
+    if kind == "load":
+        return state | {payload}
+    if kind == "wait":
+        return frozenset(t for t in state if not (set(range(t[0], t[1] + 1)) & payload))
+    if kind == "waitall":
+        return frozenset()
+    if report is not None and state:
+        used = regs_of(payload)
+        for lo, hi in state:
+            if used & set(range(lo, hi + 1)):
+                report.append((no, payload, "v[%d:%d]" % (lo, hi)))
+    return state
+
+
+def check_kernel(lines):
+    blocks = parse_blocks(lines)
+    loads = sum(1 for b in blocks for o in b.ops if o[1] == "load")
+    waits = sum(1 for b in blocks for o in b.ops if o[1] in ("wait", "waitall"))
+    if loads == 0:
+        return 0, 0, []
+    work = [blocks[0]]
+    seen = {id(blocks[0])}
+    while work:
+        b = work.pop()
+        state = b.entry
+        for op in b.ops:
+            state = transfer(state, op)
+        for s in b.succ:
+            merged = s.entry | state
+            if merged != s.entry or id(s) not in seen:
+                s.entry = merged
+                seen.add(id(s))
+                work.append(s)
+    bad = []
+    for b in blocks:
+        if id(b) not in seen:
+            continue
+        state = b.entry
+        for op in b.ops:
+            state = transfer(state, op, bad)
+    return loads, waits, bad
+
+
+def main(path):
+    kernels, cur = [], None
+    for no, line in enumerate(open(path), 1):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = []
+            kernels.append((m.group(1), cur))
+        elif line.startswith(".Lfunc_end"):
+            cur = None
+        elif cur is not None:
+            cur.append((no, line.rstrip("\n")))
+    status, checked = 0, 0
+    for name, lines in kernels:
+        loads, waits, bad = check_kernel(lines)
+        if loads == 0:
+            continue
+        checked += 1
+        if waits == 0:
+            print("%s: asm loads but no ring waits" % name)
+            status = 1
+        for no, instr, ring in bad[:20]:
+            print("%s:%d: '%s' names %s while its load is in flight" % (path, no, instr, ring))
+        if bad:
+            print("%s: %d instructions touch a register set in flight" % (name, len(bad)))
+            status = 1
+    if checked == 0:
+        print("%s: no kernel with a register ring found" % path)
+        status = 1
+    if status == 0:
+        print("check_ring_isa: %d kernels, no instruction touches a register set in flight" % checked)
+    return status
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

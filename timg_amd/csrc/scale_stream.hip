@@ -606,8 +606,19 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
 // never have more than four.
 // (waves per SIMD pinned to exactly 3 -- LDS allows no more: the compiler then uses the 168 registers
 // it may have instead of squeezing into 128 for an occupancy the kernel cannot reach)
+// The opaque set without the overflow row needs 115 registers: four workgroups per CU with ONE staging
+// row (a second barrier per completed row frees it), 2 % faster than three with two staging rows.  The other
+// instantiations spill at 128 registers and stay at three -- except the premultiplied set WITH the
+// overflow row (rare: alpha frames at a ratio with five live output rows), which spills even at 168 and
+// runs two per CU: a spilled kernel is not just slower here, the compiler spilled ring registers whose
+// loads were still in flight (see issue_next_row; check_ring_isa.py caught it).
+template <int M, bool kOvf> struct MKernelShape {
+    static constexpr int kWaves = (M == kOpaque && !kOvf) ? 4 : (M == kPremult && kOvf) ? 2 : 3;  // per SIMD = workgroups per CU
+    static constexpr int kStage = kWaves == 4 ? 1 : 2;              // staging rows
+};
 template <int M, bool kOvf>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(kThreads)
+    __attribute__((amdgpu_waves_per_eu(MKernelShape<M, kOvf>::kWaves, MKernelShape<M, kOvf>::kWaves)))
 ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
                    int *tile_state, int gen, int hrow, int hgroups) {
     static_assert(M == kOpaque || M == kPremult, "three or four channels");
@@ -622,11 +633,12 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     const int tid      = threadIdx.x;
     // LDS: two staging rows of (strip + zeroed pad for the padded taps) float4 columns, the
     // horizontal weights as [group][output] float4, the byte offset of every output's first tap
-    const int stage_cols = kStripCols + 4 * hgroups;
-    float *stage         = lds;
-    float *hw            = stage + (size_t)2 * stage_cols * 4;
+    constexpr int kStageM = MKernelShape<M, kOvf>::kStage;
+    const int stage_cols  = kStripCols + 4 * hgroups;
+    float *stage          = lds;
+    float *hw             = stage + (size_t)kStageM * stage_cols * 4;
     int *hbase           = reinterpret_cast<int *>(hw + (size_t)hgroups * hrow * 4);
-    for (int i = tid; i < 2 * 4 * hgroups; i += kThreads) {
+    for (int i = tid; i < kStageM * 4 * hgroups; i += kThreads) {
         const int row = i / (4 * hgroups), col = kStripCols + i % (4 * hgroups);
         *reinterpret_cast<float4 *>(stage + ((size_t)row * stage_cols + col) * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
@@ -677,6 +689,14 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     // loads + 0.32 ms of arithmetic = 0.72 ms).  Memory operations complete in order, so "at most
     // kDepth - 1 operations outstanding" means the oldest load of the ring has arrived (stores issued in
     // between only make the wait more conservative).
+    // THE HAZARD of this construction: the compiler believes the load's result is there when the asm
+    // statement ends.  Any instruction it places between the load and the ring register's s_waitcnt that
+    // touches the register (a copy for a tied operand, a live-range split, a back-edge copy into another
+    // register set) reads or clobbers data still in flight.  Nothing in the language forbids that, so
+    // the BUILD checks the generated code: check_ring_isa.py walks the kernel's assembly and fails the
+    // build if any instruction outside the asm statements names a ring register between its load and
+    // its wait (two arrangements tried in round 2 -- requesting the next row before a completed row's
+    // horizontal pass, and a fifth register set -- compiled into exactly such copies).
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     auto issue_next_row = [&](u4v &q) __attribute__((always_inline)) {
         const uint8_t *p = frame_lane + next_off;
@@ -763,7 +783,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
                 for (int b = 0; b < kBatch; ++b) DecodeMode<M>(qs[p0 + b], d[b]);
             }
 #if defined(TIMG_MABL) && TIMG_MABL >= 2
-            if (p0 == 0) acc[0][0][0] = acc[0][0][0] + f2v{d[0][0], d[0][1]};  // (ablation: keep the decode alive)
+            if (p0 == 0) acc[0][0][0] = acc[0][0][0] + d[0][0] + d[0][1];  // (ablation: keep the decode alive)
             continue;
 #endif
             // the batch's MFMAs back to back, then its sums: a sum issued right behind its MFMA
@@ -811,7 +831,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         if (code == 0) return true;  // wave- and block-uniform
 
         // an output row is complete: its column sums go to a staging row
-        float *row = stage + (size_t)(ev & 1) * stage_cols * 4;
+        float *row = stage + (size_t)(ev & (kStageM - 1)) * stage_cols * 4;
         float4 *dst = reinterpret_cast<float4 *>(row + (size_t)tid * kPix * 4);
         const bool move = kOvf && (ctl.flags & 0x80) != 0;
         auto finish_slot = [&](auto comp_tag) {
@@ -880,6 +900,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #if !defined(TIMG_MABL) || TIMG_MABL < 1
         HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
 #endif
+        if (kStageM == 1) BlockSync();  // the single staging row is free again
         ++ev;
         return true;
     };
@@ -909,7 +930,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     }
 #define TIMG_M_STEP(Q, K)                                                              \
     if (left < K + 1) break;                                                           \
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q) : "n"(kDepth - 1) : "memory");        \
+    asm volatile("s_waitcnt vmcnt(%1) ; ring %0" : "+v"(Q) : "n"(kDepth - 1) : "memory"); \
     if (!row_step(make_uint4(Q.x, Q.y, Q.z, Q.w), 0)) return;                          \
     issue_next_row(Q);
     for (int left = r1 - bi.r0 + 1; left > 0; left -= kDepth) {  // (rows still to do)
@@ -925,7 +946,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         }
     }
     // (loads still in flight must land before their registers mean anything else)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : : "memory");
 #undef TIMG_M_STEP
     if (M == kOpaque) ok = ok && (amin >> 24) == 0xffu;
     if (__any(!ok) && (tid & 63) == 0) fail = 1;
@@ -1492,6 +1513,13 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     return true;
 }
 
+// bit 0: the matrix-core kernel serves this plan, bit 1: with the overflow row compiled in
+int StreamShapeBits(const timg_hip_scaler *s) {
+    const StreamSchedule *ss = (const StreamSchedule *)s->stream_tables;
+    if (!ss) return 0;
+    return (ss->v[0].m_ok ? 1 : 0) | (ss->v[0].m_ovf || ss->v[1].m_ovf ? 2 : 0);
+}
+
 void ReleaseStreamSchedule(timg_hip_scaler *s) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
     if (!ss) return;
@@ -1525,7 +1553,7 @@ template <int M, bool kOvf>
 static hipError_t LaunchModeMO(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                                const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
     const int hgroups = (s->plan.h_width + 3) / 4;
-    const size_t lds  = ((size_t)2 * (kStripCols + 4 * hgroups) * 4 + (size_t)hgroups * ss->hrow * 4) * sizeof(float) +
+    const size_t lds  = ((size_t)MKernelShape<M, kOvf>::kStage * (kStripCols + 4 * hgroups) * 4 + (size_t)hgroups * ss->hrow * 4) * sizeof(float) +
                        (size_t)ss->hrow * sizeof(int);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {

@@ -134,7 +134,10 @@ class Scaler:
         self.owner._check(self.owner.L.timg_hip_scaler_info(self.handle, a))
         keys = ["vertical_first", "h_widest", "v_is_gather", "v_widest", "h_filter",
                 "v_filter", "streaming_ok", "max_active_rows"]
-        return dict(zip(keys, list(a)))
+        d = dict(zip(keys, list(a)))
+        bits = d["streaming_ok"]
+        d.update(streaming_ok=bits & 1, matrix_kernel=(bits >> 1) & 1, matrix_overflow_row=(bits >> 2) & 1)
+        return d
 
     def set_kernel(self, which: int):
         self.owner._check(self.owner.L.timg_hip_scaler_set_kernel(self.handle, which))

@@ -376,10 +376,15 @@ def main():
         src_alpha = make_frames("alpha", list(range(rank * n_alpha, (rank + 1) * n_alpha)))
         src_alpha = src_alpha.repeat((chunk + n_alpha - 1) // n_alpha, 1, 1, 1)[:chunk].contiguous()
         pipe.stream.wait_stream(torch.cuda.current_stream())
-        for _ in range(2):
-            pipe.scale(src_alpha)
+        # (same steady clock as the timed region: launches for --prewarm seconds first -- three launches
+        # right after the frames are generated read 20 % slow)
+        t_end = time.perf_counter() + max(0.1, args.prewarm)
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                pipe.scale(src_alpha)
+            torch.cuda.synchronize()
         evs = []
-        for _ in range(max(3, args.steps // 2)):
+        for _ in range(max(6, args.steps)):
             e0 = record(pipe.stream)
             pipe.scale(src_alpha)
             evs.append((e0, record(pipe.stream)))

@@ -39,7 +39,7 @@ def counter(sub, name):
     for fn in glob.glob(out + "/" + sub + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
             if r["Counter_Name"] == name and "ScaleStreamMKernel" in r["Kernel_Name"]:
-                acc[r["Kernel_Name"].split("ScaleStreamMKernel")[1][:3]].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"].split("ScaleStreamMKernel")[1][:2] + ">"].append(float(r["Counter_Value"]))  # "<0>" / "<1>"
     return {k: sum(v) / len(v) for k, v in acc.items()}
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 k = "<0>"

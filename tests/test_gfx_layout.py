@@ -39,23 +39,27 @@ SIZES = [(1, 1), (2, 1), (5, 3), (67, 50), (30, 26), (129, 127), (200, 90), (400
          (819, 20), (16383, 1), (341, 3)]
 
 
+# form 0: one byte / one base64 group per index; form 2: four pixels / four groups per index, the way the
+# kernels walk (dword loads, byte-wise Sub filter, sums by byte sums and dot products, arithmetic alphabet)
+@pytest.mark.parametrize("form", [0, 2])
 @pytest.mark.parametrize("w,h", SIZES)
-def test_png_layout(oracle, emulate, w, h):
+def test_png_layout(oracle, emulate, w, h, form):
     rng = np.random.default_rng(w * 7 + h)
     fb = _fb(rng, w, h)
-    assert emulate(0, fb, 0) == oracle.png_encode(fb, True)
-    assert emulate(0, fb, 1) == oracle.png_encode(fb, False)
+    assert emulate(0, fb, form) == oracle.png_encode(fb, True)
+    assert emulate(0, fb, form | 1) == oracle.png_encode(fb, False)
 
 
+@pytest.mark.parametrize("form", [0, 2])
 @pytest.mark.parametrize("w,h", SIZES)
-def test_kitty_and_iterm2_layout(oracle, emulate, w, h):
+def test_kitty_and_iterm2_layout(oracle, emulate, w, h, form):
     rng = np.random.default_rng(w * 11 + h)
     fb = _fb(rng, w, h)
     for image_id in (7, 4_000_000_123):
-        assert emulate(1, fb, 0, image_id) == oracle.kitty_encode(fb, image_id, True)
-    assert emulate(1, fb, 1, 99) == oracle.kitty_encode(fb, 99, False)
-    assert emulate(2, fb, 0) == oracle.iterm2_encode(fb, True)
-    assert emulate(2, fb, 1) == oracle.iterm2_encode(fb, False)
+        assert emulate(1, fb, form, image_id) == oracle.kitty_encode(fb, image_id, True)
+    assert emulate(1, fb, form | 1, 99) == oracle.kitty_encode(fb, 99, False)
+    assert emulate(2, fb, form) == oracle.iterm2_encode(fb, True)
+    assert emulate(2, fb, form | 1) == oracle.iterm2_encode(fb, False)
 
 
 def test_sizes_around_the_block_chunk_and_segment_boundaries(oracle, emulate):
@@ -70,5 +74,7 @@ def test_sizes_around_the_block_chunk_and_segment_boundaries(oracle, emulate):
             fb = _fb(rng, w, h)
             assert emulate(0, fb, 0) == oracle.png_encode(fb, True), (w, h)
             assert emulate(1, fb, 1, 5) == oracle.kitty_encode(fb, 5, False), (w, h)
+            assert emulate(0, fb, 2 | 1) == oracle.png_encode(fb, False), (w, h)       # (group-wise forms)
+            assert emulate(2, fb, 2) == oracle.iterm2_encode(fb, True), (w, h)
             hit += 1
     assert hit > 200

@@ -37,7 +37,8 @@ extern "C" int timg_hip_debug_plan_dump(int sw, int sh, int in_fmt, int dw, int 
 
 // The graphics-protocol path (gfx_canvas.hip) with plain loops in place of the kernels' lanes:
 // the same per-index functions (gfx_layout.h), the same order of passes.  Host only, for
-// tests/test_gfx_layout.py.  kind: 0 png, 1 kitty, 2 iTerm2; flags bit 0: RGB (alpha dropped).
+// tests/test_gfx_layout.py.  kind: 0 png, 1 kitty, 2 iTerm2; flags bit 0: RGB (alpha dropped), bit 1: the
+// group-wise forms of the body and base64 passes (what the kernels run) instead of the element-wise ones.
 extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, int h, int flags, uint32_t image_id,
                                            uint8_t *out, long cap) {
     using namespace timg_amd;
@@ -48,11 +49,23 @@ extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, i
     // pass 1: head, filtered bytes, block headers, the two sums
     for (uint32_t i = 0; i < kPngIdatData + 2; ++i) png[i] = g.head[i];
     unsigned long long sum_a = 0, sum_b = 0;
-    for (uint32_t j = 0; j < g.raw_n; ++j) {
-        const uint8_t v      = PngRawByte(fb, (size_t)w * 4, g, j);
-        png[PngRawOffset(j)] = v;
-        sum_a += v;
-        sum_b += (unsigned long long)(g.raw_n - j) * v;
+    const bool groupwise = (flags & 2) != 0;  // the kernels' four-pixel / four-group forms
+    if (groupwise) {
+        const uint32_t gpr = ((uint32_t)w + 3u) >> 2;
+        for (uint32_t i = 0; i < PngBodyGroups(g); ++i) {
+            uint32_t a;
+            unsigned long long b;
+            PngBodyGroup(fb, (size_t)w * 4, g, i / gpr, i % gpr, png, &a, &b);
+            sum_a += a;
+            sum_b += b;
+        }
+    } else {
+        for (uint32_t j = 0; j < g.raw_n; ++j) {
+            const uint8_t v      = PngRawByte(fb, (size_t)w * 4, g, j);
+            png[PngRawOffset(j)] = v;
+            sum_a += v;
+            sum_b += (unsigned long long)(g.raw_n - j) * v;
+        }
     }
     for (uint32_t b = 0; b < g.n_blocks; ++b) PngBlockHeader(g, b, png + PngBlockHeaderOffset(b));
     // pass 2: Adler-32 closes the zlib stream
@@ -68,7 +81,9 @@ extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, i
     const GfxFraming f = MakeFraming(kind, g, FormatGfxHeader(kind, g, image_id, header));
     if (cap < (long)f.total) return -1;
     for (uint32_t i = 0; i < f.header_len; ++i) out[i] = (uint8_t)header[i];
-    for (uint32_t grp = 0; grp < f.n_groups; ++grp) {
+    if (groupwise)
+        for (uint32_t quad = 0; quad * 4u < f.n_groups; ++quad) GfxFrameQuad(png, g, f, quad, out);
+    for (uint32_t grp = 0; !groupwise && grp < f.n_groups; ++grp) {
         const uint32_t q = Base64Quad(png, g.png_n, grp);
         uint8_t *o       = out + GfxGroupOffset(f, grp);
         o[0] = (uint8_t)q;

@@ -11,9 +11,10 @@
 //   CRC-32    = per-lane CRCs of 512-byte chunks, combined left to right in two levels with
 //               crc(A || B) = x^(8|B|) crc(A) + crc(B) over GF(2) (the shift factors for the four
 //               lengths that occur are computed on the host).
-// HBM-bound byte work by nature; not measured yet (no roofline claim).
+// HBM-bound byte work by nature (measured: profiles/r2/bench_modes.txt).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -36,7 +37,17 @@ struct GfxBatch {
     const uint8_t *headers;    // [frames][kGfxHeaderCap]: header text, its length in the last byte
 };
 
-// pass 1: one filtered byte per lane; the file's fixed head and the block headers on the side
+// pass 1: four pixels of a row per lane (PngBodyGroup, gfx_layout.h); the file's fixed head and the
+// block headers on the side.  The Adler sums: per lane from byte sums and dot products, 64-bit wave
+// reduction, one LDS atomic per wave, one pair of global atomics per workgroup.
+// (First version: one BYTE per lane and two 64-bit LDS atomics per byte -- 3.1 ms per 64 frames of
+// 800x450, 25x the scale kernel's time for a twentieth of its bytes.)
+__device__ __forceinline__ unsigned long long WaveSumU64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 __global__ void __launch_bounds__(256) PngBodyKernel(PngGeom g, GfxBatch b) {
     __shared__ unsigned long long s_a, s_b;
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
@@ -44,11 +55,11 @@ __global__ void __launch_bounds__(256) PngBodyKernel(PngGeom g, GfxBatch b) {
     uint8_t *png     = b.png + (size_t)f * b.png_stride;
     if (threadIdx.x == 0) s_a = s_b = 0;
     __syncthreads();
-    if (j < g.raw_n) {
-        const uint8_t v      = PngRawByte(b.fb + (size_t)f * b.frame_stride, b.stride, g, j);
-        png[PngRawOffset(j)] = v;
-        atomicAdd(&s_a, (unsigned long long)v);
-        atomicAdd(&s_b, (unsigned long long)(g.raw_n - j) * v);
+    uint32_t a = 0;
+    unsigned long long bs = 0;
+    if (j < PngBodyGroups(g)) {
+        const uint32_t gpr = ((uint32_t)g.w + 3u) >> 2, y = j / gpr;
+        PngBodyGroup(b.fb + (size_t)f * b.frame_stride, b.stride, g, y, j - y * gpr, png, &a, &bs);
     }
     if (j < kPngIdatData + 2) png[j] = g.head[j];
     if (j < g.n_blocks) {
@@ -56,6 +67,11 @@ __global__ void __launch_bounds__(256) PngBodyKernel(PngGeom g, GfxBatch b) {
         PngBlockHeader(g, j, hdr);
         uint8_t *p = png + PngBlockHeaderOffset(j);
         for (int i = 0; i < 5; ++i) p[i] = hdr[i];
+    }
+    const unsigned long long wa = WaveSumU64(a), wb = WaveSumU64(bs);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_a, wa);
+        atomicAdd(&s_b, wb);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -71,12 +87,42 @@ __global__ void PngAdlerKernel(PngGeom g, GfxBatch b, int n_frames) {
     PutBE32(b.png + (size_t)f * b.png_stride + PngAdlerOffset(g), AdlerFromSums(g, b.sums[2 * f], b.sums[2 * f + 1]));
 }
 
-// pass 3: CRC of every 512-byte chunk of "IDAT" + stream
-__global__ void PngChunkCrcKernel(PngGeom g, GfxBatch b) {
+// pass 3: CRC of every 512-byte chunk of "IDAT" + stream, a lane per chunk, a dword per step through four
+// 256-entry tables in LDS (slicing by four; the tables are built by the workgroup itself: T0 bit by bit,
+// Tk[i] = (Tk-1[i] >> 8) ^ T0[Tk-1[i] & 255]).  The checksummed region starts 37 bytes into the file:
+// the dwords are unaligned loads.  Bit-by-bit over byte loads this pass took as long as the scale kernel
+// takes for a fourth of the batch.
+__global__ void __launch_bounds__(256) PngChunkCrcKernel(PngGeom g, GfxBatch b) {
+    __shared__ uint32_t tab[4][256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+        tab[0][threadIdx.x] = c;
+    }
+    __syncthreads();
+    {
+        const uint32_t t0 = tab[0][threadIdx.x];
+        const uint32_t t1 = (t0 >> 8) ^ tab[0][t0 & 255u];
+        const uint32_t t2 = (t1 >> 8) ^ tab[0][t1 & 255u];
+        const uint32_t t3 = (t2 >> 8) ^ tab[0][t2 & 255u];
+        tab[1][threadIdx.x] = t1;
+        tab[2][threadIdx.x] = t2;
+        tab[3][threadIdx.x] = t3;
+    }
+    __syncthreads();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     const int f      = blockIdx.y;
     if (c >= g.n_chunks) return;
-    b.chunk_crc[(size_t)f * g.n_chunks + c] = PngChunkCrc(b.png + (size_t)f * b.png_stride, g, c);
+    const uint32_t at = c * kCrcChunk, left = g.crc_len - at, n = left < kCrcChunk ? left : kCrcChunk;
+    const uint8_t *p  = b.png + (size_t)f * b.png_stride + PngCrcRegion() + at;
+    uint32_t crc      = 0xffffffffu;
+    uint32_t i        = 0;
+    for (; i + 4 <= n; i += 4) {
+        crc ^= GfxLoadU32(p + i);
+        crc = tab[3][crc & 255u] ^ tab[2][(crc >> 8) & 255u] ^ tab[1][(crc >> 16) & 255u] ^ tab[0][crc >> 24];
+    }
+    for (; i < n; ++i) crc = (crc >> 8) ^ tab[0][(crc ^ p[i]) & 255u];
+    b.chunk_crc[(size_t)f * g.n_chunks + c] = ~crc;
 }
 
 // pass 4a: 64 chunk CRCs -> one segment CRC
@@ -94,31 +140,24 @@ __global__ void PngTailKernel(PngGeom g, GfxBatch b, int n_frames) {
     PngTail(b.png + (size_t)f * b.png_stride, g, PngTotalCrc(b.segment_crc + (size_t)f * g.n_segments, g));
 }
 
-// pass 5: one group of three PNG bytes per lane -> four base64 characters in their place;
-// header, kitty chunk separators and trailer on the side
+// pass 5: FOUR groups of three PNG bytes per lane -> sixteen base64 characters in their place
+// (GfxFrameQuad, gfx_layout.h); header, kitty chunk separators and trailer on the side
 __global__ void __launch_bounds__(256) GfxFrameKernel(PngGeom g, GfxBatch b, int kind) {
-    const uint32_t grp  = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t quad = blockIdx.x * 256u + threadIdx.x;
     const int f         = blockIdx.y;
     const uint8_t *png  = b.png + (size_t)f * b.png_stride;
     uint8_t *out        = b.out + (size_t)f * b.out_cap;
     const uint8_t *head = b.headers + (size_t)f * kGfxHeaderCap;
     const GfxFraming fr = MakeFraming(kind, g, head[kGfxHeaderCap - 1]);
-    if (grp < fr.n_groups) {
-        const uint32_t q = Base64Quad(png, g.png_n, grp);
-        uint8_t *o       = out + GfxGroupOffset(fr, grp);
-        o[0] = (uint8_t)q;
-        o[1] = (uint8_t)(q >> 8);
-        o[2] = (uint8_t)(q >> 16);
-        o[3] = (uint8_t)(q >> 24);
-    }
-    if (grp < fr.header_len) out[grp] = head[grp];
-    if (kind == kGfxKitty && grp >= 1 && grp < fr.n_kitty_chunks) {
+    GfxFrameQuad(png, g, fr, quad, out);
+    if (quad < fr.header_len) out[quad] = head[quad];
+    if (kind == kGfxKitty && quad >= 1 && quad < fr.n_kitty_chunks) {
         uint8_t sep[13];
-        KittySeparator(fr, grp, sep);
-        uint8_t *p = out + KittySeparatorOffset(fr, grp);
+        KittySeparator(fr, quad, sep);
+        uint8_t *p = out + KittySeparatorOffset(fr, quad);
         for (int i = 0; i < 13; ++i) p[i] = sep[i];
     }
-    if (grp == 0) GfxTrailer(fr, out);
+    if (quad == 0) GfxTrailer(fr, out);
 }
 
 }  // namespace
@@ -214,14 +253,18 @@ static int GfxEncode(int kind, timg_hip_ctx *ctx, const uint8_t *fb, int w, int 
         TIMG_HIP_TRY(ctx, hipMemcpyAsync(base + o_head, headers.data(), headers.size(), hipMemcpyHostToDevice, st));
     }
     const unsigned frames = (unsigned)n_frames;
-    hipLaunchKernelGGL(PngBodyKernel, dim3((g.raw_n + 255) / 256, frames), dim3(256), 0, st, g, b);
+    // (lanes: a group of four pixels each, and at least one per byte of the fixed head / per block header)
+    const uint32_t body_lanes = std::max(std::max(PngBodyGroups(g), kPngIdatData + 2), g.n_blocks);
+    hipLaunchKernelGGL(PngBodyKernel, dim3((body_lanes + 255) / 256, frames), dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(PngAdlerKernel, dim3((frames + 63) / 64), dim3(64), 0, st, g, b, n_frames);
-    hipLaunchKernelGGL(PngChunkCrcKernel, dim3((g.n_chunks + 63) / 64, frames), dim3(64), 0, st, g, b);
+    hipLaunchKernelGGL(PngChunkCrcKernel, dim3((g.n_chunks + 255) / 256, frames), dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(PngSegmentCrcKernel, dim3((g.n_segments + 63) / 64, frames), dim3(64), 0, st, g, b);
     hipLaunchKernelGGL(PngTailKernel, dim3((frames + 63) / 64), dim3(64), 0, st, g, b, n_frames);
     if (kind != kGfxPng) {
-        const uint32_t n_groups = (g.png_n + 2) / 3;
-        hipLaunchKernelGGL(GfxFrameKernel, dim3((n_groups + 255) / 256, frames), dim3(256), 0, st, g, b, kind);
+        // (lanes: four base64 groups each, and at least one per header byte / per kitty separator)
+        const uint32_t n_quads = ((g.png_n + 2) / 3 + 3) / 4;
+        const uint32_t lanes   = std::max(std::max(n_quads, kGfxHeaderCap), (g.png_n + kKittyChunk - 1) / kKittyChunk);
+        hipLaunchKernelGGL(GfxFrameKernel, dim3((lanes + 255) / 256, frames), dim3(256), 0, st, g, b, kind);
     }
     TIMG_HIP_TRY(ctx, hipGetLastError());
     if (!out_on_device) {

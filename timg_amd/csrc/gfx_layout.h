@@ -186,6 +186,88 @@ TIMG_HD void PngTail(uint8_t *png, const PngGeom &g, uint32_t crc) {  // IDAT's 
     p[12] = 0xae; p[13] = 0x42; p[14] = 0x60; p[15] = 0x82;
 }
 
+// ---- PNG body, group-wise: FOUR pixels of a row per index (what PngBodyKernel runs) ----------
+// Same bytes as PngRawByte / PngRawOffset element by element, but a lane handles the 16 (RGBA) or
+// 12 (RGB) filtered bytes of four adjacent pixels: dword loads, the Sub filter as one byte-wise
+// subtraction per pixel, one run of (unaligned) dword stores unless a stored-block boundary cuts
+// through the run, and the lane's share of the two Adler sums from byte sums / dot products.
+TIMG_HD uint32_t GfxLoadU32(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+TIMG_HD void GfxStoreU32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+// a - b (mod 256) in each of the four bytes
+TIMG_HD uint32_t SubBytes4(uint32_t a, uint32_t b) {
+    return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u);
+}
+TIMG_HD uint32_t SumBytes4(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sad_u8(v, 0u, 0u);
+#else
+    return (v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24);
+#endif
+}
+TIMG_HD uint32_t Dot0123(uint32_t v) {  // 0 * byte0 + 1 * byte1 + 2 * byte2 + 3 * byte3
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(v, 0x03020100u, 0u, false);
+#else
+    return ((v >> 8) & 255u) + 2u * ((v >> 16) & 255u) + 3u * (v >> 24);
+#endif
+}
+// group xg (pixels 4 xg .. 4 xg + 3) of row y; returns the group's contribution to
+// A' = sum d_j and B' = sum (raw_n - j) d_j (the row's filter-type byte rides with group 0)
+TIMG_HD void PngBodyGroup(const uint8_t *frame, size_t stride, const PngGeom &g, uint32_t y, uint32_t xg, uint8_t *png,
+                          uint32_t *sum_a, unsigned long long *sum_b) {
+    const uint32_t x0 = xg * 4u, npx = (uint32_t)g.w - x0 < 4u ? (uint32_t)g.w - x0 : 4u;
+    const uint8_t *line = frame + (size_t)y * stride;
+    uint32_t prev = x0 ? GfxLoadU32(line + 4u * (x0 - 1u)) : 0u;  // (the first pixel of a row is stored as it is)
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t k = 0; k < 4u; ++k) {
+        if (k < npx) {
+            const uint32_t cur = GfxLoadU32(line + 4u * (x0 + k));
+            d[k]               = SubBytes4(cur, prev);
+            prev               = cur;
+        }
+    }
+    uint32_t o[4], nbytes;
+    if (g.bpp == 4) {
+        o[0] = d[0], o[1] = d[1], o[2] = d[2], o[3] = d[3];
+        nbytes = 4u * npx;
+    } else {  // alpha dropped: 3 bytes per pixel, packed
+        const uint32_t t0 = d[0] & 0xffffffu, t1 = d[1] & 0xffffffu, t2 = d[2] & 0xffffffu, t3 = d[3] & 0xffffffu;
+        o[0] = t0 | (t1 << 24);
+        o[1] = (t1 >> 8) | (t2 << 16);
+        o[2] = (t2 >> 16) | (t3 << 8);
+        o[3] = 0u;
+        nbytes = 3u * npx;
+    }
+    const uint32_t j0 = y * g.row + 1u + (uint32_t)g.bpp * x0;
+    uint32_t a = 0, kd = 0;
+    for (uint32_t q = 0; q < 4u; ++q) {  // (bytes past nbytes are zero)
+        const uint32_t sq = SumBytes4(o[q]);
+        a += sq;
+        kd += Dot0123(o[q]) + 4u * q * sq;
+    }
+    unsigned long long bsum = (unsigned long long)(g.raw_n - j0) * a - kd;
+    if (xg == 0) {  // filter type 1 in front of the row
+        png[PngRawOffset(y * g.row)] = 1;
+        a += 1u;
+        bsum += g.raw_n - y * g.row;
+    }
+    if (j0 / kStoredBlock == (j0 + nbytes - 1u) / kStoredBlock) {
+        uint8_t *dst = png + PngRawOffset(j0);
+        for (uint32_t q = 0; q < 4u; ++q)
+            if (4u * q + 4u <= nbytes) GfxStoreU32(dst + 4u * q, o[q]);
+        for (uint32_t i = nbytes & ~3u; i < nbytes; ++i) dst[i] = (uint8_t)(o[i >> 2] >> (8u * (i & 3u)));
+    } else {  // a block header lies inside the run
+        for (uint32_t i = 0; i < nbytes; ++i) png[PngRawOffset(j0 + i)] = (uint8_t)(o[i >> 2] >> (8u * (i & 3u)));
+    }
+    *sum_a = a;
+    *sum_b = bsum;
+}
+TIMG_HD uint32_t PngBodyGroups(const PngGeom &g) { return (uint32_t)g.h * (((uint32_t)g.w + 3u) >> 2); }
+
 // ---- base64 + framing: one group of three PNG bytes per index g ----------------------------
 struct GfxFraming {
     int kind;               // GfxKind
@@ -222,6 +304,40 @@ TIMG_HD uint32_t GfxGroupOffset(const GfxFraming &f, uint32_t grp) {
     const uint32_t groups_per_chunk = kKittyChunk / 3;
     const uint32_t sep = f.kind == kGfxKitty ? (grp / groups_per_chunk) * kKittySepLen : 0;
     return f.header_len + 4 * grp + sep;
+}
+// FOUR groups per index (what GfxFrameKernel runs): 12 PNG bytes as three dwords -> 16 characters
+// as four (unaligned) dword stores; the alphabet by byte-wise arithmetic instead of a table:
+// 0..25 -> +65 ('A'), 26..51 -> +71 ('a' - 26), 52..61 -> -4 ('0' - 52), 62 -> -19 ('+'), 63 -> -16 ('/')
+TIMG_HD uint32_t Base64Chars4(uint32_t v) {  // four 6-bit values, one per byte
+    const uint32_t k = 0x01010101u;
+    const uint32_t ge26 = ((v + (128u - 26u) * k) >> 7) & k, ge52 = ((v + (128u - 52u) * k) >> 7) & k;
+    const uint32_t ge62 = ((v + (128u - 62u) * k) >> 7) & k, ge63 = ((v + (128u - 63u) * k) >> 7) & k;
+    return v + 65u * k + 6u * ge26 - 75u * ge52 - 15u * ge62 + 3u * ge63;
+}
+TIMG_HD uint32_t Base64FromTriple(uint32_t n) {  // n = b0 << 16 | b1 << 8 | b2 -> characters, first in the low byte
+    return Base64Chars4((n >> 18) | ((n >> 4) & 0x3f00u) | ((n << 10) & 0x3f0000u) | ((n << 24) & 0x3f000000u));
+}
+static_assert((kKittyChunk / 3) % 4 == 0, "four groups never straddle a kitty chunk");
+TIMG_HD void GfxFrameQuad(const uint8_t *png, const PngGeom &g, const GfxFraming &fr, uint32_t quad, uint8_t *out) {
+    const uint32_t g0 = 4u * quad;
+    if (g0 >= fr.n_groups) return;
+    if (12u * (quad + 1u) <= g.png_n) {  // four complete groups
+        const uint32_t d0 = GfxLoadU32(png + 12u * quad), d1 = GfxLoadU32(png + 12u * quad + 4u),
+                       d2 = GfxLoadU32(png + 12u * quad + 8u);
+        // bytes b0..b11 in memory order; triples (b0 b1 b2) (b3 b4 b5) (b6 b7 b8) (b9 b10 b11), big-endian each
+        const uint32_t n0 = ((d0 & 0xffu) << 16) | (d0 & 0xff00u) | ((d0 >> 16) & 0xffu);
+        const uint32_t n1 = ((d0 >> 24) << 16) | ((d1 & 0xffu) << 8) | ((d1 >> 8) & 0xffu);
+        const uint32_t n2 = (d1 & 0xff0000u) | ((d1 >> 24) << 8) | (d2 & 0xffu);
+        const uint32_t n3 = ((d2 & 0xff00u) << 8) | ((d2 >> 8) & 0xff00u) | (d2 >> 24);
+        uint8_t *o = out + GfxGroupOffset(fr, g0);
+        GfxStoreU32(o, Base64FromTriple(n0));
+        GfxStoreU32(o + 4, Base64FromTriple(n1));
+        GfxStoreU32(o + 8, Base64FromTriple(n2));
+        GfxStoreU32(o + 12, Base64FromTriple(n3));
+    } else {
+        for (uint32_t grp = g0; grp < g0 + 4u && grp < fr.n_groups; ++grp)
+            GfxStoreU32(out + GfxGroupOffset(fr, grp), Base64Quad(png, g.png_n, grp));
+    }
 }
 // separator in front of kitty chunk c >= 1: ESC \ ESC _ G q = 2 , m = <more> ;
 TIMG_HD uint32_t KittySeparatorOffset(const GfxFraming &f, uint32_t c) {

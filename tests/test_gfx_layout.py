@@ -78,3 +78,15 @@ def test_sizes_around_the_block_chunk_and_segment_boundaries(oracle, emulate):
             assert emulate(2, fb, 2) == oracle.iterm2_encode(fb, True), (w, h)
             hit += 1
     assert hit > 200
+
+
+def test_crc_tree_across_segments(oracle, emulate):
+    """More than 1024 chunk CRCs: the tree continues across the workgroups' segments (a segment = levels 0..9);
+    checksummed regions of exactly 1024 x 512 bytes and one byte more, two segments and a bit, three segments."""
+    rng = np.random.default_rng(5)
+    for w, h, rgb in ((5957, 22, 0), (5698, 23, 0), (8191, 16, 0), (14562, 24, 1), (14569, 24, 1), (17483, 15, 0),
+                      (800, 450, 0), (400, 340, 1)):
+        fb = _fb(rng, w, h)
+        assert emulate(0, fb, 2 | rgb) == oracle.png_encode(fb, not rgb), (w, h, rgb)
+    fb = _fb(rng, 800, 450)
+    assert emulate(1, fb, 2, 77) == oracle.kitty_encode(fb, 77, True)

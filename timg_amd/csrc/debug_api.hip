@@ -3,6 +3,7 @@
 // (not declared in include/timg_hip.h) and not linked into libtimg_hip.so.
 #include <cstring>
 
+#include <algorithm>
 #include <vector>
 
 #include "gfx_layout.h"
@@ -53,11 +54,9 @@ extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, i
     if (groupwise) {
         const uint32_t gpr = ((uint32_t)w + 3u) >> 2;
         for (uint32_t i = 0; i < PngBodyGroups(g); ++i) {
-            uint32_t a;
-            unsigned long long b;
-            PngBodyGroup(fb, (size_t)w * 4, g, i / gpr, i % gpr, png, &a, &b);
-            sum_a += a;
-            sum_b += b;
+            const PngGroupSums r = PngBodyGroup(fb, (size_t)w * 4, g, i / gpr, i % gpr, png);
+            sum_a += r.a;
+            sum_b += (unsigned long long)(g.raw_n - r.j0) * r.a - (long long)r.t;
         }
     } else {
         for (uint32_t j = 0; j < g.raw_n; ++j) {
@@ -73,8 +72,13 @@ extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, i
     // passes 3 and 4: CRC of "IDAT" + stream from chunk CRCs
     std::vector<uint32_t> chunk(g.n_chunks), segment(g.n_segments);
     for (uint32_t c = 0; c < g.n_chunks; ++c) chunk[c] = PngChunkCrc(png, g, c);
-    for (uint32_t s = 0; s < g.n_segments; ++s) segment[s] = PngSegmentCrc(chunk.data(), g, s);
-    PngTail(png, g, PngTotalCrc(segment.data(), g));
+    for (uint32_t s = 0; s < g.n_segments; ++s) {  // levels 0..9 inside a segment of 1024 chunks ...
+        const uint32_t base = s * kCrcSegment, count = std::min(kCrcSegment, g.n_chunks - base);
+        PngTreeReduce(chunk.data() + base, count, base, 0, kCrcSegmentLog, g);
+        segment[s] = chunk[base];
+    }
+    PngTreeReduce(segment.data(), g.n_segments, 0, kCrcSegmentLog, kCrcLevels, g);  // ... the rest across segments
+    PngTail(png, g, segment[0]);
     if (kind == kGfxPng) return (long)g.png_n;
     // pass 5: base64 and framing
     char header[kGfxHeaderCap];

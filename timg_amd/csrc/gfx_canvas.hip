@@ -8,9 +8,9 @@
 //   Adler-32  = plain sums  A' = sum d_j,  B' = sum (n - j) d_j  over the filtered bytes
 //               (64-bit, per workgroup in LDS, one global atomic per workgroup), reduced mod 65521
 //               once at the end;
-//   CRC-32    = per-lane CRCs of 512-byte chunks, combined left to right in two levels with
-//               crc(A || B) = x^(8|B|) crc(A) + crc(B) over GF(2) (the shift factors for the four
-//               lengths that occur are computed on the host).
+//   CRC-32    = per-lane CRCs of 512-byte chunks, combined as a binary tree with
+//               crc(A || B) = x^(8|B|) crc(A) + crc(B) over GF(2) (the shift factors of every level, for
+//               complete right children and for the one that holds the short last chunk, come from the host).
 // HBM-bound byte work by nature (measured: profiles/r2/bench_modes.txt).
 #include <hip/hip_runtime.h>
 
@@ -20,6 +20,7 @@
 
 #include "context.h"
 #include "gfx_layout.h"
+#include "wave_ops.h"
 
 namespace timg_amd {
 namespace {
@@ -29,7 +30,8 @@ struct GfxBatch {
     size_t stride, frame_stride;
     uint8_t *png;  // [frames] slots of png_stride bytes
     size_t png_stride;
-    unsigned long long *sums;  // [frames][2]
+    unsigned long long *sums;  // [frames][body workgroups][2]: every workgroup's share of the two Adler sums
+    uint32_t sum_slots;        // body workgroups per frame
     uint32_t *chunk_crc;       // [frames][n_chunks]
     uint32_t *segment_crc;     // [frames][n_segments]
     uint8_t *out;              // [frames] slots of out_cap bytes (framed kinds)
@@ -42,12 +44,6 @@ struct GfxBatch {
 // reduction, one LDS atomic per wave, one pair of global atomics per workgroup.
 // (First version: one BYTE per lane and two 64-bit LDS atomics per byte -- 3.1 ms per 64 frames of
 // 800x450, 25x the scale kernel's time for a twentieth of its bytes.)
-__device__ __forceinline__ unsigned long long WaveSumU64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
 __global__ void __launch_bounds__(256) PngBodyKernel(PngGeom g, GfxBatch b) {
     __shared__ unsigned long long s_a, s_b;
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
@@ -55,11 +51,11 @@ __global__ void __launch_bounds__(256) PngBodyKernel(PngGeom g, GfxBatch b) {
     uint8_t *png     = b.png + (size_t)f * b.png_stride;
     if (threadIdx.x == 0) s_a = s_b = 0;
     __syncthreads();
-    uint32_t a = 0;
-    unsigned long long bs = 0;
-    if (j < PngBodyGroups(g)) {
+    PngGroupSums r{0u, 0u, 0};
+    const bool active = j < PngBodyGroups(g);
+    if (active) {
         const uint32_t gpr = ((uint32_t)g.w + 3u) >> 2, y = j / gpr;
-        PngBodyGroup(b.fb + (size_t)f * b.frame_stride, b.stride, g, y, j - y * gpr, png, &a, &bs);
+        r = PngBodyGroup(b.fb + (size_t)f * b.frame_stride, b.stride, g, y, j - y * gpr, png);
     }
     if (j < kPngIdatData + 2) png[j] = g.head[j];
     if (j < g.n_blocks) {
@@ -68,23 +64,52 @@ __global__ void __launch_bounds__(256) PngBodyKernel(PngGeom g, GfxBatch b) {
         uint8_t *p = png + PngBlockHeaderOffset(j);
         for (int i = 0; i < 5; ++i) p[i] = hdr[i];
     }
-    const unsigned long long wa = WaveSumU64(a), wb = WaveSumU64(bs);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&s_a, wa);
-        atomicAdd(&s_b, wb);
+    // B' = sum (raw_n - j0) a - t over the groups.  With J = (first lane's j0) - 1 and j0 = J + delta
+    // (1 <= delta <= 64 * 17 inside a wave: the groups are consecutive) a wave's share is
+    // (raw_n - J) * sum a  -  sum (delta * a + t): two 32-bit wave sums (delta * a + t < 2^23) instead of
+    // 64-bit ones.  (Active lanes are a prefix of the wave; an all-idle wave adds zero.)
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.j0) - 1u;
+    const uint32_t wa   = WaveSum(r.a);
+    const uint32_t wt   = WaveSum(active ? (r.j0 - base) * r.a + (uint32_t)r.t : 0u);
+    if ((threadIdx.x & 63) == 0 && wa != 0) {
+        atomicAdd(&s_a, (unsigned long long)wa);
+        atomicAdd(&s_b, (unsigned long long)(g.raw_n - base) * wa - wt);
     }
     __syncthreads();
+    // (a slot per workgroup, summed by the next pass: global atomics of 22 000 workgroups on the 128 words
+    // of the batch's sums -- eight cache lines -- were what this pass waited for)
     if (threadIdx.x == 0) {
-        atomicAdd(&b.sums[2 * f], s_a);
-        atomicAdd(&b.sums[2 * f + 1], s_b);
+        unsigned long long *slot = b.sums + ((size_t)f * b.sum_slots + blockIdx.x) * 2;
+        slot[0] = s_a;
+        slot[1] = s_b;
     }
 }
 
-// pass 2: the Adler-32 closes the zlib stream (one lane per frame)
-__global__ void PngAdlerKernel(PngGeom g, GfxBatch b, int n_frames) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
-    PutBE32(b.png + (size_t)f * b.png_stride + PngAdlerOffset(g), AdlerFromSums(g, b.sums[2 * f], b.sums[2 * f + 1]));
+// pass 2: the workgroups' shares summed (a workgroup per frame); the Adler-32 closes the zlib stream
+__device__ __forceinline__ unsigned long long WaveSumU64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__global__ void __launch_bounds__(256) PngAdlerKernel(PngGeom g, GfxBatch b) {
+    __shared__ unsigned long long s_a, s_b;
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0) s_a = s_b = 0;
+    __syncthreads();
+    const unsigned long long *slots = b.sums + (size_t)f * b.sum_slots * 2;
+    unsigned long long a = 0, bs = 0;
+    for (uint32_t i = threadIdx.x; i < b.sum_slots; i += 256u) {
+        a += slots[2 * i];
+        bs += slots[2 * i + 1];
+    }
+    a  = WaveSumU64(a);
+    bs = WaveSumU64(bs);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_a, a);
+        atomicAdd(&s_b, bs);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) PutBE32(b.png + (size_t)f * b.png_stride + PngAdlerOffset(g), AdlerFromSums(g, s_a, s_b));
 }
 
 // pass 3: CRC of every 512-byte chunk of "IDAT" + stream, a lane per chunk, a dword per step through four
@@ -117,27 +142,81 @@ __global__ void __launch_bounds__(256) PngChunkCrcKernel(PngGeom g, GfxBatch b) 
     const uint8_t *p  = b.png + (size_t)f * b.png_stride + PngCrcRegion() + at;
     uint32_t crc      = 0xffffffffu;
     uint32_t i        = 0;
-    for (; i + 4 <= n; i += 4) {
-        crc ^= GfxLoadU32(p + i);
+    // sixteen bytes per load, the next load in flight while these are folded in: the lanes of a wave read
+    // 512 bytes apart, so every load touches 64 cache lines -- as dword loads (128 per chunk) the pass spent
+    // its time on L2 round trips
+    auto step4 = [&](uint32_t w) {
+        crc ^= w;
         crc = tab[3][crc & 255u] ^ tab[2][(crc >> 8) & 255u] ^ tab[1][(crc >> 16) & 255u] ^ tab[0][crc >> 24];
+    };
+    if (n >= 16u) {
+        uint32_t q[4], nx[4];
+        __builtin_memcpy(q, p, 16);
+        for (i = 16u; i + 16u <= n; i += 16u) {
+            __builtin_memcpy(nx, p + i, 16);
+            step4(q[0]), step4(q[1]), step4(q[2]), step4(q[3]);
+            q[0] = nx[0], q[1] = nx[1], q[2] = nx[2], q[3] = nx[3];
+        }
+        step4(q[0]), step4(q[1]), step4(q[2]), step4(q[3]);
     }
+    for (; i + 4 <= n; i += 4) step4(GfxLoadU32(p + i));
     for (; i < n; ++i) crc = (crc >> 8) ^ tab[0][(crc ^ p[i]) & 255u];
     b.chunk_crc[(size_t)f * g.n_chunks + c] = ~crc;
 }
 
-// pass 4a: 64 chunk CRCs -> one segment CRC
-__global__ void PngSegmentCrcKernel(PngGeom g, GfxBatch b) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f      = blockIdx.y;
-    if (s >= g.n_segments) return;
-    b.segment_crc[(size_t)f * g.n_segments + s] = PngSegmentCrc(b.chunk_crc + (size_t)f * g.n_chunks, g, s);
+// pass 4a: a workgroup combines up to 2^10 chunk CRCs as a binary tree (levels 0..9 of the frame's tree,
+// PngTreeParent in gfx_layout.h), a lane per parent.  (First version: a lane walked 64 chunks, then ONE lane
+// per frame walked the segments -- 107 dependent GF(2) multiplications of 32 steps each, 240 us per batch.)
+__global__ void __launch_bounds__(256) PngCrcTreeKernel(PngGeom g, GfxBatch b) {
+    __shared__ uint32_t nodes[kCrcSegment];
+    const int f         = blockIdx.y;
+    const uint32_t seg  = blockIdx.x, tid = threadIdx.x;
+    uint32_t base       = seg * kCrcSegment;
+    uint32_t count      = g.n_chunks - base < kCrcSegment ? g.n_chunks - base : kCrcSegment;
+    const uint32_t *src = b.chunk_crc + (size_t)f * g.n_chunks + base;
+    for (uint32_t i = tid; i < count; i += 256u) nodes[i] = src[i];
+    __syncthreads();
+    for (uint32_t k = 0; k < kCrcSegmentLog; ++k) {
+        const uint32_t pbase = base >> 1, parents = ((base + count + 1u) >> 1) - pbase;  // (<= 512: two per lane)
+        uint32_t v[2] = {0u, 0u};
+#pragma unroll
+        for (uint32_t q = 0; q < 2u; ++q)
+            if (tid + 256u * q < parents) v[q] = PngTreeParent(nodes, base, g, k, pbase + tid + 256u * q);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 2u; ++q)
+            if (tid + 256u * q < parents) nodes[tid + 256u * q] = v[q];
+        __syncthreads();
+        base  = pbase;
+        count = parents;
+    }
+    if (tid == 0) b.segment_crc[(size_t)f * g.n_segments + seg] = nodes[0];
 }
 
-// pass 4b: segment CRCs -> IDAT's CRC; IEND behind it (one lane per frame)
-__global__ void PngTailKernel(PngGeom g, GfxBatch b, int n_frames) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
-    PngTail(b.png + (size_t)f * b.png_stride, g, PngTotalCrc(b.segment_crc + (size_t)f * g.n_segments, g));
+// pass 4b: a workgroup per frame takes the tree from the segment nodes (level 10) to its root = IDAT's CRC;
+// IEND behind it
+constexpr uint32_t kMaxSegments = 1024;
+__global__ void __launch_bounds__(256) PngTailKernel(PngGeom g, GfxBatch b) {
+    __shared__ uint32_t nodes[kMaxSegments];
+    const int f        = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    uint32_t count     = g.n_segments;
+    for (uint32_t i = tid; i < count; i += 256u) nodes[i] = b.segment_crc[(size_t)f * g.n_segments + i];
+    __syncthreads();
+    for (uint32_t k = kCrcSegmentLog; count > 1u && k < kCrcLevels; ++k) {
+        const uint32_t parents = (count + 1u) >> 1;  // (<= 512: two per lane)
+        uint32_t v[2] = {0u, 0u};
+#pragma unroll
+        for (uint32_t q = 0; q < 2u; ++q)
+            if (tid + 256u * q < parents) v[q] = PngTreeParent(nodes, 0u, g, k, tid + 256u * q);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 2u; ++q)
+            if (tid + 256u * q < parents) nodes[tid + 256u * q] = v[q];
+        __syncthreads();
+        count = parents;
+    }
+    if (tid == 0) PngTail(b.png + (size_t)f * b.png_stride, g, nodes[0]);
 }
 
 // pass 5: FOUR groups of three PNG bytes per lane -> sixteen base64 characters in their place
@@ -189,6 +268,7 @@ static int GfxEncode(int kind, timg_hip_ctx *ctx, const uint8_t *fb, int w, int 
     if (stride < w * 4) return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride");
     if (frame_stride == 0) frame_stride = (size_t)stride * h;
     const PngGeom g = MakePngGeom(w, h, !(flags & TIMG_HIP_GFX_RGB24));
+    if (g.n_segments > kMaxSegments) return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "frame of %d x %d pixels is too large", w, h);
     // per-frame header text (the image id is the caller's: src/kitty-canvas.cc:47-52 derives it from time())
     std::vector<uint8_t> headers((size_t)n_frames * kGfxHeaderCap, 0);
     size_t worst = g.png_n;
@@ -229,7 +309,10 @@ static int GfxEncode(int kind, timg_hip_ctx *ctx, const uint8_t *fb, int w, int 
         return at;
     };
     const size_t o_png  = carve(kind == kGfxPng ? 0 : nf * png_slot);
-    const size_t o_sums = carve(nf * 2 * sizeof(unsigned long long));
+    // (lanes of the body pass: a group of four pixels each, and at least one per byte of the fixed head / per block header)
+    const uint32_t body_lanes = std::max(std::max(PngBodyGroups(g), kPngIdatData + 2), g.n_blocks);
+    const uint32_t body_wgs   = (body_lanes + 255) / 256;
+    const size_t o_sums = carve(nf * body_wgs * 2 * sizeof(unsigned long long));
     const size_t o_ccrc = carve(nf * g.n_chunks * sizeof(uint32_t));
     const size_t o_scrc = carve(nf * g.n_segments * sizeof(uint32_t));
     const size_t o_head = carve(nf * kGfxHeaderCap);
@@ -242,24 +325,22 @@ static int GfxEncode(int kind, timg_hip_ctx *ctx, const uint8_t *fb, int w, int 
     b.png          = kind == kGfxPng ? (uint8_t *)dout : (uint8_t *)(base + o_png);
     b.png_stride   = kind == kGfxPng ? out_cap : png_slot;
     b.sums         = (unsigned long long *)(base + o_sums);
+    b.sum_slots    = body_wgs;
     b.chunk_crc    = (uint32_t *)(base + o_ccrc);
     b.segment_crc  = (uint32_t *)(base + o_scrc);
     b.out          = (uint8_t *)dout;
     b.out_cap      = out_cap;
     b.headers      = (const uint8_t *)(base + o_head);
-    TIMG_HIP_TRY(ctx, hipMemsetAsync(b.sums, 0, nf * 2 * sizeof(unsigned long long), st));
     if (kind != kGfxPng) {
         // (`headers` outlives the copy: the stream is synchronised before this function returns)
         TIMG_HIP_TRY(ctx, hipMemcpyAsync(base + o_head, headers.data(), headers.size(), hipMemcpyHostToDevice, st));
     }
     const unsigned frames = (unsigned)n_frames;
-    // (lanes: a group of four pixels each, and at least one per byte of the fixed head / per block header)
-    const uint32_t body_lanes = std::max(std::max(PngBodyGroups(g), kPngIdatData + 2), g.n_blocks);
-    hipLaunchKernelGGL(PngBodyKernel, dim3((body_lanes + 255) / 256, frames), dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(PngAdlerKernel, dim3((frames + 63) / 64), dim3(64), 0, st, g, b, n_frames);
+    hipLaunchKernelGGL(PngBodyKernel, dim3(body_wgs, frames), dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(PngAdlerKernel, dim3(frames), dim3(256), 0, st, g, b);
     hipLaunchKernelGGL(PngChunkCrcKernel, dim3((g.n_chunks + 255) / 256, frames), dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL(PngSegmentCrcKernel, dim3((g.n_segments + 63) / 64, frames), dim3(64), 0, st, g, b);
-    hipLaunchKernelGGL(PngTailKernel, dim3((frames + 63) / 64), dim3(64), 0, st, g, b, n_frames);
+    hipLaunchKernelGGL(PngCrcTreeKernel, dim3(g.n_segments, frames), dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL(PngTailKernel, dim3(frames), dim3(256), 0, st, g, b);
     if (kind != kGfxPng) {
         // (lanes: four base64 groups each, and at least one per header byte / per kitty separator)
         const uint32_t n_quads = ((g.png_n + 2) / 3 + 3) / 4;

@@ -26,7 +26,9 @@ namespace timg_amd {
 constexpr uint32_t kStoredBlock  = 65535;  // libdeflate level 0: stored blocks of at most this
 constexpr uint32_t kPngIdatData  = 8 + 25 + 8;  // signature, IHDR chunk, IDAT length + type
 constexpr uint32_t kCrcChunk     = 512;    // bytes per lane in the chunk CRC pass
-constexpr uint32_t kCrcSegment   = 64;     // chunks combined serially by one lane
+constexpr uint32_t kCrcSegmentLog = 10;    // a workgroup combines 2^10 chunk CRCs as a binary tree ...
+constexpr uint32_t kCrcSegment   = 1u << kCrcSegmentLog;
+constexpr uint32_t kCrcLevels    = 24;     // ... and the frame's tree has at most this many levels
 constexpr uint32_t kKittyChunk   = 3072;   // bytes per kitty escape (4096 base64 characters)
 constexpr uint32_t kKittySepLen  = 13;     // ESC \ ESC _ G q = 2 , m = X ;
 constexpr uint32_t kGfxHeaderCap = 96;
@@ -43,8 +45,11 @@ struct PngGeom {
     uint32_t crc_len;      // "IDAT" + zlib stream
     uint32_t n_chunks;     // CRC chunks of kCrcChunk bytes
     uint32_t n_segments;   // groups of kCrcSegment chunks
-    // x^(8 * len) mod P for the lengths the combination steps shift by
-    uint32_t x_chunk, x_last_chunk, x_segment, x_last_segment;
+    // The chunk CRCs are combined as a binary tree by index: the node r of level k covers chunks
+    // [r 2^k, (r + 1) 2^k) (cut off at n_chunks).  crc(A || B) = x^(8 |B|) crc(A) + crc(B): the shift a
+    // level-(k+1) node applies to its left child is x^(8 * 512 * 2^k) for a complete right child and
+    // x^(8 * len) for the one right child that contains the (short) last chunk -- node edge_node[k]
+    uint32_t x_full[kCrcLevels], x_edge[kCrcLevels], edge_node[kCrcLevels];
     uint8_t head[kPngIdatData + 2];  // signature, IHDR (with its CRC), IDAT length + "IDAT", 78 01
 };
 
@@ -101,12 +106,13 @@ inline PngGeom MakePngGeom(int w, int h, bool with_alpha) {
     g.crc_len  = 4 + g.zlen;
     g.n_chunks   = (g.crc_len + kCrcChunk - 1) / kCrcChunk;
     g.n_segments = (g.n_chunks + kCrcSegment - 1) / kCrcSegment;
-    const uint32_t last_chunk   = g.crc_len - (g.n_chunks - 1) * kCrcChunk;
-    const uint32_t last_segment = g.crc_len - (g.n_segments - 1) * kCrcSegment * kCrcChunk;
-    g.x_chunk        = XPowBytes(kCrcChunk);
-    g.x_last_chunk   = XPowBytes(last_chunk);
-    g.x_segment      = XPowBytes((uint64_t)kCrcSegment * kCrcChunk);
-    g.x_last_segment = XPowBytes(last_segment);
+    for (uint32_t k = 0; k < kCrcLevels; ++k) {
+        const uint64_t span = (uint64_t)kCrcChunk << k;  // bytes under a complete level-k node
+        const uint64_t last = ((uint64_t)g.crc_len + span - 1) / span - 1;  // the last node of the level
+        g.edge_node[k] = (uint32_t)last;
+        g.x_full[k]    = XPowBytes(span);
+        g.x_edge[k]    = XPowBytes((uint64_t)g.crc_len - last * span);
+    }
     static const uint8_t sig[8] = {0x89, 0x50, 0x4e, 0x47, '\r', '\n', 0x1a, '\n'};
     uint8_t *p = g.head;
     for (int i = 0; i < 8; ++i) *p++ = sig[i];
@@ -163,20 +169,25 @@ TIMG_HD uint32_t PngChunkCrc(const uint8_t *png, const PngGeom &g, uint32_t c) {
     const uint32_t at = c * kCrcChunk, left = g.crc_len - at;
     return Crc32Bytes(png + PngCrcRegion() + at, left < kCrcChunk ? left : kCrcChunk);
 }
-// crc(A || B) = x^(8|B|) * crc(A) + crc(B): chunks of segment s left to right
-TIMG_HD uint32_t PngSegmentCrc(const uint32_t *chunk_crc, const PngGeom &g, uint32_t s) {
-    const uint32_t c0 = s * kCrcSegment, c1 = c0 + kCrcSegment < g.n_chunks ? c0 + kCrcSegment : g.n_chunks;
-    uint32_t acc = chunk_crc[c0];
-    for (uint32_t c = c0 + 1; c < c1; ++c)
-        acc = MultModP(c + 1 == g.n_chunks ? g.x_last_chunk : g.x_chunk, acc) ^ chunk_crc[c];
-    return acc;
+// crc(A || B) = x^(8|B|) * crc(A) + crc(B): the parent `parent` of level k + 1 from its children of level k
+// (child[] holds the level-k nodes from index child_base on)
+TIMG_HD uint32_t PngTreeParent(const uint32_t *child, uint32_t child_base, const PngGeom &g, uint32_t k, uint32_t parent) {
+    const uint32_t left = 2u * parent, right = left + 1u;
+    const uint32_t lv   = child[left - child_base];
+    if (right > g.edge_node[k]) return lv;  // no right child: the node is its left child
+    return MultModP(right == g.edge_node[k] ? g.x_edge[k] : g.x_full[k], lv) ^ child[right - child_base];
 }
-// ... and the segments left to right
-TIMG_HD uint32_t PngTotalCrc(const uint32_t *segment_crc, const PngGeom &g) {
-    uint32_t acc = segment_crc[0];
-    for (uint32_t s = 1; s < g.n_segments; ++s)
-        acc = MultModP(s + 1 == g.n_segments ? g.x_last_segment : g.x_segment, acc) ^ segment_crc[s];
-    return acc;
+// levels k0 .. until one node is left, in place, serially (the host's form; the kernels walk the same levels
+// with a lane per parent).  nodes[] holds `count` level-k0 nodes starting at node index `base`.
+TIMG_HD uint32_t PngTreeReduce(uint32_t *nodes, uint32_t count, uint32_t base, uint32_t k0, uint32_t levels,
+                               const PngGeom &g) {
+    for (uint32_t k = k0; k < k0 + levels && k < kCrcLevels; ++k) {
+        const uint32_t pbase = base >> 1, parents = ((base + count + 1u) >> 1) - pbase;
+        for (uint32_t r = 0; r < parents; ++r) nodes[r] = PngTreeParent(nodes, base, g, k, pbase + r);  // (r <= 2 r: in place)
+        base  = pbase;
+        count = parents;
+    }
+    return count;
 }
 TIMG_HD void PngTail(uint8_t *png, const PngGeom &g, uint32_t crc) {  // IDAT's CRC and the IEND chunk
     uint8_t *p = png + PngCrcOffset(g);
@@ -215,20 +226,28 @@ TIMG_HD uint32_t Dot0123(uint32_t v) {  // 0 * byte0 + 1 * byte1 + 2 * byte2 + 3
     return ((v >> 8) & 255u) + 2u * ((v >> 16) & 255u) + 3u * (v >> 24);
 #endif
 }
-// group xg (pixels 4 xg .. 4 xg + 3) of row y; returns the group's contribution to
-// A' = sum d_j and B' = sum (raw_n - j) d_j (the row's filter-type byte rides with group 0)
-TIMG_HD void PngBodyGroup(const uint8_t *frame, size_t stride, const PngGeom &g, uint32_t y, uint32_t xg, uint8_t *png,
-                          uint32_t *sum_a, unsigned long long *sum_b) {
+// group xg (pixels 4 xg .. 4 xg + 3) of row y.  Returns what the Adler sums need from it (the row's
+// filter-type byte rides with group 0): a = sum of its bytes d, j0 = index of its first pixel byte,
+// t = sum i * d_i over its pixel bytes (i from 0) minus 1 if it carries a filter byte -- then
+//   A' += a,   B' += (raw_n - j0) * a - t     [B' = sum (raw_n - j) d_j]
+struct PngGroupSums {
+    uint32_t a, j0;
+    int32_t t;
+};
+TIMG_HD PngGroupSums PngBodyGroup(const uint8_t *frame, size_t stride, const PngGeom &g, uint32_t y, uint32_t xg,
+                                  uint8_t *png) {
     const uint32_t x0 = xg * 4u, npx = (uint32_t)g.w - x0 < 4u ? (uint32_t)g.w - x0 : 4u;
     const uint8_t *line = frame + (size_t)y * stride;
     uint32_t prev = x0 ? GfxLoadU32(line + 4u * (x0 - 1u)) : 0u;  // (the first pixel of a row is stored as it is)
-    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    uint32_t cur[4] = {0u, 0u, 0u, 0u}, d[4] = {0u, 0u, 0u, 0u};
+    if (npx == 4u) {
+        __builtin_memcpy(cur, line + 4u * x0, 16);  // (one 16-byte load)
+    } else {
+        for (uint32_t k = 0; k < npx; ++k) cur[k] = GfxLoadU32(line + 4u * (x0 + k));
+    }
     for (uint32_t k = 0; k < 4u; ++k) {
-        if (k < npx) {
-            const uint32_t cur = GfxLoadU32(line + 4u * (x0 + k));
-            d[k]               = SubBytes4(cur, prev);
-            prev               = cur;
-        }
+        if (k < npx) d[k] = SubBytes4(cur[k], prev);
+        prev = cur[k];
     }
     uint32_t o[4], nbytes;
     if (g.bpp == 4) {
@@ -242,29 +261,34 @@ TIMG_HD void PngBodyGroup(const uint8_t *frame, size_t stride, const PngGeom &g,
         o[3] = 0u;
         nbytes = 3u * npx;
     }
-    const uint32_t j0 = y * g.row + 1u + (uint32_t)g.bpp * x0;
+    PngGroupSums r;
+    r.j0 = y * g.row + 1u + (uint32_t)g.bpp * x0;
     uint32_t a = 0, kd = 0;
     for (uint32_t q = 0; q < 4u; ++q) {  // (bytes past nbytes are zero)
         const uint32_t sq = SumBytes4(o[q]);
         a += sq;
         kd += Dot0123(o[q]) + 4u * q * sq;
     }
-    unsigned long long bsum = (unsigned long long)(g.raw_n - j0) * a - kd;
-    if (xg == 0) {  // filter type 1 in front of the row
-        png[PngRawOffset(y * g.row)] = 1;
-        a += 1u;
-        bsum += g.raw_n - y * g.row;
+    r.a = a;
+    r.t = (int32_t)kd;
+    if (xg == 0) {  // filter type 1 in front of the row: value 1 at index j0 - 1
+        png[PngRawOffset(r.j0 - 1u)] = 1;
+        r.a += 1u;   // (raw_n - (j0 - 1)) * 1 = (raw_n - j0) * 1 + 1
+        r.t -= 1;
     }
-    if (j0 / kStoredBlock == (j0 + nbytes - 1u) / kStoredBlock) {
-        uint8_t *dst = png + PngRawOffset(j0);
-        for (uint32_t q = 0; q < 4u; ++q)
-            if (4u * q + 4u <= nbytes) GfxStoreU32(dst + 4u * q, o[q]);
-        for (uint32_t i = nbytes & ~3u; i < nbytes; ++i) dst[i] = (uint8_t)(o[i >> 2] >> (8u * (i & 3u)));
+    if (r.j0 / kStoredBlock == (r.j0 + nbytes - 1u) / kStoredBlock) {
+        uint8_t *dst = png + PngRawOffset(r.j0);
+        if (nbytes == 16u) {
+            __builtin_memcpy(dst, o, 16);
+        } else {
+            for (uint32_t q = 0; q < 4u; ++q)
+                if (4u * q + 4u <= nbytes) GfxStoreU32(dst + 4u * q, o[q]);
+            for (uint32_t i = nbytes & ~3u; i < nbytes; ++i) dst[i] = (uint8_t)(o[i >> 2] >> (8u * (i & 3u)));
+        }
     } else {  // a block header lies inside the run
-        for (uint32_t i = 0; i < nbytes; ++i) png[PngRawOffset(j0 + i)] = (uint8_t)(o[i >> 2] >> (8u * (i & 3u)));
+        for (uint32_t i = 0; i < nbytes; ++i) png[PngRawOffset(r.j0 + i)] = (uint8_t)(o[i >> 2] >> (8u * (i & 3u)));
     }
-    *sum_a = a;
-    *sum_b = bsum;
+    return r;
 }
 TIMG_HD uint32_t PngBodyGroups(const PngGeom &g) { return (uint32_t)g.h * (((uint32_t)g.w + 3u) >> 2); }
 

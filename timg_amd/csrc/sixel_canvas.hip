@@ -1796,11 +1796,19 @@ __global__ void __launch_bounds__(256) CopyBandsKernel(SixelGeom g, SixelBatch b
     const uint32_t at         = s.band_off[band * 2 + 0];
     const uint32_t elide      = s.band_off[band * 2 + 1];
     const uint32_t lead       = band > 0 ? 1u : 0u;  // the elided tag sits right after '-'
-    for (uint32_t i = threadIdx.x; i < len; i += 256) {
-        if (i >= lead && i < lead + elide) continue;
-        const uint32_t o = i < lead ? i : i - elide;
-        if ((size_t)at + o < b.out_cap) out[at + o] = src[i];
+    if (lead && threadIdx.x == 0 && (size_t)at < b.out_cap) out[at] = src[0];
+    // the rest is one shifted copy: 16 bytes per lane (both ends unaligned), the last bytes one by one
+    const uint32_t from = lead + elide, n = len > from ? len - from : 0u;
+    const char *sp      = src + from;
+    char *dp            = out + at + lead;
+    const size_t room   = (size_t)at + lead < b.out_cap ? b.out_cap - ((size_t)at + lead) : 0;
+    const uint32_t m    = (uint32_t)(n < room ? n : room);
+    for (uint32_t i = threadIdx.x * 16u; i + 16u <= m; i += 256u * 16u) {
+        uint32_t v[4];
+        __builtin_memcpy(v, sp + i, 16);
+        __builtin_memcpy(dp + i, v, 16);
     }
+    for (uint32_t i = (m & ~15u) + threadIdx.x; i < m; i += 256u) dp[i] = sp[i];
 }
 
 }  // namespace

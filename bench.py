@@ -286,8 +286,18 @@ def main():
     # The shader clock ramps up over the first tens of milliseconds of load (a cold 64-frame scale launch
     # reads 0.85-0.94 ms, the same launch 0.70 ms once the clock has settled: profiles/r2): run untimed
     # steps for --prewarm seconds before the W warm-up steps, so that K timed steps see a settled clock.
+    # (With several ranks a step contains collectives: rank 0's clock decides for everybody how long the
+    # loop runs -- ranks that counted their own seconds would leave it after different numbers of steps and
+    # the next collective would never complete.)
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:
+    while True:
+        go = time.perf_counter() - t_pre < args.prewarm
+        if world > 1:
+            t = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+            dist.broadcast(t, src=0)
+            go = bool(t.item())
+        if not go:
+            break
         run_steps(1)
         torch.cuda.synchronize()
     run_steps(args.warmup)

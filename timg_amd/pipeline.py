@@ -69,10 +69,14 @@ class GridPipeline:
         return self.encode()
 
     def packed_output(self):
-        """(payload uint8 tensor, lengths int64 tensor): frames back to back."""
+        """(payload uint8 tensor, lengths int64 tensor): frames back to back, as a SNAPSHOT -- new
+        tensors, complete when this returns, so the pipeline may overwrite its buffers right away
+        (run_batched_streams lets the next step start while this step's bytes are being gathered)."""
         lens = torch.tensor(self.lengths, dtype=torch.int64)
         parts = [self.out[i, :n] for i, n in enumerate(self.lengths)]
-        return torch.cat(parts), lens.to(self.out.device)
+        payload, lens = torch.cat(parts), lens.to(self.out.device)
+        torch.cuda.current_stream(self.out.device).synchronize()
+        return payload, lens
 
     def frame_bytes(self, i: int) -> bytes:
         return self.out[i, :self.lengths[i]].cpu().numpy().tobytes()
@@ -86,8 +90,10 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
     """n_steps passes of the hot path over `src`, step k on pipeline k % n_pipes, every pipeline
     driven by its own host thread (one batch in flight per pipeline).  With several ranks the
     variable-length outputs are handed to `gather(payload, lengths)` by the CALLING thread in
-    step order -- collectives must be issued in the same order on every rank -- and a pipeline
-    starts its next step only after its previous output has been gathered.
+    step order -- collectives must be issued in the same order on every rank.  packed_output()
+    returns a snapshot, so a pipeline starts its next step as soon as its previous output has been
+    PACKED: the gather of step k (all-gather of lengths, payloads to the root) runs beside the
+    kernels of step k + 1.
 
     pipes: objects with scale(src), encode(), packed_output() (and .stream when record_event is
     given); record_event(stream) -> event, used to bracket the two stages of each step."""
@@ -124,8 +130,8 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
             if errors:
                 break
             payload, lens = pipes[k % n_pipes].packed_output()
-            gather(payload, lens)
             consumed[k].set()
+            gather(payload, lens)
     for t in threads:
         t.join()
     if errors:

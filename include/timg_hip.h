@@ -19,7 +19,12 @@
  * `stream` is a hipStream_t (NULL = the context's own stream); work is
  * enqueued on it and, unless stated otherwise, NOT synchronised: device
  * pointers are valid to consume on the same stream, host pointers force a
- * synchronisation before return.
+ * synchronisation before return.  The context's own stream is NON-BLOCKING: it
+ * is not ordered against the NULL stream or any other stream.  Device buffers
+ * that another stream fills or clears (a framework's allocator zeroing `dst`,
+ * a decoder writing `src`) must be finished -- or that stream passed here as
+ * `stream` -- before the call; nothing in this library waits for foreign
+ * streams.
  */
 #ifndef TIMG_HIP_H
 #define TIMG_HIP_H

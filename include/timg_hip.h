@@ -232,6 +232,12 @@ void timg_hip_block_canvas_forget(timg_hip_block_canvas *c);
  * within a stated Delta-E of the CPU restatement (libsixel is un-vendored:
  * parity unpinned). */
 #define TIMG_HIP_SIXEL_BROKEN_CURSOR 1 /* SixelOptions::known_broken_cursor_placement */
+/* libsixel's lookup cache exactly as sixel_encode fills it: a 15-bit cell answers with the palette entry
+ * nearest to the FIRST pixel value that lands in it, in raster order, diffused errors included.  That order
+ * is inherently serial: one wave walks a frame (~0.3 s per 800x450 frame, frames of a batch in parallel).
+ * Without the flag a cell answers with the entry nearest to its centre and the diffusion is pipelined
+ * (1.6 ms per 64 frames); both rules stay within the per-pixel bound stated in DESIGN.md. */
+#define TIMG_HIP_SIXEL_FIRST_HIT 2
 
 size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
 /* Frames up to 4095 pixels wide (columns travel in 12-bit fields); wider ones are refused

@@ -291,6 +291,33 @@ def test_sixel_geometry_corner_cases(hip, oracle, kind, w, h):
     assert len(got) == len(want) and got == want, (len(got), len(want))
 
 
+@pytest.mark.parametrize("kind,w,h", [("photo", 320, 203), ("alpha", 200, 100), ("noise", 97, 61), ("photo", 64, 7),
+                                      ("noise", 33, 6), ("photo", 2, 13), ("alpha", 1, 1), ("photo", 800, 450)])
+def test_sixel_first_hit_lookup_is_libsixels_cache(hip, oracle, kind, w, h):
+    """TIMG_HIP_SIXEL_FIRST_HIT: the 15-bit lookup cache filled the way sixel_encode fills it (the entry of a cell
+    is the palette colour nearest to the first pixel value that lands in it, raster order, diffused errors
+    included) -- byte-identical to the restatement's lookup_mode 0, pad rows and checkerboard included."""
+    fb = synth.make(kind, w, h, seed=9)
+    got = hip.sixel_encode(fb, w, h, flags=timg_amd.TimgHip.SIXEL_FIRST_HIT, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 4),
+                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 4, 4, lookup_mode=0)
+    assert len(got) == len(want) and got == want, (len(got), len(want))
+
+
+def test_sixel_first_hit_batch_and_few_colours(hip, oracle):
+    n, w, h = 3, 120, 40
+    frames = np.stack([synth.photo(w, h, 70 + i) for i in range(n)])
+    outs = hip.sixel_encode(frames, w, h, flags=timg_amd.TimgHip.SIXEL_FIRST_HIT, n_frames=n)
+    for i in range(n):
+        assert outs[i] == oracle.sixel_encode(frames[i], has_getter=False, lookup_mode=0), i
+    fb = np.zeros((36, 120, 4), np.uint8)  # <= 256 colours: no diffusion, the palette is the histogram
+    fb[..., 3] = 255
+    for i in range(20):
+        fb[:, 6 * i:6 * i + 6, :3] = (8 * i % 256, 16 * (i % 16), 248 - 8 * (i % 32))
+    assert hip.sixel_encode(fb, 120, 36, flags=timg_amd.TimgHip.SIXEL_FIRST_HIT)[0] == \
+        oracle.sixel_encode(fb, has_getter=False, lookup_mode=0)
+
+
 def test_sixel_within_stated_delta_e_of_the_libsixel_like_lookup(hip, oracle):
     """north_star: sixel palette selection within a stated dE.  The HIP path (exact nearest
     colour per 15-bit cell) against the restatement's libsixel-like lossy lookup cache

@@ -1074,6 +1074,98 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     if (gave_up && lane == 0) atomicExch(b.error, 1);
 }
 
+// ---- K4, first-hit variant: libsixel's lookup cache as libsixel fills it -----------------------------
+// sixel_encode looks a pixel up through a 15-bit (5:5:5) cache whose entry is the palette colour nearest to
+// the FIRST pixel value that lands in the cell -- first in raster order, with the diffused errors of all
+// earlier pixels already added (what src/sixel-canvas.cc:144-145 executes; oracle/sixel.c lookup_mode 0).
+// The cache makes every lookup depend on every earlier pixel, so there is exactly one order: this kernel
+// walks a frame serially, ONE WAVE per frame -- the lanes agree on every value, lane 0 writes, a cache miss
+// searches the palette with all 64 lanes.  Pixel rows y and y + 1 live in LDS as 8-bit RGB and take the error
+// terms in place, clamped after every single contribution, as libsixel's in-place diffusion does.  Two orders
+// of magnitude slower than the pipelined kernel above (TIMG_HIP_SIXEL_FIRST_HIT asks for it): a validation
+// mode, and the proof that the difference between the two is the lookup rule and nothing else.
+// data + error * num / 16 with C's truncating division, clamped to 0..255 (libsixel's diffuse step)
+__device__ __forceinline__ void FirstHitAdd(uint8_t *rows, int at, int err, int num, int lane) {
+    int c = (int)rows[at] + err * num / 16;
+    c     = c < 0 ? 0 : (c > 255 ? 255 : c);
+    if (lane == 0) rows[at] = (uint8_t)c;
+}
+__device__ __forceinline__ void FirstHitLoadRow(const uint8_t *frame, const SixelGeom &g, int y, uint8_t *rows, int at,
+                                                int lane) {
+    // (PaddedPixel's logic on scalars: with `g.pad[alt]` indexed dynamically here, instcombine of ROCm 7.2's
+    // clang dies in visitAllocaInst)
+    const uint32_t pad0 = g.pad[0], pad1 = g.pad[1];
+    const int pw = g.pad_pw, ph = g.pad_ph, checker = g.pad_checker, h = g.h;
+    const size_t stride = g.stride;
+    for (int x = lane; x < g.w; x += 64) {
+        uint32_t px;
+        if (y < h) px = *reinterpret_cast<const uint32_t *>(frame + (size_t)y * stride + (size_t)x * 4);
+        else px = (checker && (((x / pw) + (y / ph)) & 1)) ? pad1 : pad0;
+        rows[at + 3 * x]     = (uint8_t)px;
+        rows[at + 3 * x + 1] = (uint8_t)(px >> 8);
+        rows[at + 3 * x + 2] = (uint8_t)(px >> 16);
+    }
+}
+__global__ void __launch_bounds__(64) DitherFirstHitKernel(SixelGeom g, SixelBatch b) {
+    extern __shared__ uint32_t lds[];
+    const int W = g.w, H = g.h6;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    uint16_t *cache = reinterpret_cast<uint16_t *>(lds);        // [32768]: palette index + 1, 0 = empty
+    uint32_t *pal   = lds + 16384;                              // [256]: r | g << 8 | b << 16
+    uint8_t *rows   = reinterpret_cast<uint8_t *>(pal + 256);   // [2][row_bytes]
+    const int row_bytes = (3 * W + 3) & ~3;
+    const SixelFrameScratch s = FrameScratch(b, g, f);
+    const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
+    const int ncolors         = s.meta[0];
+    const bool dither         = s.meta[1] != 0;
+    for (int i = lane; i < 16384; i += 64) lds[i] = 0u;
+    for (int i = lane; i < 256; i += 64)
+        pal[i] = i < ncolors ? (uint32_t)s.palette[i * 3] | ((uint32_t)s.palette[i * 3 + 1] << 8) |
+                                   ((uint32_t)s.palette[i * 3 + 2] << 16)
+                             : 0u;
+    FirstHitLoadRow(frame, g, 0, rows, 0, lane);
+    if (H > 1) FirstHitLoadRow(frame, g, 1, rows, row_bytes, lane);
+    __syncthreads();
+    for (int y = 0; y < H; ++y) {
+        // byte offsets into rows[] (plain integers: a select between two LDS pointers crashed the compiler)
+        const int cur = (y & 1) * row_bytes, nxt = ((y + 1) & 1) * row_bytes;
+        uint8_t *idx_row = s.index + (size_t)y * g.idx_stride;
+        for (int x = 0; x < W; ++x) {
+            const int r = rows[cur + 3 * x], gg = rows[cur + 3 * x + 1], bb = rows[cur + 3 * x + 2];
+            const uint32_t cell = ((uint32_t)(r >> 3) << 10) | ((uint32_t)(gg >> 3) << 5) | (uint32_t)(bb >> 3);
+            int ci = (int)__builtin_amdgcn_readfirstlane((int)cache[cell]) - 1;
+            if (ci < 0) {  // first pixel in this cell: the nearest palette entry (smallest index among equals)
+                uint32_t best = 0xffffffffu;
+                for (int i = lane; i < ncolors; i += 64) {
+                    const uint32_t p = pal[i];
+                    const int dr = r - (int)(p & 255u), dg = gg - (int)((p >> 8) & 255u), db = bb - (int)((p >> 16) & 255u);
+                    best = min(best, ((uint32_t)(dr * dr + dg * dg + db * db) << 8) | (uint32_t)i);
+                }
+                ci = (int)(~WaveMaxU32(~best) & 255u);
+                if (lane == 0) cache[cell] = (uint16_t)(ci + 1);
+            }
+            if (lane == 0) idx_row[x] = (uint8_t)ci;
+            if (dither && x < W - 1 && y < H - 1) {
+                const uint32_t p = pal[ci];
+                // (the "below left" neighbour of a row's first pixel is, in libsixel's linear addressing, the
+                // LAST pixel of the same row)
+                const int right = cur + 3 * (x + 1), below_left = x == 0 ? cur + 3 * (W - 1) : nxt + 3 * (x - 1);
+                const int below = nxt + 3 * x, below_right = nxt + 3 * (x + 1);
+                for (int n = 0; n < 3; ++n) {
+                    const int e = (n == 0 ? r : n == 1 ? gg : bb) - (int)((p >> (8 * n)) & 255u);
+                    FirstHitAdd(rows, right + n, e, 7, lane);
+                    FirstHitAdd(rows, below_left + n, e, 3, lane);
+                    FirstHitAdd(rows, below + n, e, 5, lane);
+                    FirstHitAdd(rows, below_right + n, e, 1, lane);
+                }
+            }
+        }
+        __syncthreads();
+        if (y + 2 < H) FirstHitLoadRow(frame, g, y + 2, rows, cur, lane);  // (row y is done: its buffer takes row y + 2)
+        __syncthreads();
+    }
+}
+
 // ---- K5: band encode, three kernels --------------------------------------------------------
 // libsixel encodes a 6-row band as "nodes" (a colour's run of columns, gaps of < 10
 // empty columns merged), sorts them by (start asc, end desc, colour asc) and packs them
@@ -1984,6 +2076,11 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)HistKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLdsBytes));
+    const bool first_hit       = (flags & TIMG_HIP_SIXEL_FIRST_HIT) != 0;
+    const size_t first_hit_lds = (16384 + 256) * sizeof(uint32_t) + 2 * (size_t)((3 * w + 3) & ~3);
+    if (first_hit)
+        TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherFirstHitKernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)first_hit_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kCutLdsBytes));
@@ -2040,11 +2137,15 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
 
         hipLaunchKernelGGL(HistKernel, dim3(nfr), dim3(kHistThreads), kHistLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
-        hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
-        if (w > 2)
-            hipLaunchKernelGGL(DitherKernel<false>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
-        else
-            hipLaunchKernelGGL(DitherKernel<true>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+        if (first_hit) {
+            hipLaunchKernelGGL(DitherFirstHitKernel, dim3(nfr), dim3(64), first_hit_lds, gs, g, gb);
+        } else {
+            hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
+            if (w > 2)
+                hipLaunchKernelGGL(DitherKernel<false>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+            else
+                hipLaunchKernelGGL(DitherKernel<true>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+        }
         if (wide_bands)
             hipLaunchKernelGGL(BandNodesKernel<true>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         else

@@ -185,6 +185,7 @@ class TimgHip:
     """One timg_hip_ctx."""
 
     QUARTER, UPPER, COLOR256 = 1, 2, 4
+    SIXEL_BROKEN_CURSOR, SIXEL_FIRST_HIT = 1, 2  # timg_hip_sixel_encode flags
 
     def __init__(self, device: int = 0):
         self.L = load_library()

@@ -1,5 +1,7 @@
 #include "hip-sixel-canvas.h"
 
+#include <cstdlib>
+
 #include <cassert>
 #include <cstring>
 #include <functional>
@@ -25,6 +27,16 @@ HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_po
       ctx_(SharedHipContext()) {
     if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
     DeviceFrameConsumerCreated();
+}
+
+// TIMG_HIP_SIXEL_FIRST_HIT=1 in the environment: libsixel's lookup cache exactly as sixel_encode fills it (serial,
+// ~0.3 s per 800x450 frame) instead of the pipelined nearest-to-the-cell's-centre rule
+int HipSixelCanvas::EncodeFlags() const {
+    static const bool first_hit = [] {
+        const char *e = getenv("TIMG_HIP_SIXEL_FIRST_HIT");
+        return e && *e && *e != '0';
+    }();
+    return (broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0) | (first_hit ? TIMG_HIP_SIXEL_FIRST_HIT : 0);
 }
 
 int HipSixelCanvas::cell_height_for_pixels(int pixels) const {  // src/sixel-canvas.cc:157-172
@@ -59,7 +71,7 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch) {
     const size_t slot = timg_hip_sixel_max_bytes(batch.w, batch.h) * 2;
     std::vector<char> bytes(slot * n);
     std::vector<size_t> lens(n);
-    const int flags = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
+    const int flags = EncodeFlags();
     if (timg_hip_sixel_encode(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
                               bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_sixel_encode");
@@ -125,7 +137,7 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     } else {
         memcpy(pixels->data(), fb_orig.begin(), frame_bytes);
     }
-    const int flags = broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0;
+    const int flags = EncodeFlags();
     const std::function<OutBuffer()> encode_fun = [=]() {
         OutBuffer out(buffer, offset - buffer);
         size_t len = 0;

@@ -50,6 +50,7 @@ private:
     const DisplayOptions &options_;
     const bool full_cell_jump_;
     const bool broken_cursor_;
+    int EncodeFlags() const;  // timg_hip_sixel_encode flags of this canvas
     ThreadPool *const executor_;
     timg_hip_ctx *const ctx_;
     int hold_limit_   = 1;

@@ -74,16 +74,32 @@ __device__ __forceinline__ uint32_t GammaByte(float v) {
     return s > 255.0f ? 255u : (uint32_t)s;
 }
 
+// One channel of LinearColor(px).AlphaBlend(bg).repack(): x = c^2 a + bg^2 (255 - a) is an exact integer
+// below 2^24 in fp32 (c, a bytes; bg^2 <= 65025), and the reference then computes
+//     byte = trunc(min(255, sqrtf(x / 255.0f)))      -- correctly rounded divide and square root.
+// Over ALL 16 581 376 possible x that byte equals floor(sqrt(x / 255)) in exact arithmetic, i.e. the largest
+// k with 255 k^2 <= x (tests/test_blend_identity.py enumerates them: the rounding of the quotient and of the
+// root never carries a value across an integer).  So no IEEE divide (10 instructions) and no correctly rounded
+// sqrt (~20): an approximate root, truncated, is at most one off, and two comparisons against 255 k^2 and
+// 255 (k + 1)^2 -- exact in fp32 -- settle it.  ~14 instructions per channel instead of ~45.
+__device__ __forceinline__ uint32_t BlendChannelByte(float x) {
+    float k = __builtin_truncf(__builtin_amdgcn_sqrtf(x * (1.0f / 255.0f)));
+    k       = (k * k) * 255.0f > x ? k - 1.0f : k;                    // (products exact: k <= 256)
+    const float k1 = k + 1.0f;
+    k       = (k1 * k1) * 255.0f <= x ? k1 : k;
+    return (uint32_t)k;                                               // (x <= 255 * 255^2: k <= 255)
+}
+
 // LinearColor(px).AlphaBlend(bg).repack() for a pixel whose alpha != 255
 // (src/framebuffer.h:155-161, src/framebuffer.cc:126-131).
 __device__ __forceinline__ uint32_t BlendOver(uint32_t px, const float bg[3]) {
     const uint32_t r8 = px & 0xffu, g8 = (px >> 8) & 0xffu, b8 = (px >> 16) & 0xffu;
     const float a  = (float)(px >> 24);
     const float na = 255.0f - a;
-    const float r  = ((float)(r8 * r8) * a + bg[0] * na) / 255.0f;
-    const float g  = ((float)(g8 * g8) * a + bg[1] * na) / 255.0f;
-    const float b  = ((float)(b8 * b8) * a + bg[2] * na) / 255.0f;
-    return GammaByte(r) | (GammaByte(g) << 8) | (GammaByte(b) << 16) | 0xff000000u;
+    const float r  = (float)(r8 * r8) * a + bg[0] * na;  // (exact integers: see BlendChannelByte)
+    const float g  = (float)(g8 * g8) * a + bg[1] * na;
+    const float b  = (float)(b8 * b8) * a + bg[2] * na;
+    return BlendChannelByte(r) | (BlendChannelByte(g) << 8) | (BlendChannelByte(b) << 16) | 0xff000000u;
 }
 
 }  // namespace timg_amd

@@ -41,3 +41,13 @@ def test_device_recipe_survives_an_inexact_root():
         root = (exact * (1.0 + rel)).astype(np.float32)
         root = np.maximum(root, np.float32(0.0))
         assert np.array_equal(_device_recipe(x, root), f), rel
+
+
+def test_checkerboard_column_division_by_multiplication():
+    """CheckerAlt (timg_amd/csrc/device_plan.h): x / pw as mulhi(x, ceil(2^32 / pw)) for pixel columns and cell
+    widths below 65 536 -- exact for every column and a sweep of cell widths incl. the extremes."""
+    x = np.arange(65536, dtype=np.uint64)
+    for pw in list(range(2, 300)) + [511, 512, 513, 1000, 4095, 4096, 4097, 32767, 32768, 65535]:
+        magic = (2 ** 32 + pw - 1) // pw
+        assert magic < 2 ** 32
+        assert np.array_equal((x * np.uint64(magic)) >> np.uint64(32), x // np.uint64(pw)), pw

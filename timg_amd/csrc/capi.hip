@@ -44,6 +44,7 @@ DevBlend MakeDevBlend(const timg_hip_blend *b) {
         d.pw = b->pattern_w;
         d.ph = b->pattern_h;
     }
+    d.pw_magic = d.pw > 1 ? (unsigned)((0x100000000ull + (unsigned)d.pw - 1) / (unsigned)d.pw) : 0u;
     return d;
 }
 

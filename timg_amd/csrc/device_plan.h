@@ -29,10 +29,26 @@ struct DevBlend {
     int enabled;     // blend at all (getter present and bg alpha != 0)
     int checker;     // alternate bg / pattern
     int pw, ph;      // checker cell size in pixels
+    // ceil(2^32 / pw) (0 for pw == 1): x / pw == mulhi(x, pw_magic) for every x below 2^32 / pw -- one
+    // instruction per pixel instead of the ~25 of a division by a run-time divisor
+    unsigned pw_magic;
     int start_row;
     float bg[3];     // linear r,g,b of the background
     float pat[3];    // linear r,g,b of the pattern colour
 };
+
+#if defined(__HIPCC__)
+// (x / pw + y / ph) & 1 of Framebuffer::AlphaComposeBackground's checkerboard (src/framebuffer.cc:135-149);
+// x a pixel column (< 65 536), y uniform
+__device__ __forceinline__ bool CheckerAlt(const DevBlend &blend, int x, int y) {
+    unsigned qx;
+    if ((unsigned)x < 65536u && (unsigned)blend.pw < 65536u)  // (x * pw < 2^32: the multiplication is exact)
+        qx = blend.pw_magic ? __umulhi((unsigned)x, blend.pw_magic) : (unsigned)x;
+    else
+        qx = (unsigned)x / (unsigned)blend.pw;  // (frames wider than 65 536 pixels: the long way)
+    return blend.checker && ((qx + (unsigned)(y / blend.ph)) & 1u);
+}
+#endif
 
 struct FrameBatch {
     const uint8_t *src;

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t FinishPixel(const Px7 &acc, int x, int y,
     if ((out >> 24) != 0xffu && y >= blend.start_row) {
         if (transparent_flag) *transparent_flag = 1;  // benign race: all write 1
         if (blend.enabled) {
-            const bool alt = blend.checker && (((x / blend.pw) + (y / blend.ph)) & 1);
+            const bool alt = CheckerAlt(blend, x, y);
             out            = BlendOver(out, alt ? blend.pat : blend.bg);
         }
     }
@@ -148,7 +148,7 @@ CopyBlendKernel(DevPlan plan, DevBlend blend, FrameBatch batch) {
     if ((px >> 24) != 0xffu && y >= blend.start_row) {
         if (batch.transparent_flags) batch.transparent_flags[f] = 1;
         if (blend.enabled) {
-            const bool alt = blend.checker && (((x / blend.pw) + (y / blend.ph)) & 1);
+            const bool alt = CheckerAlt(blend, x, y);
             px             = BlendOver(px, alt ? blend.pat : blend.bg);
         }
     }
@@ -170,7 +170,7 @@ AlphaComposeKernel(uint8_t *fb, int w, int h, size_t stride, size_t frame_stride
     if ((px >> 24) == 0xffu) return;
     if (flags) flags[f] = 1;
     if (!blend.enabled) return;
-    const bool alt = blend.checker && (((x / blend.pw) + (y / blend.ph)) & 1);
+    const bool alt = CheckerAlt(blend, x, y);
     *p             = BlendOver(px, alt ? blend.pat : blend.bg);
 }
 

@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t FinishStreamPixel(const Px7 &acc, int x, int
     if ((out >> 24) != 0xffu && y >= blend.start_row) {
         if (flag) *flag = 1;
         if (blend.enabled) {
-            const bool alt = blend.checker && (((x / blend.pw) + (y / blend.ph)) & 1);
+            const bool alt = CheckerAlt(blend, x, y);
             const float bg[3] = {alt ? blend.pat[0] : blend.bg[0], alt ? blend.pat[1] : blend.bg[1],
                                  alt ? blend.pat[2] : blend.bg[2]};
             out = BlendOver(out, bg);

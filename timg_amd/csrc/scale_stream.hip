@@ -1000,8 +1000,10 @@ __device__ __forceinline__ float FromPartner(float v) {
 
 // TAPS = taps per LANE (the column's taps 2j + parity): the loop is unrolled with its
 // weights in registers.
+// (three waves per SIMD for the opaque and the premultiplied set: the opaque one came out at 170 registers --
+// two over the budget of three waves -- and ran at two; the 40-tap instantiations spill at 168 and stay at two)
 template <int M, int TAPS>
-__global__ void __launch_bounds__(kThreadsH)
+__global__ void __launch_bounds__(kThreadsH) __attribute__((amdgpu_waves_per_eu((M == kFull || TAPS > 20) ? 2 : 3, (M == kFull || TAPS > 20) ? 2 : 3)))
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
                    int gen, int win, int w4) {
     // One row buffer of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at

@@ -171,7 +171,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # (a collective that cannot complete fails after three minutes instead of holding the node)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=180))
 
     cfg = dict(CONFIGS[args.config])
     if args.frames:

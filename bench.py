@@ -168,13 +168,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # TIMG_DIST_BACKEND=gloo: the collectives travel through host memory.  With it, several ranks can share one
+    # GPU (LOCAL_RANK modulo the device count) -- the multi-rank control flow of this script can then be exercised
+    # on a single-GPU box; the numbers of such a run mean nothing.
+    backend = os.environ.get("TIMG_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # (a collective that cannot complete fails after three minutes instead of holding the node)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=180))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=180))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180))
 
     cfg = dict(CONFIGS[args.config])
     if args.frames:
@@ -281,7 +291,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -296,7 +306,7 @@ def main():
     while True:
         go = time.perf_counter() - t_pre < args.prewarm
         if world > 1:
-            t = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+            t = torch.tensor([1 if go else 0], dtype=torch.int32, device=comm_dev)
             dist.broadcast(t, src=0)
             go = bool(t.item())
         if not go:
@@ -312,14 +322,18 @@ def main():
     encode_ms = [b.elapsed_time(c) for _, b, c in events]
     sizes = [c.shape[0] for c in chunks] * args.steps if strong else [chunk] * len(events)
     full = [s for s, n in zip(scale_ms, sizes) if n == chunk]  # (a ragged tail launch is not the roofline's launch)
+    roof_frames = chunk
+    if not full:  # this rank's shard is smaller than a batch (or empty): what it launched, as it is
+        full = scale_ms
+        roof_frames = max(sizes) if sizes else chunk
     scale_avg_ms = sum(full) / max(1, len(full))
-    alg_bytes = pipe.scaler.algorithmic_bytes() * chunk  # per launch (one full batch)
-    achieved = alg_bytes / (scale_avg_ms * 1e-3) / 1e9
+    alg_bytes = pipe.scaler.algorithmic_bytes() * roof_frames  # per launch (one full batch)
+    achieved = alg_bytes / (scale_avg_ms * 1e-3) / 1e9 if scale_avg_ms > 0 else 0.0
     frames_total = cfg["frames"] if strong else world * cfg["frames"]
     total_px = frames_total * in_w * in_h * args.steps
     value = total_px / 1e6 / elapsed
     info = pipe.scaler.info()
-    out_bytes = sum(pipe.lengths)
+    out_bytes = sum(pipe.lengths or [])  # (None on a rank whose shard is empty)
 
     canvas_name = {"sixel": "sixel", "quarter": "quarter-block", "half": "half-block"}.get(mode, mode + " (--compress=0)")
     result = {

@@ -26,6 +26,9 @@ def gather_frames_to_root(payload: torch.Tensor, lengths: torch.Tensor, root: in
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lengths = lengths.to(torch.int64)
+    if world > 1 and dist.get_backend() == "gloo" and payload.is_cuda:
+        # (gloo has no point-to-point for device tensors: through host memory -- a testing configuration)
+        payload, lengths = payload.cpu(), lengths.cpu()
     if world == 1:
         offs = torch.cumsum(lengths, 0) - lengths
         return [[payload[int(o):int(o) + int(n)] for o, n in zip(offs.tolist(), lengths.tolist())]]

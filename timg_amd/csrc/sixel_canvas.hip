@@ -219,7 +219,12 @@ __global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBat
 // Inside a split: boxes of <= 64 colours are sorted in registers (ds_permute), up to 256
 // colours four entries per lane, larger ones by a stable per-lane-segment counting sort on
 // the 5-bit key.  The list itself is never materialised: see "The box list" in the kernel.
-constexpr int kCutWaves      = 8;
+// (12 waves = 12 speculative splits per round: 320 us per 64 frames against 346 with 8; the per-wave scratch of a
+// 13th would not fit beside the 96 KB colour table and the box list any more)
+#ifndef TIMG_CUT_WAVES
+#define TIMG_CUT_WAVES 12
+#endif
+constexpr int kCutWaves      = TIMG_CUT_WAVES;
 constexpr int kCutLdsEntries = 12288;             // colour table kept in LDS up to this size
 // words of per-wave scratch: [64][33] 16-bit counters (a lane's segment of a box and every
 // exclusive prefix stay below 65536: a box has at most 32768 colours) plus 32 + 32 key totals /

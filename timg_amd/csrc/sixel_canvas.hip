@@ -921,7 +921,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // A poll is an LDS round trip in the middle of a step: when the producer is not far
         // enough ahead, wait until it is kPollBatch columns further than needed, so that a wave
         // that runs right behind its producer polls every kPollBatch steps, not every step.
-        constexpr int kPollBatch = 4;
+#ifndef TIMG_DITHER_POLL
+#define TIMG_DITHER_POLL 4
+#endif
+        constexpr int kPollBatch = TIMG_DITHER_POLL;
         int spins = 0;
         auto wait_for = [&](int need) __attribute__((always_inline)) {
             if (avail < need) {

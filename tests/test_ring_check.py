@@ -92,3 +92,27 @@ def test_built_library_passes():
     r = subprocess.run([sys.executable, CHECK, BUILT], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "4 kernels" in r.stdout
+    # the sixel diffusion keeps eight source pixels in flight the same way (two instantiations)
+    sixel = BUILT.replace("scale_stream", "sixel_canvas")
+    r = subprocess.run([sys.executable, CHECK, sixel], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "2 kernels" in r.stdout
+
+
+def test_single_register_ring_is_checked_too(tmp_path):
+    body = """\
+_Z6kernelv:
+\t;;#ASMSTART
+\tglobal_load_dword v7, v[20:21], off
+\t;;#ASMEND
+\tv_add_u32_e32 v8, 1, v7
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0) ; ring v7
+\t;;#ASMEND
+\ts_endpgm
+.Lfunc_end0:
+"""
+    path = tmp_path / "k.s"
+    path.write_text(body)
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "v[7:7]" in r.stdout

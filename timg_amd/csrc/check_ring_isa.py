@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""check_ring_isa.py <device assembly of scale_stream.hip>
+"""check_ring_isa.py <device assembly of scale_stream.hip or sixel_canvas.hip>
 
 ScaleStreamMKernel keeps source rows in flight in a ring of register sets that are loaded by inline
-asm (`global_load_dwordx4`) and released by an inline-asm `s_waitcnt vmcnt(n) ; ring v[a:b]`.  The
+asm (`global_load_dwordx4`) and released by an inline-asm `s_waitcnt vmcnt(n) ; ring v[a:b]`; the sixel
+DitherKernel does the same with source pixels (`global_load_dword`, `; ring vN`).  The
 compiler does not know that such a load completes later: this script proves, on the generated code,
 that on no path between a set's load and its wait an instruction outside the asm statements names one
 of its registers (a copy for a tied operand, a live-range split, a back-edge copy into another register
@@ -17,6 +18,7 @@ import sys
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"global_load_dwordx4 v\[(\d+):(\d+)\]")
+LOAD1 = re.compile(r"global_load_dword v(\d+),")  # (the sixel diffusion's one-pixel ring)
 WAIT = re.compile(r"s_waitcnt vmcnt\(\d+\) ; ring (.*)")
 
 
@@ -52,6 +54,9 @@ def parse_blocks(lines):
             m = LOAD.match(code)
             if m:
                 blocks[-1].ops.append((no, "load", (int(m.group(1)), int(m.group(2)))))
+            m = LOAD1.match(code)
+            if m:
+                blocks[-1].ops.append((no, "load", (int(m.group(1)), int(m.group(1)))))
             m = WAIT.match(code)
             if m:
                 what = m.group(1).strip()
@@ -159,7 +164,7 @@ def main(path):
         print("%s: no kernel with a register ring found" % path)
         status = 1
     if status == 0:
-        print("check_ring_isa: %d kernels, no instruction touches a register set in flight" % checked)
+        print("check_ring_isa: %s: %d kernels, no instruction touches a register set in flight" % (path.split("/")[-1], checked))
     return status
 
 

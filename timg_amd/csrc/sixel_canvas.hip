@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // (no early exit inside the unrolled body: with one the compiler loses count of the
         // loads in flight; the up to 7 extra steps find every lane out of range)
 #define TIMG_DITHER_STEP(k, P)                                    \
-    asm volatile("s_waitcnt vmcnt(7)" : "+v"(P) : : "memory");    \
+    asm volatile("s_waitcnt vmcnt(7) ; ring %0" : "+v"(P) : : "memory"); \
     step(t + k, P, (k & 1) != 0);                                 \
     P = fetch(t + k + kDitherAhead);
         for (int t = 0; t < steps; t += 8) {
@@ -1071,7 +1071,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             TIMG_DITHER_STEP(7, p7)
         }
         // the 8 requests still in flight must land before their registers are used for anything else
-        asm volatile("s_waitcnt vmcnt(0)"
+        asm volatile("s_waitcnt vmcnt(0) ; ring all"
                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
                      :
                      : "memory");

@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
 
 
+def pytest_sessionstart(session):
+    """On a GPU box, before any test: is the BOX healthy?  (tests/box_canary.py: pure torch in a child
+    process, retried.)  The verdict goes to stderr so that it is in the driver's log whatever happens next;
+    an unhealthy box does not stop the run -- the tests then fail on their own, with this line above them."""
+    if os.environ.get("TIMG_SKIP_CANARY") or not os.path.exists("/dev/kfd"):
+        return
+    import box_canary
+    ok, text = box_canary.run_canary()
+    sys.__stderr__.write(("[box canary] GPU BOX OK: " if ok else
+                          "[box canary] GPU BOX UNHEALTHY (pure torch, none of this repository's code): ") + text + "\n")
+    sys.__stderr__.flush()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the checker (oracle/) and the product library exist.  Building

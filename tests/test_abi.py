@@ -105,27 +105,6 @@ def test_header_is_valid_c99():
 
 
 @pytest.mark.gpu
-def test_rccl_gather_through_the_c_abi_world_1(hip):
-    """timg_hip_gather_to_root with one rank (all this box has): the same calls a multi-GPU job makes --
-    ncclCommInitRank, ncclAllGather of the lengths, the payload hand-over -- in a process that also holds
-    torch's HIP runtime."""
-    import numpy as np
-    from timg_amd import comm
-    c = comm.Comm(0, 1, 0, comm.Comm.unique_id())
-    rng = np.random.default_rng(5)
-    lens = rng.integers(1, 5000, 9)
-    data = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
-    src = hip.upload(data)
-    dst = hip.malloc(int(lens.sum()) + 64)
-    all_len, total = c.gather_to_root(src, lens, n_frames_max=12, recv_ptr=dst, recv_cap=int(lens.sum()) + 64)
-    assert total == lens.sum() and (all_len[0, :9] == lens).all() and (all_len[0, 9:] == 0).all()
-    assert np.array_equal(hip.download(dst, total), data)
-    hip.free(src)
-    hip.free(dst)
-    c.close()
-
-
-@pytest.mark.gpu
 def test_c_example_runs_and_matches_the_python_binding(oracle):
     """examples/abi_demo.c (plain C against the C-ABI): its sixel stream decodes to the 320x200
     picture, its quarter-block output is what the oracle produces for the same pixels."""

@@ -31,6 +31,7 @@ SCALE_CASES = [
     ("photo", 1280, 720, 400, 225),
     ("alpha", 1, 1, 5, 5),
     ("alpha", 5, 5, 1, 1),
+    ("alpha", 320, 200, 100, 56),  # __graft_entry__.smoke()'s geometry
 ]
 
 

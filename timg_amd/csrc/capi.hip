@@ -107,7 +107,7 @@ void timg_hip_destroy(timg_hip_ctx *ctx) {
 int timg_hip_malloc(timg_hip_ctx *ctx, size_t bytes, void **dev_ptr) {
     if (!ctx || !dev_ptr) return TIMG_HIP_ERR_ARG;
     TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(dev_ptr, bytes ? bytes : 1);
+    hipError_t e = timg_amd::DevMalloc(dev_ptr, bytes);
     if (e == hipErrorOutOfMemory) return ctx->Fail(TIMG_HIP_ERR_NOMEM, "hipMalloc(%zu)", bytes);
     if (e != hipSuccess) return ctx->FailHip(e, "hipMalloc");
     return TIMG_HIP_OK;
@@ -115,7 +115,7 @@ int timg_hip_malloc(timg_hip_ctx *ctx, size_t bytes, void **dev_ptr) {
 
 int timg_hip_free(timg_hip_ctx *ctx, void *dev_ptr) {
     if (!ctx) return TIMG_HIP_ERR_ARG;
-    TIMG_HIP_TRY(ctx, hipFree(dev_ptr));
+    TIMG_HIP_TRY(ctx, timg_amd::DevFree(dev_ptr));
     return TIMG_HIP_OK;
 }
 
@@ -181,10 +181,10 @@ int timg_hip_scaler_create(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, in
     memcpy(&host[o_vi], p.v_rows.data(), p.v_rows.size() * sizeof(int));
     memcpy(&host[o_vc], p.v_coeff.data(), p.v_coeff.size() * sizeof(float));
     hipError_t e = hipSetDevice(ctx->device);
-    if (e == hipSuccess) e = hipMalloc(&s->tables, total);
+    if (e == hipSuccess) e = timg_amd::DevMalloc(&s->tables, total);
     if (e == hipSuccess) e = hipMemcpy(s->tables, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (s->tables) (void)hipFree(s->tables);
+        if (s->tables) (void)timg_amd::DevFree(s->tables);
         delete s;
         return ctx->FailHip(e, "uploading resample tables");
     }
@@ -211,7 +211,7 @@ int timg_hip_scaler_create(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, in
 void timg_hip_scaler_destroy(timg_hip_scaler *s) {
     if (!s) return;
     timg_amd::ReleaseStreamSchedule(s);
-    if (s->tables) (void)hipFree(s->tables);
+    if (s->tables) (void)timg_amd::DevFree(s->tables);
     delete s;
 }
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/timg_hip.h"
+#include "dev_alloc.h"
 #include "device_plan.h"
 #include "resample_plan.h"
 
@@ -26,14 +27,15 @@ struct TimgBuffer {
             if (pinned)
                 (void)hipHostFree(ptr);
             else
-                (void)hipFree(ptr);
+                (void)timg_amd::DevFree(ptr);
             ptr   = nullptr;
             bytes = 0;
         }
-        // grow geometrically so repeated calls settle quickly
-        size_t cap = want + want / 4 + 256;
+        // grow geometrically so repeated calls settle quickly (guard mode, dev_alloc.h: exactly `want`,
+        // so that nothing hides in the slack)
+        size_t cap = (!pinned && timg_amd::GuardMode()) ? want : want + want / 4 + 256;
         hipError_t e = pinned ? hipHostMalloc(&ptr, cap, hipHostMallocDefault)
-                              : hipMalloc(&ptr, cap);
+                              : timg_amd::DevMalloc(&ptr, cap);
         if (e == hipSuccess) bytes = cap;
         return e;
     }
@@ -42,7 +44,7 @@ struct TimgBuffer {
             if (pinned)
                 (void)hipHostFree(ptr);
             else
-                (void)hipFree(ptr);
+                (void)timg_amd::DevFree(ptr);
         }
         ptr   = nullptr;
         bytes = 0;

@@ -1393,9 +1393,9 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     memcpy(&host[o_sched], sched.data(), sched.size() * sizeof(RowSched));
     memcpy(&host[o_recs], recs.data(), recs.size() * sizeof(RowRec));
     void *dev = nullptr;
-    if (hipMalloc(&dev, total) != hipSuccess) return false;
+    if (DevMalloc(&dev, total) != hipSuccess) return false;
     if (hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(dev);
+        (void)DevFree(dev);
         return false;
     }
     out->device     = dev;
@@ -1503,7 +1503,7 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     if (!BuildVariant(p, strips, first, last, tall, &ss->v[0]) ||
         !BuildVariant(p, strips, first, last, fine, &ss->v[1])) {
         for (auto &v : ss->v)
-            if (v.device) (void)hipFree(v.device);
+            if (v.device) (void)DevFree(v.device);
         delete ss;
         return no("uploading the schedule failed");
     }
@@ -1526,8 +1526,8 @@ void ReleaseStreamSchedule(timg_hip_scaler *s) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
     if (!ss) return;
     for (auto &v : ss->v)
-        if (v.device) (void)hipFree(v.device);
-    if (ss->tile_state) (void)hipFree(ss->tile_state);
+        if (v.device) (void)DevFree(v.device);
+    if (ss->tile_state) (void)DevFree(ss->tile_state);
     delete ss;
     s->stream_tables = nullptr;
 }
@@ -1621,10 +1621,10 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
     const StreamVariant &v = enough ? tall : ss->v[1];
     const size_t tiles = (size_t)v.t.n_strips * v.t.n_bands * batch.n_frames;
     if (tiles > ss->tile_cap) {
-        if (ss->tile_state) (void)hipFree(ss->tile_state);
+        if (ss->tile_state) (void)DevFree(ss->tile_state);
         ss->tile_state = nullptr;
         ss->tile_cap   = 0;
-        hipError_t e   = hipMalloc((void **)&ss->tile_state, tiles * sizeof(int));
+        hipError_t e   = DevMalloc((void **)&ss->tile_state, tiles * sizeof(int));
         if (e != hipSuccess) return e;
         // (once per allocation, ordered in front of the kernels on this stream)
         if ((e = hipMemsetAsync(ss->tile_state, 0, tiles * sizeof(int), stream)) != hipSuccess) return e;

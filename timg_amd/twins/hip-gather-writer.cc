@@ -21,23 +21,28 @@ bool HipGatherWriter::GatherAndWrite(const uint8_t *payload, const uint64_t *len
         if (n > n_max) n_max = n;
     }
     if (n_max < 1) return true;
-    std::vector<uint64_t> all;
+    // step 1: the byte counts of every rank's frames, on every rank -- the root sizes its buffer exactly
+    std::vector<uint64_t> all((size_t)world_ * n_max);
+    if (timg_hip_gather_lengths(comm_, lengths, n_local, n_max, all.data(), nullptr) != 0) {
+        fprintf(stderr, "timg: gather of the frame lengths failed: %s\n", timg_hip_comm_last_error(comm_));
+        return false;
+    }
     size_t got = 0;
     if (rank_ == root_) {
-        all.resize((size_t)world_ * n_max);
-        // (worst case: every frame as large as this rank's largest; grown on demand below)
-        size_t want = 1 << 20;
-        for (int i = 0; i < n_local; ++i) want += (size_t)lengths[i];
-        want *= (size_t)world_ * 2;
+        size_t want = 0;
+        for (uint64_t v : all) want += (size_t)v;
         if (want > recv_cap_) {
             if (recv_) (void)timg_hip_free(ctx_, recv_);
-            recv_ = nullptr;
-            if (timg_hip_malloc(ctx_, want, (void **)&recv_) != TIMG_HIP_OK) return false;
-            recv_cap_ = want;
+            recv_     = nullptr;
+            recv_cap_ = 0;
+            want += want / 4 + 4096;  // (headroom: the next call usually fits)
+            // an allocation failure must not leave the peers waiting: enter step 2 with capacity 0,
+            // every rank then returns TIMG_HIP_COMM_ERR_CAP
+            if (timg_hip_malloc(ctx_, want, (void **)&recv_) == TIMG_HIP_OK) recv_cap_ = want;
         }
     }
-    if (timg_hip_gather_to_root(comm_, root_, payload, lengths, n_local, n_max, all.data(), recv_, recv_cap_, &got,
-                                nullptr) != 0) {
+    // step 2: the payloads
+    if (timg_hip_gather_payload(comm_, root_, payload, all.data(), n_max, recv_, recv_cap_, &got, nullptr) != 0) {
         fprintf(stderr, "timg: gather of the encoded frames failed: %s\n", timg_hip_comm_last_error(comm_));
         return false;
     }

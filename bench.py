@@ -91,6 +91,13 @@ def cpu_baseline(in_w, in_h, out_w, out_h, blend_args, cores, frames, target_sec
         stage["sixel"] += t3 - t2
         scaled.append(fb)
     single = n1 * in_w * in_h / 1e6 / sum(stage.values())
+    # the same stage under the rule the GPU path runs (cell centre, lookup_mode 1) -- the ratio below compares
+    # the device against libsixel's OWN rule (first hit, lookup_mode 0: what the reference executes); this
+    # figure says what the comparison would be rule for rule
+    t0 = time.perf_counter()
+    for fb in scaled:
+        orc.sixel_encode(fb, bg, pattern, pw, ph, lookup_mode=1)
+    sixel_same_rule_ms = (time.perf_counter() - t0) / len(scaled) * 1e3
 
     def run(fn, n, threads):
         shards = [list(range(t, n, threads)) for t in range(threads)]
@@ -127,7 +134,50 @@ def cpu_baseline(in_w, in_h, out_w, out_h, blend_args, cores, frames, target_sec
         "single_thread_value": round(single, 2),
         "stages_ms_per_frame_1_thread": {k: round(v / n1 * 1e3, 2) for k, v in stage.items()},
         "sixel_only_source_mpx_per_s_by_threads": sixel_rates,
+        "sixel_lookup_rule": ("host figures: libsixel's first-hit cache (restatement, parity unpinned) = what the reference "
+                              "runs; the device runs the cell-centre rule (DESIGN 2) -- same stage on one host thread "
+                              f"under the device's rule: {sixel_same_rule_ms:.2f} ms per frame"),
     }
+
+
+def parity_check(pipe, src_batch, out_w, out_h, mode, blend_args, chunk):
+    """Outside the timed region: frames 0 and N-1 of the batch the LAST timed step left in HBM -- the scaled
+    + composed frame and its escape bytes -- against the checkers (oracle/_ref = the compiled reference for
+    scale + compose where it travelled with the repo, else its restatement; the restatement for the canvas
+    bytes).  A number whose bytes were never looked at is a claim; a mismatch fails the run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    ref = oracle_lib.Ref.try_load()
+    scaler = ref if ref is not None else orc
+    bg, pattern, pw, ph = blend_args
+    frames = sorted({0, chunk - 1})
+    res = {"frames": frames, "scale_checker": "reference (oracle/_ref)" if ref is not None else "oracle restatement",
+           "scale": "bit-exact", "canvas": "byte-exact vs restatement"
+           + (" (lookup rule of the device: cell centre; libsixel itself unpinned)" if mode == "sixel" else "")}
+    ok = True
+    for i in frames:
+        src = src_batch[i].cpu().numpy()
+        want = scaler.scale(src, out_w, out_h)
+        want, _ = scaler.alpha_compose(want, bg, pattern, pw, ph)
+        got = pipe.scaled[i].cpu().numpy()
+        if not np.array_equal(got, want):
+            res["scale"] = f"MISMATCH frame {i}: {int(np.count_nonzero(got != want))} bytes"
+            ok = False
+        got_bytes = pipe.frame_bytes(i)
+        if mode == "sixel":
+            want_bytes = orc.sixel_encode(got, bg, pattern, pw, ph, lookup_mode=1)
+        elif mode in ("quarter", "half"):
+            want_bytes = orc.block_encode(got, quarter=(mode == "quarter"), x=(i % 8) * (out_w + 2))
+        else:
+            want_bytes = None
+            res["canvas"] = "not checked in bench.py for this canvas (tests/test_gpu_parity.py does)"
+        if want_bytes is not None and got_bytes != want_bytes:
+            res["canvas"] = f"MISMATCH frame {i}: {len(got_bytes)} vs {len(want_bytes)} bytes"
+            ok = False
+    res["ok"] = ok
+    return res
 
 
 def main():
@@ -152,6 +202,7 @@ def main():
     ap.add_argument("--prewarm", type=float, default=0.4,
                     help="seconds of untimed steps before the warm-up steps (clock ramp-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed output")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_alpha / d2h / batched_streams")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the CPU sample")
@@ -316,6 +367,16 @@ def main():
     run_steps(args.warmup)
     events = []
     elapsed = timed(args.steps, n_pipes, events)  # THE timed region: exactly K steps
+    parity = None
+    if rank == 0 and not args.no_parity and n_mine > 0:
+        # what the last timed step left behind (pipeline (K-1) % n_pipes holds it; strong configs: the last chunk)
+        if strong:
+            last_pipe = tail_pipe if (tail_pipe is not None and chunks[-1].shape[0] != chunk) else pipe
+            last_src = chunks[-1]
+        else:
+            last_pipe, last_src = pipes[(args.steps - 1) % n_pipes], src
+        parity = parity_check(last_pipe, last_src, out_w, out_h, mode,
+                              (BG, PATTERN if cfg.get("checker") else (0, 0, 0, 0), pw, ph), last_src.shape[0])
 
     launches_per_step = len(chunks) if strong else 1
     scale_ms = [a.elapsed_time(b) for a, b, _ in events]
@@ -384,6 +445,8 @@ def main():
                       "encode": round(sum(encode_ms) / args.steps, 3)},
         "output_bytes_per_step": out_bytes * (launches_per_step if strong else 1),
     }
+    if parity is not None:
+        result["parity_check"] = parity
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(traffic_file):
         try:
@@ -391,8 +454,10 @@ def main():
             if (t.get("workload_frames") == chunk and t.get("kernel") == result["config"]["scale_kernel"]
                     and t.get("config", "metric") == args.config):
                 result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / "
-                                                        "WRITE_SIZE of this command in a separate run")
+                result["roofline"]["traffic_measured_in_this_run"] = False
+                result["roofline"]["traffic_source"] = ("NOT measured in this run: profiles/hbm_traffic.json, rocprofv3 "
+                                                        "--pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
+                                                        "(profiles/collect.sh)")
         except Exception:
             pass
 
@@ -492,6 +557,7 @@ def main():
                                             cb["sixel_only_source_mpx_per_s_by_threads"].items()}
     if rank == 0:
         print(json.dumps(result), flush=True)
+    parity_failed = parity is not None and not parity["ok"]
     for p in pipes:
         p.close()
     if tail_pipe is not None:
@@ -501,6 +567,8 @@ def main():
         dist.destroy_process_group()
     for h in hips:
         h.close()
+    if parity_failed:
+        raise SystemExit("bench.py: the timed output does not match the oracle: " + json.dumps(parity))
 
 
 if __name__ == "__main__":

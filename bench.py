@@ -180,6 +180,33 @@ def parity_check(pipe, src_batch, out_w, out_h, mode, blend_args, chunk):
     return res
 
 
+def cpp_dropin():
+    """The drop-in path measured as a drop-in (north_star: "drops into the existing C++ renderer unchanged"):
+    tests/twins/build/twin_bench drives HipRawRGBASource -> the reference's Renderer -> the Hip canvases -> the
+    reference's BufferedWriteSequencer the way src/timg.cc:311-396,948-968 does (loader pool, one Send per image,
+    queue of 4 / a grid row / the whole grid), and the reference's own classes on the host cores beside it.
+    Not the contract's `value`: one process, one Send per image, bytes delivered to the host and written."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "twins", "build", "twin_bench")
+    if not os.path.exists(exe):
+        return {"skipped": "tests/twins/build/twin_bench not built (needs the reference's headers at build time)"}
+    try:
+        r = subprocess.run([exe, "--config", "metric,c4,c3", "--repeat", "2", "--cpu-frames", "64"], capture_output=True,
+                           text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "twin_bench timed out"}
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    out = {"unit": "Mpixels/s", "what": "timg's own loop (loader pool, Renderer, one Send per image, BufferedWriteSequencer on "
+                                        "/dev/null); gpu = C++ twins, cpu = the reference's classes on the host cores"}
+    for x in rows:
+        out.setdefault(x["config"], {}).setdefault(x["path"], {})["queue_%d" % x["queue_len"]] = {
+            "mpx_per_s": x["mpx_per_s"], "ms_per_frame": x["ms_per_frame"], "frames": x["frames"],
+            "loader_threads": x["loader_threads"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +230,8 @@ def main():
                     help="seconds of untimed steps before the warm-up steps (clock ramp-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed output")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip tests/twins/build/twin_bench (the C++ drop-in path as src/timg.cc drives it)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_alpha / d2h / batched_streams")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the CPU sample")
@@ -555,6 +584,8 @@ def main():
         cb["gpu_sixel_stage_source_mpx_per_s"] = round(gpu_sixel_mpx, 1)
         cb["gpu_over_host_sixel_encode"] = {k: round(gpu_sixel_mpx / v, 1) for k, v in
                                             cb["sixel_only_source_mpx_per_s_by_threads"].items()}
+    if rank == 0 and not args.no_dropin and not args.no_extras and args.config == "metric":
+        result["cpp_dropin"] = cpp_dropin()
     if rank == 0:
         print(json.dumps(result), flush=True)
     parity_failed = parity is not None and not parity["ok"]

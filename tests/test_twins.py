@@ -1,8 +1,8 @@
 """The C++ twins (timg_amd/twins) against the reference's own classes.
 
-build/twin_check links hzeller/timg's ImageScaler / Framebuffer /
+tests/twins/build/twin_check links hzeller/timg's ImageScaler / Framebuffer /
 UnicodeBlockCanvas / BufferedWriteSequencer (compiled from /root/reference in
-this container by timg_amd/twins/Makefile) next to HipImageScaler,
+this container by tests/twins/Makefile) next to timg_amd/twins/build/libtimg_hip_twins.a: HipImageScaler,
 HipUnicodeBlockCanvas, HipSixelCanvas and the kitty / iTerm2 twins and drives both
 through the calls the renderer makes.  The binary travels to the GPU box with the snapshot."""
 import os
@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "timg_amd", "twins", "build", "twin_check")
+BIN = os.path.join(ROOT, "tests", "twins", "build", "twin_check")
+BENCH = os.path.join(ROOT, "tests", "twins", "build", "twin_bench")
 
 
 def test_twin_sources_bind_only_the_c_abi():
@@ -28,7 +29,7 @@ def test_twin_sources_bind_only_the_c_abi():
 @pytest.mark.gpu
 def test_twins_match_reference_classes(oracle, tmp_path):
     if not os.path.exists(BIN):
-        pytest.skip("timg_amd/twins/build/twin_check not built (needs /root/reference at build time)")
+        pytest.skip("tests/twins/build/twin_check not built (needs /root/reference at build time)")
     dump = tmp_path / "sixel.bin"
     r = subprocess.run([BIN, "all", str(dump)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -46,6 +47,10 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     # the device-resident ImageSource twin: same pixels through QOIImageSource + reference scaler + reference
     # canvas and through HipRawRGBASource (scaled, composed and encoded in device memory)
     assert "device-resident image source: 6 pipelines identical" in r.stdout
+    # a multi-frame stream (BASELINE config 4's shape) through the device-resident source: frame_offset, frame_count, loops
+    assert "multi-frame device-resident source: 16 streams identical" in r.stdout
+    # --crop-border / --auto-crop wired into the source (still images, before scaling)
+    assert "crop-border / auto-crop in the device-resident source: 8 pipelines identical" in r.stdout
     # the RCCL gather behind its C-ABI + the C++ writer that feeds BufferedWriteSequencer in frame order
     assert "RCCL gather to the root + ordered hand-over to the write sequencer (world 1): checked" in r.stdout
     # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
@@ -57,3 +62,30 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     img, ncolors = oracle.sixel_decode(frames[0])
     assert img.shape[:2] == (114, 200) and 2 <= ncolors <= 256
     assert (img[..., 3] == 255).all()  # every pixel drawn (pad rows blended, not transparent)
+
+
+@pytest.mark.gpu
+def test_bilinear_scaler_twin_is_selectable():
+    """A stock timg build scales with libswscale's SWS_BILINEAR (src/image-scaler.cc:45-72): TIMG_HIP_FILTER=bilinear
+    (or a twin build with WITH_TIMG_SWS_RESIZE) makes HipImageScaler::Create ask the device for the triangle filter."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/twins/build/twin_check not built (needs /root/reference at build time)")
+    r = subprocess.run([BIN, "bilinear"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TIMG_HIP_FILTER="bilinear"))
+    assert r.returncode == 0 and "bilinear scaler twin" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_twin_bench_runs_the_drop_in_path_like_timg_cc():
+    """tests/twins/twin_bench: sources on a loader pool, PresentImages' loop, the reference's renderer and sequencer --
+    twins and reference classes; here only that every configuration completes and reports (numbers: profiles/)."""
+    import json
+    if not os.path.exists(BENCH):
+        pytest.skip("tests/twins/build/twin_bench not built (needs /root/reference at build time)")
+    r = subprocess.run([BENCH, "--config", "c2,c3,c4,metric", "--frames", "6", "--cpu-frames", "6", "--repeat", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    seen = {(x["config"], x["path"]) for x in rows}
+    assert seen == {(c, p) for c in ("c2", "c3", "c4", "metric") for p in ("gpu", "cpu")}, seen
+    assert all(x["mpx_per_s"] > 0 and x["bytes_written"] > 1000 for x in rows), rows

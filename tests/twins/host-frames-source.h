@@ -1,0 +1,95 @@
+// tests/twins/host-frames-source.h -- TEST INFRASTRUCTURE: the reference's CPU path for frames that are
+// already decoded, as a timg::ImageSource.  It does what the reference's own loaders do once they hold the
+// pixels -- src/qoi-image-source.cc:42-77 / src/stb-image-source.cc:44-61: copy into a Framebuffer,
+// ImageScaler::Create + Scale (the reference's scaler), Framebuffer::AlphaComposeBackground -- and sends
+// frames with the loop of src/stb-image-source.cc:172-205.  twin_check compares HipRawRGBASource's
+// multi-frame streams against it; twin_bench times it as the CPU side of the drop-in measurement.
+// Only reference classes are used here.
+#ifndef TESTS_TWINS_HOST_FRAMES_SOURCE_H
+#define TESTS_TWINS_HOST_FRAMES_SOURCE_H
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "display-options.h"
+#include "framebuffer.h"
+#include "image-scaler.h"
+#include "image-source.h"
+
+namespace timg {
+
+class HostFramesSource final : public ImageSource {
+public:
+    // frames: `n` RGBA8 frames of w x h back to back (not owned; must outlive LoadAndScale)
+    HostFramesSource(const std::string &name, const uint8_t *frames, int n, int w, int h)
+        : ImageSource(name), src_(frames), n_src_(n), w_(w), h_(h) {}
+
+    // crop window (x, y, w, h) applied before scaling (what GraphicsMagick's crop()/trim() would leave);
+    // default: the whole frame
+    void SetCrop(int x, int y, int w, int h) {
+        cx_ = x; cy_ = y; cw_ = w; ch_ = h;
+    }
+
+    bool LoadAndScale(const DisplayOptions &opts, int frame_offset, int frame_count) final {
+        options_     = opts;
+        const int f0 = std::max(0, std::min(frame_offset, n_src_ - 1));
+        int n        = n_src_ - f0;
+        if (frame_count > 0) n = std::min(n, frame_count);
+        const int sw = cw_ > 0 ? cw_ : w_, sh = ch_ > 0 ? ch_ : h_;
+        int tw, th;
+        CalcScaleToFitDisplay(sw, sh, opts, false, &tw, &th);
+        for (int i = 0; i < n; ++i) {
+            timg::Framebuffer in(sw, sh);  // (the copy the reference's loaders make)
+            const uint8_t *frame = src_ + (size_t)(f0 + i) * w_ * h_ * 4;
+            for (int y = 0; y < sh; ++y)
+                memcpy((uint8_t *)in.begin() + (size_t)y * sw * 4, frame + ((size_t)(cy_ + y) * w_ + cx_) * 4, (size_t)sw * 4);
+            auto scaler = ImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
+            if (!scaler) return false;
+            std::unique_ptr<timg::Framebuffer> out(new timg::Framebuffer(tw, th));
+            scaler->Scale(in, out.get());
+            out->AlphaComposeBackground(options_.bgcolor_getter, options_.bg_pattern_color,
+                                        options_.pattern_size * options_.cell_x_px,
+                                        options_.pattern_size * options_.cell_y_px / 2);
+            frames_.push_back(std::move(out));
+        }
+        return !frames_.empty();
+    }
+
+    void SendFrames(const Duration &duration, int loops, const volatile sig_atomic_t &interrupt_received,
+                    const Renderer::WriteFramebufferFun &sink) final {
+        int last_height         = -1;
+        const bool is_animation = frames_.size() > 1;
+        if (!is_animation) loops = 1;
+        const bool loop_forever = loops < 0;
+        const timg::Duration time_from_first_frame;
+        bool is_first = true;
+        const int indent = options_.center_horizontally ? (options_.width - frames_[0]->width()) / 2 : 0;
+        for (int k = 0; (loop_forever || k < loops) && !interrupt_received && time_from_first_frame < duration; ++k) {
+            for (size_t f = 0; f < frames_.size() && !interrupt_received; ++f) {
+                const int dy = is_animation && last_height > 0 ? -last_height : 0;
+                SeqType seq  = SeqType::FrameImmediate;
+                if (is_animation) seq = is_first ? SeqType::StartOfAnimation : SeqType::AnimationFrame;
+                sink(indent, dy, *frames_[f], seq, std::min(time_from_first_frame, duration));
+                last_height = frames_[f]->height();
+                is_first    = false;
+            }
+        }
+    }
+
+    std::string FormatTitle(const std::string &fmt) const final {
+        return FormatFromParameters(fmt, filename_, w_, h_, "host-rgba");
+    }
+
+private:
+    const uint8_t *const src_;
+    const int n_src_, w_, h_;
+    int cx_ = 0, cy_ = 0, cw_ = 0, ch_ = 0;
+    DisplayOptions options_;
+    std::vector<std::unique_ptr<timg::Framebuffer>> frames_;
+};
+
+}  // namespace timg
+#endif

@@ -1,10 +1,10 @@
-// timg_amd/twins/twin_check.cc -- TEST DRIVER (not part of the product).
+// tests/twins/twin_check.cc -- TEST DRIVER (not part of the product).
 //
 // Links the reference's own classes (compiled from /root/reference where they
 // lie) next to the GPU twins and drives both through the SAME calls the
 // renderer makes (ImageScaler::Create/Scale, AlphaComposeBackground,
 // TerminalCanvas::Send through a BufferedWriteSequencer), then compares bytes.
-// Built by timg_amd/twins/Makefile into build/twin_check (git-ignored, travels
+// Built by tests/twins/Makefile into build/twin_check (git-ignored, travels
 // to the GPU box); tests/test_twins.py runs it under -m gpu.
 #include <sys/mman.h>
 #include <unistd.h>
@@ -26,6 +26,8 @@
 #include "hip-raw-rgba-source.h"
 #include "hip-sixel-canvas.h"
 #include "hip-unicode-block-canvas.h"
+#include "host-frames-source.h"
+#include "timg_oracle.h"
 #include "image-scaler.h"
 #include "image-source.h"
 #include "iterm2-canvas.h"
@@ -557,6 +559,203 @@ static void CheckImageSource() {
     fflush(stdout);
 }
 
+
+// One pipeline: source -> reference Renderer -> canvas -> sequencer on a memfd; returns the terminal stream.
+// canvas_kind 0: quarter blocks, 1: sixel.  hip_canvas: the twin or the reference class.
+template <class MakeSource>
+static std::string RunSourcePipeline(int canvas_kind, bool hip_canvas, DisplayOptions opts, int loops, MakeSource make) {
+    volatile sig_atomic_t intr = 0;
+    const int fd = memfd_create("src", 0);
+    {
+        BufferedWriteSequencer seq(fd, false, 4, true, intr);
+        ThreadPool pool(2);
+        opts.cell_x_px        = canvas_kind ? 9 : 2;
+        opts.cell_y_px        = canvas_kind ? 18 : 2;
+        opts.width            = canvas_kind ? 200 : 160;
+        opts.height           = canvas_kind ? 126 : 90;
+        opts.width_stretch    = canvas_kind ? 1.0f : 2.0f;
+        opts.pattern_size     = 2;
+        opts.bg_pattern_color.r = 200; opts.bg_pattern_color.g = 190; opts.bg_pattern_color.b = 180;
+        opts.bg_pattern_color.a = 255;
+        opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+        static SixelOptions so;
+        std::unique_ptr<TerminalCanvas> canvas;
+        if (canvas_kind == 0 && hip_canvas) canvas.reset(new HipUnicodeBlockCanvas(&seq, true, false, false));
+        if (canvas_kind == 0 && !hip_canvas) canvas.reset(new UnicodeBlockCanvas(&seq, true, false, false));
+        if (canvas_kind == 1 && hip_canvas) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
+        if (canvas_kind == 1 && !hip_canvas) canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
+        {
+            auto renderer = Renderer::Create(canvas.get(), opts, 1, 1, Duration(), Duration());
+            std::unique_ptr<ImageSource> source(make(opts));
+            CHECK(source != nullptr, "pipeline source");
+            if (source) source->SendFrames(Duration::InfiniteFuture(), loops, intr, renderer->render_cb(""));
+            seq.Flush();
+        }
+        canvas.reset();
+    }
+    std::string s = Slurp(fd);
+    close(fd);
+    return s;
+}
+
+// A multi-frame stream (BASELINE config 4's shape: frames of one source, StartOfAnimation / AnimationFrame,
+// dy = -height) through HipRawRGBASource -- frame_offset, frame_count and loops honoured as the reference's
+// loaders do -- against the same frames through the reference's scaler + compose + canvases.
+static void CheckAnimationSource() {
+    timg_stub_sixel_set_lookup_mode(1);
+    char dir_template[] = "/tmp/twin_anim_XXXXXX";
+    const char *dir = mkdtemp(dir_template);
+    CHECK(dir != nullptr, "mkdtemp");
+    if (!dir) return;
+    const int sw = 320, sh = 200, nf = 5;
+    std::vector<uint8_t> frames((size_t)nf * sw * sh * 4);
+    for (int f = 0; f < nf; ++f) {
+        Framebuffer fb(sw, sh);
+        rng_state = 900 + f;
+        Fill(&fb, f == 3 ? 1 : 2);  // (one frame with alpha: the compose runs for the stream)
+        if (f > 0 && f != 3) {      // consecutive frames share most pixels: the block canvas' frame-diff mode has work
+            memcpy((void *)fb.begin(), frames.data(), (size_t)sw * sh * 4);
+            rgba_t c; c.r = 250; c.g = (uint8_t)(60 * f); c.b = 20; c.a = 255;
+            for (int y = 20 * f; y < 20 * f + 15; ++y)
+                for (int x = 30; x < 200; ++x) fb.SetPixel(x, y, c);
+        }
+        memcpy(frames.data() + (size_t)f * sw * sh * 4, fb.begin(), (size_t)sw * sh * 4);
+    }
+    const std::string raw_name = std::string(dir) + "/anim.rgba";
+    {
+        FILE *f = fopen(raw_name.c_str(), "wb");
+        const uint32_t dims[2] = {(uint32_t)sw, (uint32_t)sh};
+        fwrite("TIMGRGBA", 1, 8, f);
+        fwrite(dims, 4, 2, f);
+        fwrite(frames.data(), 1, frames.size(), f);
+        fclose(f);
+    }
+    int n = 0;
+    const int cases[][3] = {{0, -1, 1}, {1, 3, 2}, {4, 5, 1}, {0, 1, 3}};  // frame_offset, frame_count, loops
+    for (const auto &c : cases) {
+        for (int canvas_kind = 0; canvas_kind < 2; ++canvas_kind) {
+            DisplayOptions opts;
+            const std::string want = RunSourcePipeline(canvas_kind, false, opts, c[2], [&](const DisplayOptions &o) -> ImageSource * {
+                auto *s = new HostFramesSource("anim", frames.data(), nf, sw, sh);
+                if (!s->LoadAndScale(o, c[0], c[1])) { delete s; return nullptr; }
+                return s;
+            });
+            for (int hip_canvas = 1; hip_canvas >= 0; --hip_canvas) {
+                const std::string got = RunSourcePipeline(canvas_kind, hip_canvas != 0, opts, c[2], [&](const DisplayOptions &o) {
+                    return HipRawRGBASource::TryCreate(raw_name, o, c[0], c[1]);
+                });
+                CHECK(got == want && want.size() > 1000,
+                      "animation offset %d count %d loops %d canvas %d (hip canvas %d): %zu (reference) vs %zu bytes", c[0],
+                      c[1], c[2], canvas_kind, hip_canvas, want.size(), got.size());
+                ++n;
+            }
+        }
+    }
+    unlink(raw_name.c_str());
+    rmdir(dir);
+    // the generator's streams: frame f of "synth:...:<first>:<count>" is frame <first> + f of the hash
+    {
+        DisplayOptions opts;
+        const std::string a = RunSourcePipeline(0, true, opts, 1, [&](const DisplayOptions &o) {
+            return HipRawRGBASource::TryCreate("synth:photo:640x360:9:2:3", o, 1, 1);
+        });
+        const std::string b = RunSourcePipeline(0, true, opts, 1, [&](const DisplayOptions &o) {
+            return HipRawRGBASource::TryCreate("synth:photo:640x360:9:3", o, 0, -1);
+        });
+        CHECK(a == b && a.size() > 1000, "synth stream frame 1 of (first 2, count 3) == single frame 3: %zu vs %zu", a.size(), b.size());
+    }
+    printf("multi-frame device-resident source: %d streams identical to the reference's scaler + canvases\n", n);
+    fflush(stdout);
+}
+
+// --crop-border / --auto-crop wired into the device-resident source (src/graphics-magick-source.cc:231-241:
+// crop, then trim, before scaling; still images only) against the same window cut on the host (the oracle's
+// bounding box -- parity unpinned against GraphicsMagick) through the reference's scaler.
+static void CheckAutoCropSource() {
+    timg_stub_sixel_set_lookup_mode(1);
+    char dir_template[] = "/tmp/twin_crop_XXXXXX";
+    const char *dir = mkdtemp(dir_template);
+    CHECK(dir != nullptr, "mkdtemp");
+    if (!dir) return;
+    const int sw = 400, sh = 300;
+    Framebuffer src(sw, sh);
+    rng_state = 4242;
+    Fill(&src, 0);
+    rgba_t border; border.r = 12; border.g = 200; border.b = 90; border.a = 255;
+    for (int y = 0; y < sh; ++y)
+        for (int x = 0; x < sw; ++x)
+            if (x < 31 || x >= sw - 22 || y < 17 || y >= sh - 40) src.SetPixel(x, y, border);
+    const std::string raw_name = std::string(dir) + "/crop.rgba";
+    {
+        FILE *f = fopen(raw_name.c_str(), "wb");
+        const uint32_t dims[2] = {(uint32_t)sw, (uint32_t)sh};
+        fwrite("TIMGRGBA", 1, 8, f);
+        fwrite(dims, 4, 2, f);
+        fwrite(src.begin(), 4, (size_t)sw * sh, f);
+        fclose(f);
+    }
+    int n = 0;
+    const int cases[][2] = {{1, 0}, {1, 5}, {0, 9}, {1, 40}};  // auto_crop, crop_border
+    for (const auto &c : cases) {
+        int box[4] = {0, 0, sw, sh};
+        if (c[0]) {
+            oracle_autocrop_bbox((const uint8_t *)src.begin(), sw, sh, sw * 4, c[1], box);
+        } else {
+            box[0] = box[1] = c[1];
+            box[2] = sw - 2 * c[1];
+            box[3] = sh - 2 * c[1];
+        }
+        if (c[0] && c[1] == 0) CHECK(box[0] == 31 && box[1] == 17 && box[2] == sw - 53 && box[3] == sh - 57, "bbox %d %d %d %d", box[0], box[1], box[2], box[3]);
+        for (int canvas_kind = 0; canvas_kind < 2; ++canvas_kind) {
+            DisplayOptions opts;
+            opts.auto_crop   = c[0] != 0;
+            opts.crop_border = c[1];
+            const std::string want = RunSourcePipeline(canvas_kind, false, opts, 1, [&](const DisplayOptions &o) -> ImageSource * {
+                auto *s = new HostFramesSource("crop", (const uint8_t *)src.begin(), 1, sw, sh);
+                s->SetCrop(box[0], box[1], box[2], box[3]);
+                if (!s->LoadAndScale(o, 0, 1)) { delete s; return nullptr; }
+                return s;
+            });
+            const std::string got = RunSourcePipeline(canvas_kind, true, opts, 1, [&](const DisplayOptions &o) {
+                return HipRawRGBASource::TryCreate(raw_name, o, 0, 1);
+            });
+            CHECK(got == want && want.size() > 1000, "auto_crop %d crop_border %d canvas %d: %zu (host window) vs %zu bytes", c[0], c[1],
+                  canvas_kind, want.size(), got.size());
+            ++n;
+        }
+    }
+    unlink(raw_name.c_str());
+    rmdir(dir);
+    printf("crop-border / auto-crop in the device-resident source: %d pipelines identical to the window cut on the host\n", n);
+    fflush(stdout);
+}
+
+// TIMG_HIP_FILTER=bilinear (or a twin build with WITH_TIMG_SWS_RESIZE): HipImageScaler::Create asks the device for the
+// triangle filter -- what a stock timg build (libswscale SWS_BILINEAR, src/image-scaler.cc:45-72) scales with.  libswscale
+// is not in the tree (parity unpinned): the checker is the oracle's triangle resampler, itself within 0.5 LSB of an
+// independent float64 one (tests/test_triangle_reference.py).  Run as its own process: the choice is made once.
+static void CheckBilinearScaler() {
+    const int geoms[][4] = {{640, 480, 67, 50}, {320, 240, 500, 300}, {1920, 1080, 400, 225}};
+    for (const auto &g : geoms) {
+        Framebuffer in(g[0], g[1]);
+        Fill(&in, 1);
+        Framebuffer got(g[2], g[3]);
+        std::vector<uint8_t> want((size_t)g[2] * g[3] * 4);
+        auto gpu = HipImageScaler::Create(g[0], g[1], ImageScaler::ColorFmt::kRGBA, g[2], g[3]);
+        CHECK(gpu != nullptr, "bilinear scaler creation");
+        if (!gpu) continue;
+        gpu->Scale(in, &got);
+        CHECK(oracle_scale((const uint8_t *)in.begin(), g[0], g[1], 0, want.data(), g[2], g[3], 2) == 0, "oracle_scale");
+        CHECK(memcmp(want.data(), got.begin(), want.size()) == 0, "bilinear twin %dx%d -> %dx%d", g[0], g[1], g[2], g[3]);
+        // ... and it is NOT the stb filter (the switch did something)
+        std::vector<uint8_t> stb((size_t)g[2] * g[3] * 4);
+        oracle_scale((const uint8_t *)in.begin(), g[0], g[1], 0, stb.data(), g[2], g[3], 0);
+        CHECK(memcmp(stb.data(), got.begin(), stb.size()) != 0, "bilinear twin equals the stb filter");
+    }
+    printf("bilinear scaler twin (TIMG_HIP_FILTER=bilinear): checked against the triangle resampler\n");
+    fflush(stdout);
+}
+
 // The multi-GPU exchange step through its C-ABI (include/timg_hip_comm.h) and its C++ caller: the
 // frames a rank encoded, gathered over RCCL and handed to the reference's sequencer in frame order.
 // One GPU is all this box has: world = 1 (the gather to oneself runs the same calls; the frame-order
@@ -622,7 +821,7 @@ static void CheckGatherWriter() {
 }
 
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|gather] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|bilinear] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -634,7 +833,14 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "sixel") CheckSixelCanvas(argc > 2 ? argv[2] : nullptr);
     if (what == "all" || what == "sixelgrid" || what == "timggrid") CheckGridLikeTimg();
     if (what == "all" || what == "graphics") CheckGraphicsCanvases();
+    if (what == "bilinear") {  // (own process: TIMG_HIP_FILTER=bilinear must be set before the first scaler is created)
+        CheckBilinearScaler();
+        if (failures) return 1;
+        return 0;
+    }
     if (what == "all" || what == "source") CheckImageSource();
+    if (what == "all" || what == "source" || what == "animation") CheckAnimationSource();
+    if (what == "all" || what == "source" || what == "autocrop") CheckAutoCropSource();
     if (what == "all" || what == "gather") CheckGatherWriter();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);

@@ -689,12 +689,7 @@ static int BlockEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, i
     }
     if (worst > out_cap)
         return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %zu bytes, out_cap is %zu", worst, out_cap);
-    if (!out_on_device) {
-        for (int i = 0; i < n_frames; ++i)
-            TIMG_HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * out_cap, dout + (size_t)i * out_cap,
-                                             out_len[i], hipMemcpyDeviceToHost, st));
-        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    }
+    if (!out_on_device) return CopyFramesToHost(ctx, out, out_cap, dout, out_len, n_frames, st);
     return TIMG_HIP_OK;
 }
 

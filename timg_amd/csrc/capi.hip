@@ -48,6 +48,54 @@ DevBlend MakeDevBlend(const timg_hip_blend *b) {
     return d;
 }
 
+int CopyFramesToHost(timg_hip_ctx *ctx, char *out, size_t out_cap, const char *dout, const size_t *out_len,
+                     int n_frames, hipStream_t st) {
+    size_t worst = 0, total = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        worst = out_len[i] > worst ? out_len[i] : worst;
+        total += out_len[i];
+    }
+    if (total == 0) {
+        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        return TIMG_HIP_OK;
+    }
+    if (n_frames == 1 || total <= (size_t)128 * 1024) {  // small: the runtime's own staging does as well
+        for (int i = 0; i < n_frames; ++i)
+            if (out_len[i])
+                TIMG_HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * out_cap, dout + (size_t)i * out_cap, out_len[i],
+                                                 hipMemcpyDeviceToHost, st));
+        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        return TIMG_HIP_OK;
+    }
+    // a destination the device can write itself (pinned / registered host memory): one strided copy, no staging
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, out) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        TIMG_HIP_TRY(ctx, hipMemcpy2DAsync(out, out_cap, dout, out_cap, worst, (size_t)n_frames, hipMemcpyDeviceToHost, st));
+        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        return TIMG_HIP_OK;
+    }
+    (void)hipGetLastError();  // (an ordinary pointer is "invalid value" to the query: not an error of ours)
+    // groups of frames whose strided image fits the pinned budget
+    const size_t kBudget = (size_t)64 << 20;
+    const size_t pitch   = (worst + 255) & ~(size_t)255;
+    int group            = (int)(kBudget / pitch);
+    group                = group < 1 ? 1 : group > n_frames ? n_frames : group;
+    TIMG_HIP_TRY(ctx, ctx->pin[3].Reserve(pitch * (size_t)group));
+    char *pin = (char *)ctx->pin[3].ptr;
+    for (int f0 = 0; f0 < n_frames; f0 += group) {
+        const int m = n_frames - f0 < group ? n_frames - f0 : group;
+        size_t w    = 0;
+        for (int i = 0; i < m; ++i) w = out_len[f0 + i] > w ? out_len[f0 + i] : w;
+        if (w == 0) continue;
+        TIMG_HIP_TRY(ctx, hipMemcpy2DAsync(pin, pitch, dout + (size_t)f0 * out_cap, out_cap, w, (size_t)m,
+                                           hipMemcpyDeviceToHost, st));
+        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        for (int i = 0; i < m; ++i)
+            if (out_len[f0 + i]) memcpy(out + (size_t)(f0 + i) * out_cap, pin + (size_t)i * pitch, out_len[f0 + i]);
+    }
+    return TIMG_HIP_OK;
+}
+
 extern "C" {
 
 int timg_hip_version(void) { return (1 << 16) | 0; }

@@ -122,6 +122,15 @@ struct timg_hip_scaler {
 // Shared by the canvas entry points.
 timg_amd::DevBlend MakeDevBlend(const timg_hip_blend *b);
 
+// Encoded frames (device slots of out_cap bytes, out_len[i] bytes used) into the caller's HOST slots.  The caller's
+// memory is pageable and usually fresh (twins: a new char[] per Send): copied to directly, the runtime stages and
+// page-faults its way through it at ~1 GB/s (a 64-frame sixel batch: 24 ms for 22 MB).  So batches travel as ONE
+// strided copy into the context's pinned buffer (the longest frame's length from every slot -- per-copy latency, not
+// PCIe, is what many small copies pay) and are distributed from there with memcpy.  The caller holds ctx->mu.
+// Synchronises `st`.
+int CopyFramesToHost(timg_hip_ctx *ctx, char *out, size_t out_cap, const char *dout, const size_t *out_len,
+                     int n_frames, hipStream_t st);
+
 #define TIMG_HIP_TRY(ctx, expr)                                  \
     do {                                                         \
         hipError_t _e = (expr);                                  \

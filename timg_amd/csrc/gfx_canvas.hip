@@ -348,11 +348,7 @@ static int GfxEncode(int kind, timg_hip_ctx *ctx, const uint8_t *fb, int w, int 
         hipLaunchKernelGGL(GfxFrameKernel, dim3((lanes + 255) / 256, frames), dim3(256), 0, st, g, b, kind);
     }
     TIMG_HIP_TRY(ctx, hipGetLastError());
-    if (!out_on_device) {
-        for (int i = 0; i < n_frames; ++i)
-            TIMG_HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)i * out_cap, dout + (size_t)i * out_cap, out_len[i],
-                                             hipMemcpyDeviceToHost, st));
-    }
+    if (!out_on_device) return CopyFramesToHost(ctx, out, out_cap, dout, out_len, n_frames, st);
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     return TIMG_HIP_OK;
 }

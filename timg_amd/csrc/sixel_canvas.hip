@@ -2183,12 +2183,6 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     }
     if (worst > out_cap)
         return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %zu bytes, out_cap is %zu", worst, out_cap);
-    if (!out_on_device) {
-        // one strided copy for the whole batch (the longest frame's length from every slot) instead of a
-        // copy per frame: per-copy latency, not PCIe, was what a host-side consumer paid for
-        TIMG_HIP_TRY(ctx, hipMemcpy2DAsync(out, out_cap, dout, out_cap, worst, (size_t)n_frames,
-                                           hipMemcpyDeviceToHost, st));
-        TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    }
+    if (!out_on_device) return CopyFramesToHost(ctx, out, out_cap, dout, out_len, n_frames, st);
     return TIMG_HIP_OK;
 }

@@ -1,5 +1,7 @@
 #include "held-rows.h"
 
+#include "hip-context.h"
+
 #include <algorithm>
 #include <cstdlib>
 #include <utility>
@@ -51,9 +53,8 @@ std::future<OutBuffer> HeldRows::Hold(int w, int h, const uint8_t *pixels, bool 
             open_.on_device = on_device;
             have_open_      = true;
             if (on_device) {
-                void *p = nullptr;
-                if (timg_hip_malloc(ctx_, frame_bytes * (size_t)limit, &p) != TIMG_HIP_OK) abort();
-                open_.dev_pixels = (uint8_t *)p;
+                open_.dev_pixels = (uint8_t *)HipPoolMalloc(ctx_, frame_bytes * (size_t)limit);
+                if (!open_.dev_pixels) abort();
             }
         }
         if (pad) open_.pad = *pad;
@@ -112,7 +113,7 @@ void HeldRows::Work() {
         busy_ = true;
         l.unlock();
         encode_(batch);
-        if (batch.dev_pixels) (void)timg_hip_free(ctx_, batch.dev_pixels);
+        if (batch.dev_pixels) HipPoolFree(ctx_, batch.dev_pixels);
         l.lock();
         busy_ = false;
         if (sealed_.empty()) idle_.notify_all();

@@ -2,7 +2,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace timg {
 
@@ -20,6 +24,120 @@ timg_hip_ctx *SharedHipContext() {
         if (timg_hip_init(d ? atoi(d) : 0, &ctx) != TIMG_HIP_OK) ctx = nullptr;
     });
     return ctx;
+}
+
+int HipScalerFilter() {
+    static const int filter = []() {
+        const char *v = getenv("TIMG_HIP_FILTER");
+        if (v && !strcmp(v, "bilinear")) return TIMG_HIP_FILTER_TRIANGLE;
+        if (v && !strcmp(v, "stb")) return TIMG_HIP_FILTER_STB_DEFAULT;
+#if defined(WITH_TIMG_SWS_RESIZE) && !defined(WITH_TIMG_STB_RESIZE)
+        return TIMG_HIP_FILTER_TRIANGLE;
+#else
+        return TIMG_HIP_FILTER_STB_DEFAULT;
+#endif
+    }();
+    return filter;
+}
+
+namespace {
+constexpr size_t kPoolBytes = (size_t)8 << 30;
+std::mutex g_pool_mu;
+std::map<size_t, std::vector<void *>> g_pool_idle;  // size -> blocks
+std::map<void *, size_t> g_pool_size;               // every block handed out or idle
+size_t g_pool_cached = 0;
+
+typedef std::tuple<int, int, int, int, int, int> ScalerKey;
+std::mutex g_scaler_mu;
+std::map<ScalerKey, std::vector<timg_hip_scaler *>> g_scaler_idle;
+std::map<timg_hip_scaler *, ScalerKey> g_scaler_key;
+constexpr size_t kScalersPerGeometry = 16;
+}  // namespace
+
+void *HipPoolMalloc(timg_hip_ctx *ctx, size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        auto it = g_pool_idle.find(bytes);
+        if (it != g_pool_idle.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_pool_cached -= bytes;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (timg_hip_malloc(ctx, bytes, &p) != TIMG_HIP_OK) {
+        // out of memory with blocks cached: give them back and try once more
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> l(g_pool_mu);
+            for (auto &kv : g_pool_idle) {
+                for (void *q : kv.second) {
+                    drop.push_back(q);
+                    g_pool_size.erase(q);
+                }
+                kv.second.clear();
+            }
+            g_pool_cached = 0;
+        }
+        for (void *q : drop) (void)timg_hip_free(ctx, q);
+        if (timg_hip_malloc(ctx, bytes, &p) != TIMG_HIP_OK) return nullptr;
+    }
+    std::lock_guard<std::mutex> l(g_pool_mu);
+    g_pool_size[p] = bytes;
+    return p;
+}
+
+void HipPoolFree(timg_hip_ctx *ctx, void *ptr) {
+    if (!ptr) return;
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        auto it = g_pool_size.find(ptr);
+        if (it != g_pool_size.end() && g_pool_cached + it->second <= kPoolBytes) {
+            g_pool_idle[it->second].push_back(ptr);
+            g_pool_cached += it->second;
+            return;
+        }
+        if (it != g_pool_size.end()) g_pool_size.erase(it);
+    }
+    // (what is still enqueued on the context's stream may use the block: the free waits for the device)
+    (void)timg_hip_free(ctx, ptr);
+}
+
+timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, int out_w, int out_h, int filter) {
+    const ScalerKey key(in_w, in_h, in_fmt, out_w, out_h, filter);
+    {
+        std::lock_guard<std::mutex> l(g_scaler_mu);
+        auto it = g_scaler_idle.find(key);
+        if (it != g_scaler_idle.end() && !it->second.empty()) {
+            timg_hip_scaler *s = it->second.back();
+            it->second.pop_back();
+            return s;
+        }
+    }
+    timg_hip_scaler *s = nullptr;
+    if (timg_hip_scaler_create(ctx, in_w, in_h, in_fmt, out_w, out_h, filter, &s) != TIMG_HIP_OK) return nullptr;
+    std::lock_guard<std::mutex> l(g_scaler_mu);
+    g_scaler_key[s] = key;
+    return s;
+}
+
+void HipScalerRelease(timg_hip_scaler *s) {
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> l(g_scaler_mu);
+        auto it = g_scaler_key.find(s);
+        if (it != g_scaler_key.end()) {
+            auto &idle = g_scaler_idle[it->second];
+            if (idle.size() < kScalersPerGeometry) {
+                idle.push_back(s);
+                return;
+            }
+            g_scaler_key.erase(it);
+        }
+    }
+    timg_hip_scaler_destroy(s);
 }
 
 void HipFatal(timg_hip_ctx *ctx, const char *what) {

@@ -19,6 +19,27 @@ timg_hip_ctx *SharedHipContext();
 // GPU selection: TIMG_HIP_DEVICE=<n> (default 0), TIMG_HIP=0 disables.
 bool HipTwinsEnabled();
 
+// Which resampling filter the twins ask the device for (timg_hip_scaler_create's `filter`).  A timg build
+// scales with ONE back-end, chosen at build time (src/image-scaler.cc:24-35: libswscale's SWS_BILINEAR when
+// WITH_TIMG_SWS_RESIZE, else stb_image_resize2); the twin follows the same macro so that a GPU run of a
+// given timg build shows what its CPU run shows -- TIMG_HIP_FILTER_TRIANGLE for an swscale build,
+// TIMG_HIP_FILTER_STB_DEFAULT otherwise.  TIMG_HIP_FILTER=stb|bilinear in the environment overrides it.
+int HipScalerFilter();
+
+// Device memory for frames, recycled: hipMalloc / hipFree cost far more than the kernels that use a frame
+// (a 4K frame is scaled in ~20 us), and every image source and every held grid row needs a buffer.
+// Blocks are handed out again by exact size; at most kPoolBytes stay cached, the rest is really freed.
+// Thread-safe.  nullptr on failure.
+void *HipPoolMalloc(timg_hip_ctx *ctx, size_t bytes);
+void HipPoolFree(timg_hip_ctx *ctx, void *ptr);
+
+// Scalers, recycled by geometry: creating one builds the resampling plan on the host and uploads its tables
+// (O(W + H), but hundreds of microseconds) -- a grid of equally sized images needs it once, not per image.
+// A scaler is used by one caller at a time (its tile bookkeeping is per scaler): Acquire hands out an idle
+// one or creates one, Release returns it.  Thread-safe.  nullptr on failure.
+timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, int out_w, int out_h, int filter);
+void HipScalerRelease(timg_hip_scaler *s);
+
 // A device call failed after the GPU back-end had been selected: print
 // timg_hip_last_error() and terminate.  The twins never substitute CPU results
 // for a failed device call -- nothing in Scale()/Send() can fail in the

@@ -17,16 +17,15 @@ std::unique_ptr<ImageScaler> HipImageScaler::Create(int in_width, int in_height,
                                                     int out_width, int out_height) {
     timg_hip_ctx *ctx = SharedHipContext();
     if (!ctx) return nullptr;
-    timg_hip_scaler *s = nullptr;
     const int fmt = in_color_format == ColorFmt::kRGBA ? TIMG_HIP_FMT_RGBA : TIMG_HIP_FMT_BGRA;
-    if (timg_hip_scaler_create(ctx, in_width, in_height, fmt, out_width, out_height,
-                               TIMG_HIP_FILTER_STB_DEFAULT, &s) != TIMG_HIP_OK)
-        return nullptr;
+    // (recycled by geometry: the images of a grid share their plan, hip-context.h)
+    timg_hip_scaler *s = HipScalerAcquire(ctx, in_width, in_height, fmt, out_width, out_height, HipScalerFilter());
+    if (!s) return nullptr;
     return std::unique_ptr<ImageScaler>(new HipImageScaler(
         ctx, s, in_width, in_height, in_color_format, out_width, out_height));
 }
 
-HipImageScaler::~HipImageScaler() { timg_hip_scaler_destroy(scaler_); }
+HipImageScaler::~HipImageScaler() { HipScalerRelease(scaler_); }
 
 void HipImageScaler::Scale(Framebuffer &in, Framebuffer *out) {
     if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ ||

@@ -2,7 +2,10 @@
 
 #include <cstdlib>
 
+#include <algorithm>
 #include <cassert>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <future>
@@ -63,6 +66,13 @@ void HipSixelCanvas::SetGridColumns(int columns) {
     if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
 }
 
+void HipSixelCanvas::SetStreamHold(int frames) {
+    Flush();
+    const int by_queue = (int)write_sequencer_->max_queue_len();  // the writer's future + a full queue behind it
+    stream_hold_       = std::max(1, std::min(frames, by_queue));
+    if (stream_hold_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
+}
+
 void HipSixelCanvas::Flush() {
     if (rows_) rows_->Drain();
 }
@@ -71,18 +81,26 @@ void HipSixelCanvas::Flush() {
 void HipSixelCanvas::EncodeBatch(HeldBatch &batch) {
     const size_t n    = batch.frames.size();
     const size_t slot = timg_hip_sixel_max_bytes(batch.w, batch.h) * 2;
-    std::vector<char> bytes(slot * n);
+    // (uninitialised on purpose: a std::vector would zero 3.6 MB per frame; only the bytes a frame produced are touched)
+    std::unique_ptr<char[]> bytes(new char[slot * n]);
     std::vector<size_t> lens(n);
     const int flags = EncodeFlags();
+    static const bool trace = getenv("TIMG_HIP_TWIN_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (timg_hip_sixel_encode(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
-                              bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
+                              bytes.get(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_sixel_encode");
+    const auto t1 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; ++i) {
         HeldFrame &f = batch.frames[i];
         if (f.prefix + lens[i] > f.cap) HipFatal(ctx_, "sixel frame larger than its buffer");
-        memcpy(f.buffer + f.prefix, bytes.data() + i * slot, lens[i]);
+        memcpy(f.buffer + f.prefix, bytes.get() + i * slot, lens[i]);
         f.promise.set_value(OutBuffer(f.buffer, f.prefix + lens[i]));
     }
+    if (trace)
+        fprintf(stderr, "HipSixelCanvas: batch of %zu frames %dx%d: encode call %.3f ms, hand-over %.3f ms\n", n, batch.w, batch.h,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 
 void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq_type,
@@ -91,7 +109,10 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     MoveCursorDX(x / options_.cell_x_px);
 
     const int w = fb_orig.width(), h = fb_orig.height();
-    const bool may_hold = hold_limit_ > 1 && seq_type == SeqType::FrameImmediate && !(have_last_x_ && x == last_x_);
+    const bool in_stream = seq_type == SeqType::StartOfAnimation || seq_type == SeqType::AnimationFrame;
+    const bool may_hold  = in_stream ? stream_hold_ > 1
+                                     : hold_limit_ > 1 && seq_type == SeqType::FrameImmediate && !(have_last_x_ && x == last_x_);
+    const int limit      = in_stream ? stream_hold_ : hold_limit_;
     have_last_x_ = true;
     last_x_      = x;
 
@@ -121,7 +142,7 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         f.x      = x;
         f.dy     = dy;
         write_sequencer_->WriteBuffer(rows_->Hold(w, h, device ? device : (const uint8_t *)fb_orig.begin(), device != nullptr,
-                                                  &pad, std::move(f), hold_limit_),
+                                                  &pad, std::move(f), limit),
                                       seq_type, end_of_frame);
         return;
     }
@@ -133,8 +154,8 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     uint8_t *device_copy     = nullptr;
     timg_hip_ctx *ctx        = ctx_;
     if (device) {
-        if (timg_hip_malloc(ctx, frame_bytes, (void **)&device_copy) != TIMG_HIP_OK ||
-            timg_hip_memcpy_d2d(ctx, device_copy, device, frame_bytes, nullptr) != TIMG_HIP_OK)
+        device_copy = (uint8_t *)HipPoolMalloc(ctx, frame_bytes);
+        if (!device_copy || timg_hip_memcpy_d2d(ctx, device_copy, device, frame_bytes, nullptr) != TIMG_HIP_OK)
             HipFatal(ctx, "HipSixelCanvas::Send");
     } else {
         memcpy(pixels->data(), fb_orig.begin(), frame_bytes);
@@ -146,7 +167,7 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         if (timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr, 1,
                                   flags, &pad, offset, cap - (size_t)(offset - buffer), 0, &len, nullptr) != TIMG_HIP_OK)
             HipFatal(ctx, "timg_hip_sixel_encode");
-        if (device_copy) (void)timg_hip_free(ctx, device_copy);
+        if (device_copy) HipPoolFree(ctx, device_copy);
         out.size += len;
         return out;
     };

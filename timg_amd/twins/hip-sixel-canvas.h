@@ -41,6 +41,13 @@ public:
     // Animation frames and a Send at the position of the previous one are encoded on their own.
     // 0 / 1: every Send is encoded on its own (default).
     void SetGridColumns(int columns);
+    // Streams (an animation / video source: StartOfAnimation + AnimationFrame Sends, BASELINE config 4).  A sixel
+    // frame depends on no other frame, so consecutive frames of a stream can share a device call the same way
+    // the images of a grid row do: up to `frames` Sends (bounded by what the sequencer's queue holds: the writer
+    // owns the first future, the queue the rest) are encoded by ONE timg_hip_sixel_encode; every Send still
+    // queues its own future in Send order, with its own end_of_frame -- pacing and frame skipping stay the
+    // sequencer's (src/buffered-write-sequencer.cc:107-131).  0 / 1: every frame on its own (default).
+    void SetStreamHold(int frames);
     // Encodes what is still held (nothing has to call this: an idle row encodes itself).
     void Flush();
 
@@ -55,6 +62,7 @@ private:
     ThreadPool *const executor_;
     timg_hip_ctx *const ctx_;
     int hold_limit_   = 1;
+    int stream_hold_  = 1;
     bool have_last_x_ = false;
     int last_x_       = 0;
     std::unique_ptr<HeldRows> rows_;  // (last member: its thread uses the ones above)

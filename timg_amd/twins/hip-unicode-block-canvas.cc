@@ -61,16 +61,16 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
     // (every one of them follows a Send at another x).
     if (n > 1) {
         const size_t slot = timg_hip_block_max_bytes(batch.w, batch.h);
-        std::vector<char> bytes(slot * (n - 1));
+        std::unique_ptr<char[]> bytes(new char[slot * (n - 1)]);  // (uninitialised on purpose)
         std::vector<size_t> lens(n - 1);
         std::vector<int> xs(n - 1);
         for (size_t i = 0; i + 1 < n; ++i) xs[i] = batch.frames[i].x;
         if (timg_hip_block_encode_grid(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)(n - 1), flags_,
-                                       xs.data(), bytes.data(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
+                                       xs.data(), bytes.get(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
             HipFatal(ctx_, "timg_hip_block_encode_grid");
         for (size_t i = 0; i + 1 < n; ++i) {
             HeldFrame &p = batch.frames[i];
-            memcpy(p.buffer + p.prefix, bytes.data() + i * slot, lens[i]);
+            memcpy(p.buffer + p.prefix, bytes.get() + i * slot, lens[i]);
             p.promise.set_value(OutBuffer(p.buffer, lens[i] ? p.prefix + lens[i] : 0));
         }
     }

@@ -266,6 +266,55 @@ def main():
         else:
             dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180))
 
+    # -- the exchange step: THE PRODUCT ONE.  timg_hip_gather_lengths / timg_hip_gather_payload (include/timg_hip_comm.h,
+    # libtimg_hip_comm.so: RCCL behind the C-ABI -- what HipGatherWriter feeds the reference's sequencer from).  Bootstrapped
+    # like any RCCL program: rank 0's unique id travels through torch.distributed's store.  timg_amd/gather.py (the same
+    # exchange written with torch.distributed calls) remains for the gloo tests and as the fallback when the C-ABI
+    # communicator cannot be created -- which the JSON line then says.  TIMG_BENCH_FORCE_GATHER=1: gather at world 1 too
+    # (the same calls with one rank), so that the code path runs where only one GPU is reachable.
+    force_gather = bool(os.environ.get("TIMG_BENCH_FORCE_GATHER")) and world == 1
+    exchange = {"ranks": world, "via": "none (one rank)"}
+    cabi = None
+    if (world > 1 and backend == "nccl") or force_gather:
+        from timg_amd import comm as tcomm
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = (tcomm.Comm.unique_id(), tcomm.rccl_info())
+            except Exception as exc:  # no librccl, ...
+                box[0] = ("error", str(exc))
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        if box[0][0] == "error":
+            exchange = {"ranks": world, "via": "torch.distributed (C-ABI communicator unavailable: %s)" % box[0][1]}
+        else:
+            # (every rank enters ncclCommInitRank together; a failure here is fatal for the job, as it should be)
+            cabi = tcomm.Comm(local_rank, world, rank, box[0][0])
+            exchange = {"ranks": world, "via": "timg_hip_gather_lengths + timg_hip_gather_payload (libtimg_hip_comm.so, C-ABI)",
+                        "lib": box[0][1][0], "rccl_version": box[0][1][1], "gathers": 0, "bytes_at_root": 0}
+    elif world > 1:
+        exchange = {"ranks": world, "via": "torch.distributed over %s (testing configuration)" % backend}
+    recv_buf = [None]
+
+    def gather(payload, lens):
+        """One exchange step: this rank's frames (payload: device bytes back to back, lens: byte counts) to rank 0."""
+        if cabi is None:
+            return gather_frames_to_root(payload, lens)
+        import numpy as np
+        lens_h = lens.cpu().numpy().astype(np.uint64)
+        all_len = cabi.gather_lengths(lens_h, max(1, len(lens_h)))
+        total = int(all_len.sum())
+        recv_ptr = recv_cap = 0
+        if rank == 0:
+            if recv_buf[0] is None or recv_buf[0].numel() < total:
+                recv_buf[0] = torch.empty(max(total + total // 4, 1 << 20), dtype=torch.uint8, device="cuda")
+            recv_ptr, recv_cap = recv_buf[0].data_ptr(), recv_buf[0].numel()
+        got = cabi.gather_payload(payload.data_ptr() if payload.numel() else 0, all_len, recv_ptr, recv_cap)
+        if rank == 0:
+            exchange["gathers"] += 1
+            exchange["bytes_at_root"] = got
+        return None
+
     cfg = dict(CONFIGS[args.config])
     if args.frames:
         cfg["frames"] = args.frames
@@ -333,7 +382,7 @@ def main():
         """n_steps passes of the hot path; with several ranks the outputs are gathered to rank 0
         in step order by this (the main) thread."""
         if not strong:
-            run_batched_streams(pipes, src, n_steps, n_pipes, world, gather_frames_to_root, timed_events, record)
+            run_batched_streams(pipes, src, n_steps, n_pipes, 2 if force_gather else world, gather, timed_events, record)
             return
         for _ in range(n_steps):  # a step = the whole sharded stream, chunk by chunk
             for k in range(n_launches_max):
@@ -347,7 +396,7 @@ def main():
                     e2 = record(p.stream)
                     if timed_events is not None:
                         timed_events.append((e0, e1, e2))
-                if world > 1:
+                if world > 1 or force_gather:
                     # every rank takes part in every gather; ranks that own fewer frames pad their
                     # lengths with zeros (the gather wants the same frame count everywhere)
                     if c is not None:
@@ -358,7 +407,7 @@ def main():
                     want = max(min(chunk, max(0, n_r - k * chunk)) for n_r in counts)
                     if lens.numel() < want:
                         lens = torch.cat([lens, torch.zeros(want - lens.numel(), dtype=torch.int64, device="cuda")])
-                    gather_frames_to_root(payload, lens)
+                    gather(payload, lens)
 
     def timed(n_steps, n_pipes, timed_events=None):
         torch.cuda.synchronize()
@@ -470,6 +519,7 @@ def main():
             "avg_launch_ms": round(scale_avg_ms, 4),
             "limiter": "instruction issue (profiles/r2: SQ counters), not HBM",
         },
+        "rccl": exchange,
         "stages_ms": {"scale_blend": round(sum(scale_ms) / args.steps, 3),
                       "encode": round(sum(encode_ms) / args.steps, 3)},
         "output_bytes_per_step": out_bytes * (launches_per_step if strong else 1),
@@ -596,6 +646,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if cabi is not None:
+        cabi.close()
     for h in hips:
         h.close()
     if parity_failed:

@@ -99,3 +99,26 @@ def test_comm_library_does_not_link_rccl():
     so = os.path.join(ROOT, "timg_amd", "libtimg_hip_comm.so")
     dyn = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "NEEDED" in dyn and "rccl" not in dyn, dyn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--frames", "4"], ["--config", "c4", "--frames", "10", "--chunk", "4"]])
+def test_bench_exchanges_through_the_c_abi_gather(extra):
+    """bench.py's exchange step is the PRODUCT one (timg_hip_gather_lengths / _payload behind the C-ABI), not a second
+    implementation.  Only one GPU is reachable here: TIMG_BENCH_FORCE_GATHER=1 makes the single rank run the very
+    calls a multi-GPU job makes per step (all-gather of the lengths, payload hand-over to the root).  The line must say
+    which RCCL served, how many gathers ran and that the root received exactly the step's bytes -- and carry a green
+    parity_check of the timed output."""
+    env = dict(os.environ, TIMG_BENCH_FORCE_GATHER="1", TIMG_SKIP_CANARY="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--prewarm", "0.05",
+                        "--no-cpu-baseline", "--no-extras"] + extra, capture_output=True, text=True, timeout=600, env=env,
+                       cwd=ROOT)
+    line = ([ln for ln in r.stdout.splitlines() if ln.startswith("{")] or [""])[-1]
+    if r.returncode != 0 and not line and r.returncode < 0:
+        pytest.skip(f"bench.py died with signal {-r.returncode} while RCCL came up: {r.stderr[-800:]}")
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-600:], r.stderr[-1200:])
+    out = json.loads(line)
+    x = out["rccl"]
+    assert "C-ABI" in x["via"] and x["rccl_version"] > 0 and "librccl" in x["lib"], x
+    assert x["gathers"] >= 2 and x["bytes_at_root"] > 0, x
+    assert out["parity_check"]["ok"], out["parity_check"]

@@ -132,11 +132,12 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
             payload, lens = pipes[k % n_pipes].packed_output()
             consumed[k].set()
             gather(payload, lens)
+    if errors:
+        for ev in consumed:  # surviving workers may be parked on consumed[k - n_pipes]: release them BEFORE joining
+            ev.set()
     for t in threads:
         t.join()
     if errors:
-        for ev in consumed:  # (nobody is left waiting)
-            ev.set()
         raise errors[0]
 
 

@@ -32,6 +32,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The fused step forks its pieces onto side streams: with ROCm's default of 4 hardware queues a process that holds
+# more streams than that multiplexes them, and an event wait between two streams that share a queue costs
+# milliseconds (measured in round 2: 1.15 ms per extra stream per batch; gone with 8 queues).  Runtime
+# configuration, set before the HIP runtime comes up; INTEGRATION.md tells C++ hosts the same.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -226,6 +231,9 @@ def main():
     ap.add_argument("--mode", default="", choices=["", "sixel", "quarter", "half", "kitty", "iterm2", "png"],
                     help="canvas override: sixel, half/quarter blocks, or a graphics protocol at --compress=0")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 streaming")
+    ap.add_argument("--pieces", type=int, default=0,
+                    help="sixel: 0 / 1 = scale and encode as two calls (kernels undisturbed; default: profiles/r3/"
+                         "fused_pieces.txt); N > 1 = timg_hip_scale_sixel_encode with N pieces")
     ap.add_argument("--prewarm", type=float, default=0.4,
                     help="seconds of untimed steps before the warm-up steps (clock ramp-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -340,7 +348,7 @@ def main():
     n_pipes = max(1, args.pipelines) if not strong else 1
     n_extra = 0 if (strong or args.no_extras or args.config != "metric") else max(0, args.batched_streams)
     hips = [timg_amd.TimgHip(local_rank) for _ in range(max(n_pipes, n_extra, 1))]
-    pipes = [GridPipeline(h, chunk, in_w, in_h, out_w, out_h, mode, blend) for h in hips]
+    pipes = [GridPipeline(h, chunk, in_w, in_h, out_w, out_h, mode, blend, pieces=args.pieces) for h in hips]
     if args.kernel:
         for p in pipes:
             p.scaler.set_kernel(args.kernel)
@@ -368,7 +376,7 @@ def main():
               if strong else [n_mine] * world)
     n_launches_max = max((n + chunk - 1) // chunk for n in counts) if strong else 1
     if chunks and chunks[-1].shape[0] != chunk:  # a ragged tail gets its own pipeline
-        tail_pipe = GridPipeline(hips[0], chunks[-1].shape[0], in_w, in_h, out_w, out_h, mode, blend)
+        tail_pipe = GridPipeline(hips[0], chunks[-1].shape[0], in_w, in_h, out_w, out_h, mode, blend, pieces=args.pieces)
     else:
         tail_pipe = None
 
@@ -390,12 +398,16 @@ def main():
                 if c is not None:
                     p = tail_pipe if (tail_pipe is not None and c.shape[0] != chunk) else pipe
                     e0 = record(p.stream)
-                    p.scale(c)
-                    e1 = record(p.stream)
-                    p.encode()
+                    if p.fused:
+                        p.step(c)
+                        e1 = None
+                    else:
+                        p.scale(c)
+                        e1 = record(p.stream)
+                        p.encode()
                     e2 = record(p.stream)
                     if timed_events is not None:
-                        timed_events.append((e0, e1, e2))
+                        timed_events.append((e0, e1, e2, p.last_scale_ms))
                 if world > 1 or force_gather:
                     # every rank takes part in every gather; ranks that own fewer frames pad their
                     # lengths with zeros (the gather wants the same frame count everywhere)
@@ -457,8 +469,11 @@ def main():
                               (BG, PATTERN if cfg.get("checker") else (0, 0, 0, 0), pw, ph), last_src.shape[0])
 
     launches_per_step = len(chunks) if strong else 1
-    scale_ms = [a.elapsed_time(b) for a, b, _ in events]
-    encode_ms = [b.elapsed_time(c) for _, b, c in events]
+    # per launch of the hot path: device time of the scale kernels (two calls: events around the scale call; fused call:
+    # the library's own events around every piece's scale launches, summed) and the rest of the step
+    fused = pipe.fused
+    scale_ms = [ms if e1 is None else e0.elapsed_time(e1) for e0, e1, _, ms in events]
+    encode_ms = [e0.elapsed_time(e2) - sc for (e0, _, e2, _), sc in zip(events, scale_ms)]
     sizes = [c.shape[0] for c in chunks] * args.steps if strong else [chunk] * len(events)
     full = [s for s, n in zip(scale_ms, sizes) if n == chunk]  # (a ragged tail launch is not the roofline's launch)
     roof_frames = chunk
@@ -466,7 +481,11 @@ def main():
         full = scale_ms
         roof_frames = max(sizes) if sizes else chunk
     scale_avg_ms = sum(full) / max(1, len(full))
-    alg_bytes = pipe.scaler.algorithmic_bytes() * roof_frames  # per launch (one full batch)
+    # (fused call: a batch is `pieces` scale launches, the library's events sum their device time; bytes and time are
+    # divided by the same count, so `achieved` is the same number either way)
+    launches_per_batch = pipe.pieces if fused else 1
+    alg_bytes = pipe.scaler.algorithmic_bytes() * roof_frames // launches_per_batch  # per launch
+    scale_avg_ms /= launches_per_batch
     achieved = alg_bytes / (scale_avg_ms * 1e-3) / 1e9 if scale_avg_ms > 0 else 0.0
     frames_total = cfg["frames"] if strong else world * cfg["frames"]
     total_px = frames_total * in_w * in_h * args.steps
@@ -502,6 +521,7 @@ def main():
                              "RCCL gather of output bytes to rank 0" if world > 1 else "single GPU, batched launches")
                             + f"; {n_pipes} batch(es) in flight per GPU"),
             "pipelines": n_pipes,
+            "pieces": pipe.pieces,
             "scale_kernel": "streaming" if (info["streaming_ok"] and args.kernel != 1) else "generic",
             "pass_order": "vertical-first" if info["vertical_first"] else "horizontal-first",
         },
@@ -518,6 +538,11 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(scale_avg_ms, 4),
             "limiter": "instruction issue (profiles/r2: SQ counters), not HBM",
+            "launches_per_step": launches_per_batch * (launches_per_step if strong else 1),
+            "measured": ("HIP events of libtimg_hip.so around every piece's scale launches on the piece's own stream "
+                         "(timg_hip_scale_sixel_encode: the kernels run beside the serial sixel stages of the pieces in front "
+                         "-- durations are those of the timed region, not of a kernel alone on the chip; --pieces 1 times it alone)"
+                         if fused else "HIP events around the scale call on the pipeline's stream; the kernel is alone on the chip"),
         },
         "rccl": exchange,
         "stages_ms": {"scale_blend": round(sum(scale_ms) / args.steps, 3),
@@ -532,7 +557,7 @@ def main():
             t = json.load(open(traffic_file))
             if (t.get("workload_frames") == chunk and t.get("kernel") == result["config"]["scale_kernel"]
                     and t.get("config", "metric") == args.config):
-                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"] // launches_per_batch
                 result["roofline"]["traffic_measured_in_this_run"] = False
                 result["roofline"]["traffic_source"] = ("NOT measured in this run: profiles/hbm_traffic.json, rocprofv3 "
                                                         "--pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
@@ -561,12 +586,14 @@ def main():
             evs.append((e0, record(pipe.stream)))
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        batch_bytes = pipe.scaler.algorithmic_bytes() * chunk
         result["roofline_alpha"] = {
             "kernel": "scale+alpha-compose on S-alpha frames (radial alpha ramp, transparent border, 10 % special "
                       "alphas), composed over the background",
-            "bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4),
+            "bound": "hbm", "achieved": round(batch_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(batch_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": batch_bytes, "avg_launch_ms": round(ms, 4),
+            "measured": "one launch per batch, alone on the chip (HIP events around the scale call)",
         }
         del src_alpha
 

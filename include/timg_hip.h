@@ -232,14 +232,36 @@ void timg_hip_block_canvas_forget(timg_hip_block_canvas *c);
  * within a stated Delta-E of the CPU restatement (libsixel is un-vendored:
  * parity unpinned). */
 #define TIMG_HIP_SIXEL_BROKEN_CURSOR 1 /* SixelOptions::known_broken_cursor_placement */
-/* libsixel's lookup cache exactly as sixel_encode fills it: a 15-bit cell answers with the palette entry
- * nearest to the FIRST pixel value that lands in it, in raster order, diffused errors included.  That order
- * is inherently serial: one wave walks a frame (~0.3 s per 800x450 frame, frames of a batch in parallel).
- * Without the flag a cell answers with the entry nearest to its centre and the diffusion is pipelined
- * (1.6 ms per 64 frames); both rules stay within the per-pixel bound stated in DESIGN.md. */
+/* A CHECKER MODE, not a production path: libsixel's lookup cache exactly as sixel_encode fills it -- a 15-bit cell
+ * answers with the palette entry nearest to the FIRST pixel value that lands in it, in raster order, diffused errors
+ * included.  That order is inherently serial: one wave walks a frame, ~0.3 s per 800x450 frame (15x slower than one
+ * host thread running the same rule).  It exists so that the device's default rule can be compared with libsixel's
+ * semantics pixel by pixel on the device (the per-pixel bound in DESIGN.md 2, tests/test_sixel_oracle.py); a
+ * maintainer who needs libsixel's exact cache behaviour at speed keeps the CPU SixelCanvas.  Without the flag a cell
+ * answers with the entry nearest to its centre and the diffusion is pipelined (1.6 ms per 64 frames). */
 #define TIMG_HIP_SIXEL_FIRST_HIT 2
 
 size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
+
+/* ---- scale + compose + sixel encode in ONE call (device-resident batches) ------------------
+ * What an ImageSource and a SixelCanvas do to a batch of frames back to back -- ImageScaler::Scale +
+ * AlphaComposeBackground (src/qoi-image-source.cc:63-74), then SixelCanvas::Send (src/sixel-canvas.cc:
+ * 100-155) -- with the batch cut into `pieces` whose chains (scale -> histogram -> median cut ->
+ * diffusion -> bands) run on streams the context owns, forked from and joined to `stream` once per
+ * piece: the scale of a piece (all CUs, bandwidth) runs beside the per-frame serial stages of the
+ * pieces in front of it (one workgroup per frame).  Bytes are those of timg_hip_scale_blend followed
+ * by timg_hip_sixel_encode with pad_blend = blend.  src: n_frames source frames in DEVICE memory;
+ * scaled: device memory for n_frames packed out_w x out_h frames (left there); out / out_cap /
+ * out_on_device / out_len as timg_hip_sixel_encode.  pieces: 0 = library's choice (1 today: measured,
+ * profiles/r3/fused_pieces.txt -- the scale kernel's coarse tiles cost what the overlap wins), up to 4.
+ * scale_ms (optional): device time of the scale kernels, summed over the pieces (HIP events on the
+ * pieces' own streams) -- what a roofline needs when the kernels are not alone on the chip.
+ * Returns after synchronising `stream`. */
+int timg_hip_scale_sixel_encode(timg_hip_ctx *ctx, timg_hip_scaler *s, const uint8_t *src, int src_stride,
+                                size_t src_frame_stride, uint8_t *scaled, int n_frames,
+                                const timg_hip_blend *blend, int sixel_flags, char *out, size_t out_cap,
+                                int out_on_device, size_t *out_len, int pieces, float *scale_ms,
+                                void *stream);
 /* Frames up to 4095 pixels wide (columns travel in 12-bit fields); wider ones are refused
  * with TIMG_HIP_ERR_UNSUPP. */
 

@@ -44,6 +44,42 @@ def test_scale_bit_exact(hip, oracle, kind, sw, sh, dw, dh, kernel):
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} differing bytes"
 
 
+@pytest.mark.parametrize("sw,sh,dw,dh", [(1000, 300, 6000, 280), (1024, 1024, 5500, 900), (800, 600, 5000, 500),
+                                         (1500, 900, 6100, 850)])
+def test_wide_upscales_that_overflow_the_matrix_kernels_lds(hip, oracle, sw, sh, dw, dh):
+    """One- or two-tap rows with thousands of outputs per strip: the VALU streaming layout fits 128 KB of LDS, the
+    matrix kernel's float4 weight groups do not -- the launch must fall back (same bytes), not fail."""
+    src = synth.make("alpha", sw, sh, seed=sw + dh)
+    assert np.array_equal(hip.scale(src, dw, dh), oracle.scale(src, dw, dh))
+
+
+@pytest.mark.parametrize("pieces", [1, 2, 3, 4, 0])
+def test_fused_scale_sixel_call_equals_the_two_calls(hip, oracle, pieces):
+    """timg_hip_scale_sixel_encode (the batch cut into pieces on the context's side streams, a piece's scale beside
+    the serial sixel stages of the pieces in front of it) delivers the bytes of timg_hip_scale_blend followed by
+    timg_hip_sixel_encode -- ragged piece sizes included -- and those are the oracle's."""
+    n, sw, sh, dw, dh = 7, 640, 360, 133, 75
+    frames = np.stack([synth.make("alpha" if i % 2 else "photo", sw, sh, seed=40 + i) for i in range(n)])
+    blend = timg_amd.Blend.make(BG, PAT, 4, 4)
+    dsrc = hip.upload(frames)
+    dscaled = hip.malloc(n * dw * dh * 4)
+    cap = hip.sixel_max_bytes(dw, dh)
+    dout = hip.malloc(n * cap)
+    sc = hip.scaler(sw, sh, dw, dh)
+    for _ in range(2):  # (twice: the tile bookkeeping of the pieces' slots carries over between calls)
+        lens, scale_ms = hip.scale_sixel_encode(sc, dsrc, dscaled, n, blend, dout, cap, pieces=pieces)
+        assert scale_ms > 0
+        scaled = hip.download(dscaled, n * dw * dh * 4).reshape(n, dh, dw, 4)
+        out = hip.download(dout, n * cap).reshape(n, cap)
+        for i in range(n):
+            want, _ = oracle.alpha_compose(oracle.scale(frames[i], dw, dh), BG, PAT, 4, 4)
+            assert np.array_equal(scaled[i], want), i
+            assert out[i, :lens[i]].tobytes() == oracle.sixel_encode(want, BG, PAT, 4, 4, lookup_mode=1), i
+    for p in (dsrc, dscaled, dout):
+        hip.free(p)
+    sc.close()
+
+
 def test_scale_bgra_input(hip, oracle):
     src = synth.alpha(200, 150, seed=3)
     assert np.array_equal(hip.scale(src, 77, 41, in_fmt=1), oracle.scale(src, 77, 41, in_fmt=1))

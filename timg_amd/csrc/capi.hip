@@ -2,6 +2,7 @@
 // context, memory helpers, the ImageScaler twin and the standalone alpha
 // compose.  Canvas entry points live in block_canvas.hip / sixel_canvas.hip.
 #include <cstring>
+#include <functional>
 #include <new>
 
 #include "context.h"
@@ -14,10 +15,14 @@ static thread_local std::string g_global_error;
 
 namespace timg_amd {
 hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
-                             const FrameBatch &batch, hipStream_t stream);
+                             const FrameBatch &batch, hipStream_t stream, int slot);
 bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not);
 void ReleaseStreamSchedule(timg_hip_scaler *s);
 int StreamShapeBits(const timg_hip_scaler *s);
+int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride, size_t frame_stride,
+                    int fb_on_device, int n_frames, int flags, const timg_hip_blend *pad_blend, char *out,
+                    size_t out_cap, int out_on_device, size_t *out_len, void *stream, int pieces_req,
+                    const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms);
 }  // namespace timg_amd
 
 DevBlend MakeDevBlend(const timg_hip_blend *b) {
@@ -147,6 +152,8 @@ void timg_hip_destroy(timg_hip_ctx *ctx) {
     for (auto st : ctx->side)
         if (st) (void)hipStreamDestroy(st);
     for (auto ev : ctx->join_event)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : ctx->hook_event)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     delete ctx;
@@ -351,7 +358,7 @@ int timg_hip_scale_blend(timg_hip_ctx *ctx, timg_hip_scaler *s, const uint8_t *s
     } else {
         const bool want_stream =
             s->forced_kernel == 2 || (s->forced_kernel == 0 && s->streaming_ok);
-        e = want_stream ? timg_amd::LaunchScaleStream(s, db, batch, st)
+        e = want_stream ? timg_amd::LaunchScaleStream(s, db, batch, st, 0)
                         : timg_amd::LaunchScaleGeneric(s->dev, db, batch, st);
     }
     if (e != hipSuccess) return ctx->FailHip(e, "scale kernel launch");
@@ -363,6 +370,48 @@ int timg_hip_scale_blend(timg_hip_ctx *ctx, timg_hip_scaler *s, const uint8_t *s
                                          sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
     if (uses_scratch) TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     return TIMG_HIP_OK;
+}
+
+int timg_hip_scale_sixel_encode(timg_hip_ctx *ctx, timg_hip_scaler *s, const uint8_t *src, int src_stride,
+                                size_t src_frame_stride, uint8_t *scaled, int n_frames, const timg_hip_blend *blend,
+                                int sixel_flags, char *out, size_t out_cap, int out_on_device, size_t *out_len,
+                                int pieces, float *scale_ms, void *stream) {
+    if (!ctx || !s || !src || !scaled || !out || !out_len || n_frames <= 0) return TIMG_HIP_ERR_ARG;
+    if (s->ctx != ctx) return ctx->Fail(TIMG_HIP_ERR_ARG, "scaler belongs to another context");
+    const timg_amd::ResamplePlan &p = s->plan;
+    if (src_stride == 0) src_stride = p.in_w * 4;
+    if (src_stride < p.in_w * 4 || (src_stride & 3) || ((uintptr_t)src & 3) || ((uintptr_t)scaled & 3))
+        return ctx->Fail(TIMG_HIP_ERR_ARG, "bad stride/alignment");
+    if (src_frame_stride == 0) src_frame_stride = (size_t)src_stride * p.in_h;
+    if (src_frame_stride & 3) return ctx->Fail(TIMG_HIP_ERR_ARG, "buffers must be 4-byte aligned");
+    if (pieces <= 0) {
+        // MEASURED (profiles/r3/fused_pieces.txt, 64x 4K -> 800x450): two pieces 2.21 ms per step against 2.25 as two
+        // calls, four pieces 2.47 -- a scale launch beside the serial sixel kernels runs two rounds of its coarse tiles
+        // (1024 columns x 45 rows, ~0.22 ms each) on the CUs the diffusion leaves free and loses what the overlap wins.
+        // So the library's own choice is one piece; callers (or TIMG_HIP_PIECES) can ask for more.
+        pieces = 1;
+        if (const char *e = getenv("TIMG_HIP_PIECES")) pieces = atoi(e);  // tuning
+    }
+    const size_t out_frame = (size_t)p.out_w * p.out_h * 4;
+    const DevBlend db      = MakeDevBlend(blend);
+    const std::function<hipError_t(int, int, int, hipStream_t)> scale_piece = [&](int piece, int f0, int nfr,
+                                                                                  hipStream_t st) -> hipError_t {
+        FrameBatch batch;
+        batch.n_frames          = nfr;
+        batch.src               = src + (size_t)f0 * src_frame_stride;
+        batch.src_stride        = (size_t)src_stride;
+        batch.src_frame_stride  = src_frame_stride;
+        batch.dst               = scaled + (size_t)f0 * out_frame;
+        batch.dst_stride        = (size_t)p.out_w * 4;
+        batch.dst_frame_stride  = out_frame;
+        batch.transparent_flags = nullptr;
+        if (p.identity) return timg_amd::LaunchCopyBlend(s->dev, db, batch, st);
+        const bool want_stream = s->forced_kernel == 2 || (s->forced_kernel == 0 && s->streaming_ok);
+        return want_stream ? timg_amd::LaunchScaleStream(s, db, batch, st, piece)
+                           : timg_amd::LaunchScaleGeneric(s->dev, db, batch, st);
+    };
+    return timg_amd::SixelEncodeImpl(ctx, scaled, p.out_w, p.out_h, 0, 0, 1, n_frames, sixel_flags, blend, out, out_cap,
+                                     out_on_device, out_len, stream, pieces, &scale_piece, scale_ms);
 }
 
 int timg_hip_alpha_compose(timg_hip_ctx *ctx, uint8_t *fb, int w, int h, int stride,

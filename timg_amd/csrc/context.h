@@ -69,6 +69,7 @@ struct timg_hip_ctx {
     static constexpr int kSideStreams = 4;
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_event = nullptr, join_event[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t hook_event[2 * kSideStreams] = {};  // (timing: around a piece's scale launches)
     hipError_t EnsureSideStreams() {
         if (fork_event) return hipSuccess;
         for (auto &st : side) {
@@ -77,6 +78,10 @@ struct timg_hip_ctx {
         }
         for (auto &ev : join_event) {
             hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        for (auto &ev : hook_event) {
+            hipError_t e = hipEventCreate(&ev);
             if (e != hipSuccess) return e;
         }
         return hipEventCreateWithFlags(&fork_event, hipEventDisableTiming);

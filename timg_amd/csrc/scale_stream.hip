@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1229,9 +1230,13 @@ struct StreamSchedule {
     int hrow        = 0;        // widest strip, in output columns
     bool hfirst     = false;    // horizontal-first plan: ScaleStreamHKernel
     int hwin        = 0;        // ... widest source window of a strip (multiple of 4)
-    int *tile_state = nullptr;  // device, grown on demand
-    int gen         = 0;        // generation of the current scale call (tile_state holds generations)
-    size_t tile_cap = 0;
+    // Tile bookkeeping of a scale call, per SLOT: calls of one scaler that may be in flight at the same time (the
+    // pieces of timg_hip_scale_sixel_encode, each on its own stream) use different slots.
+    static constexpr int kTileSlots = 4;
+    int *tile_state[kTileSlots] = {nullptr, nullptr, nullptr, nullptr};  // device, grown on demand
+    int gen[kTileSlots]         = {0, 0, 0, 0};  // generation of the slot's current call (tile_state holds generations)
+    size_t tile_cap[kTileSlots] = {0, 0, 0, 0};
+    int slot                    = 0;             // the slot of the call being launched (host-side plumbing)
 };
 
 static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &strips,
@@ -1527,7 +1532,8 @@ void ReleaseStreamSchedule(timg_hip_scaler *s) {
     if (!ss) return;
     for (auto &v : ss->v)
         if (v.device) (void)DevFree(v.device);
-    if (ss->tile_state) (void)DevFree(ss->tile_state);
+    for (int *t : ss->tile_state)
+        if (t) (void)DevFree(t);
     delete ss;
     s->stream_tables = nullptr;
 }
@@ -1538,16 +1544,16 @@ static hipError_t LaunchMode(const timg_hip_scaler *s, const StreamSchedule *ss,
                              const FrameBatch &batch, hipStream_t stream) {
     const size_t lds = ((size_t)ModeTraits<M>::kStage * kStripCols * ModeTraits<M>::kStride + 2 * (size_t)ss->hrow +
                         (size_t)s->plan.h_width * ss->hrow) * sizeof(float);
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamKernel<M>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    // (once per instantiation and process; loader threads may get here concurrently: timg_hip.h promises them that)
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, []() {
+        attr_err = hipFuncSetAttribute((const void *)ScaleStreamKernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL(ScaleStreamKernel<M>, grid, dim3(kThreads), lds, stream, s->dev, v.t, blend,
-                       batch, ss->tile_state, ss->gen, ss->hrow);
+                       batch, ss->tile_state[ss->slot], ss->gen[ss->slot], ss->hrow);
     return hipGetLastError();
 }
 
@@ -1557,22 +1563,35 @@ static hipError_t LaunchModeMO(const timg_hip_scaler *s, const StreamSchedule *s
     const int hgroups = (s->plan.h_width + 3) / 4;
     const size_t lds  = ((size_t)MKernelShape<M, kOvf>::kStage * (kStripCols + 4 * hgroups) * 4 + (size_t)hgroups * ss->hrow * 4) * sizeof(float) +
                        (size_t)ss->hrow * sizeof(int);
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamMKernel<M, kOvf>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    // (once per instantiation and process; loader threads may get here concurrently: timg_hip.h promises them that)
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, []() {
+        attr_err = hipFuncSetAttribute((const void *)ScaleStreamMKernel<M, kOvf>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL((ScaleStreamMKernel<M, kOvf>), grid, dim3(kThreads), lds, stream, s->dev, v.t, v.m, blend, batch,
-                       ss->tile_state, ss->gen, ss->hrow, hgroups);
+                       ss->tile_state[ss->slot], ss->gen[ss->slot], ss->hrow, hgroups);
     return hipGetLastError();
+}
+
+// What the matrix kernel needs beyond the VALU kernel's own bounds: its staging rows and float4 weight groups in at
+// most 128 KB of LDS (a plan with one- or two-tap rows and thousands of outputs per strip -- large upscales -- fits
+// the VALU layout but not this one), and 32-bit row byte offsets (the kernel advances a uint32 through the frame).
+template <int M, bool kOvf>
+static bool MatrixKernelFits(const timg_hip_scaler *s, const StreamSchedule *ss, const FrameBatch &batch) {
+    const int hgroups = (s->plan.h_width + 3) / 4;
+    const size_t lds  = ((size_t)MKernelShape<M, kOvf>::kStage * (kStripCols + 4 * hgroups) * 4 + (size_t)hgroups * ss->hrow * 4) * sizeof(float) +
+                       (size_t)ss->hrow * sizeof(int);
+    return lds + 64 <= (size_t)128 * 1024 && (size_t)s->plan.in_h * batch.src_stride < ((size_t)1 << 32);
 }
 
 template <int M>
 static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    if (!(v.m_ovf ? MatrixKernelFits<M, true>(s, ss, batch) : MatrixKernelFits<M, false>(s, ss, batch)))
+        return LaunchMode<M>(s, ss, v, blend, batch, stream);  // same results, all-VALU
     return v.m_ovf ? LaunchModeMO<M, true>(s, ss, v, blend, batch, stream)
                    : LaunchModeMO<M, false>(s, ss, v, blend, batch, stream);
 }
@@ -1584,16 +1603,16 @@ static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *s
     int w4 = (ss->hwin + 2 * TAPS + 3) / 4 + 1;
     while ((w4 & 15) != 4) ++w4;
     const size_t lds = (size_t)4 * w4 * 4 * sizeof(float);
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    // (once per instantiation and process; loader threads may get here concurrently: timg_hip.h promises them that)
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, []() {
+        attr_err = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
-                       batch, ss->tile_state, ss->gen, ss->hwin, w4);
+                       batch, ss->tile_state[ss->slot], ss->gen[ss->slot], ss->hwin, w4);
     return hipGetLastError();
 }
 
@@ -1609,9 +1628,10 @@ static hipError_t LaunchModeH(const timg_hip_scaler *s, const StreamSchedule *ss
 }
 
 hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
-                             const FrameBatch &batch, hipStream_t stream) {
+                             const FrameBatch &batch, hipStream_t stream, int slot) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
-    if (!ss) return hipErrorNotSupported;
+    if (!ss || slot < 0 || slot >= StreamSchedule::kTileSlots) return hipErrorNotSupported;
+    ss->slot = slot;
     // rows of whole pixels (the 16-byte loads only need 4-byte alignment); otherwise the
     // generic kernel runs
     if (((uintptr_t)batch.src & 3) || (batch.src_stride & 3) || (batch.src_frame_stride & 3))
@@ -1620,22 +1640,26 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
     const bool enough = (size_t)tall.t.n_strips * tall.t.n_bands * batch.n_frames >= 512;
     const StreamVariant &v = enough ? tall : ss->v[1];
     const size_t tiles = (size_t)v.t.n_strips * v.t.n_bands * batch.n_frames;
-    if (tiles > ss->tile_cap) {
-        if (ss->tile_state) (void)DevFree(ss->tile_state);
-        ss->tile_state = nullptr;
-        ss->tile_cap   = 0;
-        hipError_t e   = DevMalloc((void **)&ss->tile_state, tiles * sizeof(int));
+    if (tiles > ss->tile_cap[slot]) {
+        // (a slot's previous call may still be running on ANOTHER stream: the device is idle before its table goes)
+        if (ss->tile_state[slot]) {
+            (void)hipDeviceSynchronize();
+            (void)DevFree(ss->tile_state[slot]);
+        }
+        ss->tile_state[slot] = nullptr;
+        ss->tile_cap[slot]   = 0;
+        hipError_t e         = DevMalloc((void **)&ss->tile_state[slot], tiles * sizeof(int));
         if (e != hipSuccess) return e;
         // (once per allocation, ordered in front of the kernels on this stream)
-        if ((e = hipMemsetAsync(ss->tile_state, 0, tiles * sizeof(int), stream)) != hipSuccess) return e;
-        ss->tile_cap = tiles;
-        ss->gen      = 0;
+        if ((e = hipMemsetAsync(ss->tile_state[slot], 0, tiles * sizeof(int), stream)) != hipSuccess) return e;
+        ss->tile_cap[slot] = tiles;
+        ss->gen[slot]      = 0;
     }
     // a tile is done when it carries this call's generation: nothing to clear per call
-    if (++ss->gen == 0x7fffffff) {
-        hipError_t e0 = hipMemsetAsync(ss->tile_state, 0, ss->tile_cap * sizeof(int), stream);
+    if (++ss->gen[slot] == 0x7fffffff) {
+        hipError_t e0 = hipMemsetAsync(ss->tile_state[slot], 0, ss->tile_cap[slot] * sizeof(int), stream);
         if (e0 != hipSuccess) return e0;
-        ss->gen = 1;
+        ss->gen[slot] = 1;
     }
     hipError_t e = hipSuccess;
     // cheapest channel set first; tiles whose data breaks its assumption stay

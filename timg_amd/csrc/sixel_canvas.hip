@@ -18,6 +18,7 @@
 //   K6 AssembleFrame / CopyBands  header, palette, band offsets, compaction
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <cstring>
 
 #include "context.h"
@@ -1922,11 +1923,17 @@ extern "C" size_t timg_hip_sixel_max_bytes(int w, int h) {
     return 1024 + (size_t)w * Round6(h) * 5;  // src/sixel-canvas.cc:123
 }
 
-extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
-                                     int stride, size_t frame_stride, int fb_on_device,
-                                     int n_frames, int flags, const timg_hip_blend *pad_blend,
-                                     char *out, size_t out_cap, int out_on_device,
-                                     size_t *out_len, void *stream) {
+// The encoder behind timg_hip_sixel_encode and timg_hip_scale_sixel_encode.  pieces_req > 0: the batch is cut into
+// that many pieces whose kernel chains run on the context's side streams (forked from / joined to `stream` with
+// events); before_piece, when given, is called with (piece, first frame, frames, stream) before a piece's first
+// kernel is enqueued -- the fused entry point launches the piece's SCALE there, so that it runs beside the serial
+// stages (median cut, diffusion: one workgroup per frame) of the pieces in front of it.  hook_ms (optional): device
+// time of the hooks' work, summed over the pieces (HIP events on the pieces' own streams).
+namespace timg_amd {
+int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride, size_t frame_stride,
+                    int fb_on_device, int n_frames, int flags, const timg_hip_blend *pad_blend, char *out,
+                    size_t out_cap, int out_on_device, size_t *out_len, void *stream, int pieces_req,
+                    const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms) {
     if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0)
         return TIMG_HIP_ERR_ARG;
     if (w > kMaxSixelWidth)
@@ -2100,13 +2107,13 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     // 4.7 ms, 4 groups 6.3 ms), far more than the overlap wins -- so the default is ONE
     // group; TIMG_HIP_SIXEL_GROUPS keeps the experiment reproducible.
     TIMG_HIP_TRY(ctx, hipMemsetAsync(b.error, 0, sizeof(unsigned long long), st));
-    int n_groups = 1;
-    if (const char *e = getenv("TIMG_HIP_SIXEL_GROUPS"))  // tuning
-        n_groups = std::max(1, std::min(atoi(e), std::min(n_frames, (int)timg_hip_ctx::kSideStreams)));
-    if (n_groups > 1) {
-        TIMG_HIP_TRY(ctx, ctx->EnsureSideStreams());
-        TIMG_HIP_TRY(ctx, hipEventRecord(ctx->fork_event, st));
-    }
+    int n_groups = pieces_req > 0 ? pieces_req : 1;
+    if (pieces_req <= 0)
+        if (const char *e = getenv("TIMG_HIP_SIXEL_GROUPS"))  // tuning
+            n_groups = atoi(e);
+    n_groups = std::max(1, std::min(n_groups, std::min(n_frames, (int)timg_hip_ctx::kSideStreams)));
+    if (n_groups > 1 || hook_ms) TIMG_HIP_TRY(ctx, ctx->EnsureSideStreams());
+    if (n_groups > 1) TIMG_HIP_TRY(ctx, hipEventRecord(ctx->fork_event, st));
     for (int grp = 0; grp < n_groups; ++grp) {
         const int f0 = (int)((long long)n_frames * grp / n_groups);
         const int f1 = (int)((long long)n_frames * (grp + 1) / n_groups);
@@ -2143,6 +2150,11 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         gb.out         = b.out + o * b.out_cap;
         gb.out_len     = b.out_len + o;
 
+        if (before_piece) {
+            if (hook_ms) TIMG_HIP_TRY(ctx, hipEventRecord(ctx->hook_event[2 * grp], gs));
+            TIMG_HIP_TRY(ctx, (*before_piece)(grp, f0, nfr, gs));
+            if (hook_ms) TIMG_HIP_TRY(ctx, hipEventRecord(ctx->hook_event[2 * grp + 1], gs));
+        }
         hipLaunchKernelGGL(HistKernel, dim3(nfr), dim3(kHistThreads), kHistLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
         if (first_hit) {
@@ -2176,6 +2188,15 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     if ((int)len_h[nf] != 0)
         return ctx->Fail(TIMG_HIP_ERR_DEVICE, "sixel diffusion: a workgroup gave up waiting for its neighbour");
+    if (hook_ms) {
+        *hook_ms = 0.0f;
+        for (int grp = 0; grp < n_groups && before_piece; ++grp) {
+            float ms = 0.0f;
+            if ((int)((long long)n_frames * (grp + 1) / n_groups) - (int)((long long)n_frames * grp / n_groups) <= 0) continue;
+            TIMG_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->hook_event[2 * grp], ctx->hook_event[2 * grp + 1]));
+            *hook_ms += ms;
+        }
+    }
     size_t worst = 0;
     for (int i = 0; i < n_frames; ++i) {
         out_len[i] = (size_t)len_h[i];
@@ -2185,4 +2206,14 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
         return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %zu bytes, out_cap is %zu", worst, out_cap);
     if (!out_on_device) return CopyFramesToHost(ctx, out, out_cap, dout, out_len, n_frames, st);
     return TIMG_HIP_OK;
+}
+}  // namespace timg_amd
+
+extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
+                                     int stride, size_t frame_stride, int fb_on_device,
+                                     int n_frames, int flags, const timg_hip_blend *pad_blend,
+                                     char *out, size_t out_cap, int out_on_device,
+                                     size_t *out_len, void *stream) {
+    return timg_amd::SixelEncodeImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, pad_blend, out,
+                                     out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr);
 }

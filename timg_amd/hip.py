@@ -104,6 +104,8 @@ def load_library():
     L.timg_hip_sixel_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
                                         c_int, POINTER(Blend), vp, c_size_t, c_int,
                                         POINTER(c_size_t), vp]
+    L.timg_hip_scale_sixel_encode.argtypes = [vp, vp, vp, c_int, c_size_t, vp, c_int, POINTER(Blend), c_int, vp, c_size_t,
+                                              c_int, POINTER(c_size_t), c_int, POINTER(ctypes.c_float), vp]
     L.timg_hip_png_bytes.argtypes = [c_int, c_int, c_int]
     L.timg_hip_png_bytes.restype = c_size_t
     L.timg_hip_gfx_max_bytes.argtypes = [c_int, c_int]
@@ -355,6 +357,18 @@ class TimgHip:
         if host_out:
             return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
         return list(lens)
+
+    def scale_sixel_encode(self, scaler: Scaler, src: int, scaled: int, n_frames: int, blend: Blend | None, out: int,
+                           out_cap: int, flags=0, pieces=0, stream=None, src_stride=0, src_frame_stride=0):
+        """timg_hip_scale_sixel_encode on device memory (src, scaled, out: device pointers).  Returns
+        (lengths, device ms of the scale kernels summed over the pieces)."""
+        lens = (c_size_t * n_frames)()
+        ms = ctypes.c_float(0.0)
+        self._check(self.L.timg_hip_scale_sixel_encode(
+            self.ctx, scaler.handle, c_void_p(int(src)), src_stride, src_frame_stride, c_void_p(int(scaled)), n_frames,
+            byref(blend) if blend is not None else None, flags, c_void_p(int(out)), out_cap, 1, lens, pieces, byref(ms),
+            c_void_p(stream) if stream else None))
+        return list(lens), float(ms.value)
 
     def sixel_max_bytes(self, w, h) -> int:
         return int(self.L.timg_hip_sixel_max_bytes(w, h))

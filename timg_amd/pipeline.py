@@ -17,8 +17,16 @@ class GridPipeline:
     """scale(+blend) -> canvas encode for a batch of equally sized frames."""
 
     def __init__(self, hip: TimgHip, n_frames: int, in_w: int, in_h: int, out_w: int, out_h: int,
-                 mode: str = "sixel", blend: Blend | None = None, device: str = "cuda"):
+                 mode: str = "sixel", blend: Blend | None = None, device: str = "cuda", pieces: int = 0):
+        """pieces (sixel only): 0 (library's choice: 1) or 1 = scale, then encode, as two calls; > 1 = ONE fused call
+        (timg_hip_scale_sixel_encode) that cuts the batch into pieces and runs a piece's scale beside the serial
+        stages of the pieces in front of it."""
         self.hip, self.n = hip, n_frames
+        if pieces == 0:  # (the library's own rule -- profiles/r3/fused_pieces.txt -- made explicit so that callers can report it)
+            pieces = 1
+        self.pieces = pieces if mode == "sixel" else 1
+        self.fused = mode == "sixel" and pieces != 1
+        self.last_scale_ms = None
         self.in_w, self.in_h, self.out_w, self.out_h = in_w, in_h, out_w, out_h
         self.mode = mode
         self.blend = blend
@@ -65,8 +73,13 @@ class GridPipeline:
         return lens
 
     def step(self, src: torch.Tensor):
-        self.scale(src)
-        return self.encode()
+        if not self.fused:
+            self.scale(src)
+            return self.encode()
+        self.lengths, self.last_scale_ms = self.hip.scale_sixel_encode(
+            self.scaler, src.data_ptr(), self.scaled.data_ptr(), self.n, self.blend, self.out.data_ptr(), self.cap,
+            pieces=self.pieces, stream=self.stream_ptr())
+        return self.lengths
 
     def packed_output(self):
         """(payload uint8 tensor, lengths int64 tensor): frames back to back, as a SNAPSHOT -- new
@@ -95,7 +108,7 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
     PACKED: the gather of step k (all-gather of lengths, payloads to the root) runs beside the
     kernels of step k + 1.
 
-    pipes: objects with scale(src), encode(), packed_output() (and .stream when record_event is
+    pipes: objects with scale(src), encode() (or, when `fused`, step(src)), packed_output() (and .stream when record_event is
     given); record_event(stream) -> event, used to bracket the two stages of each step."""
     import threading
     done = [threading.Event() for _ in range(n_steps)]
@@ -109,12 +122,16 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
                 if world > 1 and k >= n_pipes:
                     consumed[k - n_pipes].wait()
                 e0 = record_event(p.stream) if record_event else None
-                p.scale(src)
-                e1 = record_event(p.stream) if record_event else None
-                p.encode()
+                if getattr(p, "fused", False):  # one call; the library times its scale kernels itself
+                    p.step(src)
+                    e1 = None
+                else:
+                    p.scale(src)
+                    e1 = record_event(p.stream) if record_event else None
+                    p.encode()
                 e2 = record_event(p.stream) if record_event else None
                 if timed_events is not None and record_event:
-                    timed_events.append((e0, e1, e2))
+                    timed_events.append((e0, e1, e2, getattr(p, "last_scale_ms", None)))
                 done[k].set()
         except Exception as exc:  # surface worker failures instead of hanging the gather loop
             errors.append(exc)

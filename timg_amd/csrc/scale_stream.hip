@@ -518,8 +518,19 @@ struct RowRec {  // 48 bytes through the scalar cache per source row, from a poi
     float keep[kMSlots];  // 0 on the source row that STARTS an output row in the slot, else 1 (see the sums)
     RowCtl ctl;
 };
+// kOpaque: what the horizontal pass would compute in its alpha channel.  Every staged column of an all-opaque
+// tile carries the SAME alpha (the vertical weight sum of the row, a host constant), so the filtered alpha of
+// output column x is a function of (x, that constant) alone -- the host evaluates stb's even/odd chain for it
+// once per distinct constant and stores what the pixel needs of it: {1.0f / alpha, ToByte(alpha) << 24}.  The
+// kernel's tap loop then carries three channels, and the un-weighting has no divide.  RowCtl::flags bits 8..23
+// say which table row the completing output row uses.
+struct AlphaCell {
+    float inv;          // 1.0f / alpha  (IEEE divide, as EncodePx computes it)
+    uint32_t byte_hi;   // ToByte(alpha) << 24
+};
 struct MTables {
     const RowRec *rec;  // indexed like StreamTables::sched (BandInfo::sched + row - r0)
+    const AlphaCell *alpha_tab;  // [distinct vertical alpha sums][out_w]
 };
 
 // Horizontal pass of a completed row, every lane its own output column(s): weights as
@@ -599,6 +610,97 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
             if (need_straight && px.c[3] < TIMG_TINY_F32) *ok = false;
         }
         const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, blend, flag);
+        *reinterpret_cast<uint32_t *>(dst_row + (size_t)ox * 4) = out;
+    }
+}
+
+// one correctly rounded fp32 multiplication / addition as ONE instruction (never contracted, never regrouped)
+__device__ __forceinline__ float MulRn(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a float4 slot of LDS as ONE 16-byte read: the value passes through an (empty) asm as a whole register tuple, so
+// that the compiler cannot split the read by its uses (a ds_read_b96, or two 8-byte halves, cost the LDS twice
+// the cycles of a ds_read_b128)
+__device__ __forceinline__ f4v LdsSlot(const void *p) {
+    f4v v = *reinterpret_cast<const f4v *>(p);
+    asm("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float AddRn(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// The same pass for all-opaque tiles: three channels in the chains, alpha and its reciprocal from the host's
+// table (AlphaCell).  R G B go through exactly the arithmetic of HorizontalRowM -- tap k of the pair (k, k + 1)
+// feeds the even / odd chain, padded taps add v * 0 -- and are un-weighted by the multiplication EncodePx does.
+__device__ __forceinline__ void HorizontalRowOpaque(const DevPlan &plan, const DevBlend &blend, const FrameBatch &batch,
+                                                    const StripInfo &si, int f, const float *stage_row, const float *hw,
+                                                    const int *hbase, int hrow, int hgroups, int y,
+                                                    const AlphaCell *alpha_row, int *flag) {
+    const int n_out  = si.ox1 - si.ox0;
+    uint8_t *dst_row = batch.dst + (size_t)f * batch.dst_frame_stride + (size_t)y * batch.dst_stride;
+    for (int o = threadIdx.x; o < n_out; o += kThreads) {
+        const int ox       = si.ox0 + o;
+        const AlphaCell ac = alpha_row[ox];  // (requested first: the tap loop hides it)
+        // (staged columns and weight groups are float4 slots: said out loud, or the 16-byte reads are split)
+        const char *base   = reinterpret_cast<const char *>(
+            __builtin_assume_aligned(reinterpret_cast<const char *>(stage_row) + hbase[o], 16));
+        const float *wbase = reinterpret_cast<const float *>(__builtin_assume_aligned(hw + (size_t)o * 4, 16));
+        float even[3] = {0.0f, 0.0f, 0.0f}, odd[3] = {0.0f, 0.0f, 0.0f};
+        if (plan.h_sequential) {
+            for (int g = 0; g < hgroups; ++g) {
+                const f4v w4 = LdsSlot(wbase + (size_t)g * hrow * 4);
+                const float wk[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4v t = LdsSlot(base + (g * 4 + j) * 16);
+                    even[0] = even[0] + t.x * wk[j];
+                    even[1] = even[1] + t.y * wk[j];
+                    even[2] = AddRn(even[2], MulRn(t.z, wk[j]));
+                }
+            }
+        } else {
+            for (int g = 0; g < hgroups; ++g) {
+                const f4v w4 = LdsSlot(wbase + (size_t)g * hrow * 4);
+                const f4v t0 = LdsSlot(base + (g * 4 + 0) * 16);
+                const f4v t1 = LdsSlot(base + (g * 4 + 1) * 16);
+                const f4v t2 = LdsSlot(base + (g * 4 + 2) * 16);
+                const f4v t3 = LdsSlot(base + (g * 4 + 3) * 16);
+                // R and G as the packed pair the compiler forms; B through MulRn / AddRn (single instructions the
+                // vectoriser cannot regroup: left alone it pairs B of tap k with B of tap k + 2 and pays seven
+                // register moves per four taps for it).
+                even[0] = even[0] + t0.x * w4.x;
+                even[1] = even[1] + t0.y * w4.x;
+                even[2] = AddRn(even[2], MulRn(t0.z, w4.x));
+                odd[0]  = odd[0] + t1.x * w4.y;
+                odd[1]  = odd[1] + t1.y * w4.y;
+                odd[2]  = AddRn(odd[2], MulRn(t1.z, w4.y));
+                even[0] = even[0] + t2.x * w4.z;
+                even[1] = even[1] + t2.y * w4.z;
+                even[2] = AddRn(even[2], MulRn(t2.z, w4.z));
+                odd[0]  = odd[0] + t3.x * w4.w;
+                odd[1]  = odd[1] + t3.y * w4.w;
+                odd[2]  = AddRn(odd[2], MulRn(t3.z, w4.w));
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) even[ch] = even[ch] + odd[ch];
+        }
+        // EncodePx with alpha >= 2^-120 (the host made sure): c * (1.0f / alpha), quantised; alpha's byte from the table
+        uint32_t out = ToByte(even[0] * ac.inv) | (ToByte(even[1] * ac.inv) << 8) | (ToByte(even[2] * ac.inv) << 16) | ac.byte_hi;
+        if (plan.swap_rb) out = (out & 0xff00ff00u) | ((out & 0xffu) << 16) | ((out >> 16) & 0xffu);
+        if ((out >> 24) != 0xffu && y >= blend.start_row) {  // (as FinishStreamPixel)
+            if (flag) *flag = 1;
+            if (blend.enabled) {
+                const bool alt    = CheckerAlt(blend, ox, y);
+                const float bg[3] = {alt ? blend.pat[0] : blend.bg[0], alt ? blend.pat[1] : blend.bg[1],
+                                     alt ? blend.pat[2] : blend.bg[2]};
+                out = BlendOver(out, bg);
+            }
+        }
         *reinterpret_cast<uint32_t *>(dst_row + (size_t)ox * 4) = out;
     }
 }
@@ -744,7 +846,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
                        "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[1]))),
                        "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[2]))),
                        "s"(__builtin_amdgcn_readfirstlane(__float_as_int(rw.w[3]))));  // (uniform: folds away)
-        if (M == kOpaque) amin = min(min(amin, min(q.x, q.y)), min(q.z, q.w));
+        if (M == kOpaque) amin = min(min(min(min(amin, q.x), q.y), q.z), q.w);  // (a chain: two v_min3_u32)
         // (fully transparent pixels announce filtered alphas of zero: see RunTile)
         if (M == kPremult && need_straight)
             ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
@@ -899,7 +1001,11 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         BlockSync();
         if (fail) return false;
 #if !defined(TIMG_MABL) || TIMG_MABL < 1
-        HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
+        if (M == kOpaque)
+            HorizontalRowOpaque(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y,
+                                mt.alpha_tab + (size_t)((ctl.flags >> 8) & 0xffff) * plan.out_w, flag);
+        else
+            HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
 #endif
         if (kStageM == 1) BlockSync();  // the single staging row is free again
         ++ev;
@@ -1246,6 +1352,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     std::vector<RowSched> sched;
     std::vector<RowW> wrows;    // matrix-slot schedule, indexed like sched
     std::vector<RowCtl> crows;
+    std::vector<uint32_t> alpha_vals;  // distinct vertical alpha sums (bit patterns), in order of first use
     std::vector<float> keeps;  // [row][kMSlots]
     bool m_ok = p.vertical_first, uses_ovf = false;
     for (int oy = 0; oy < p.out_h; oy += band_rows) {
@@ -1354,6 +1461,15 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
                     ce.flags |= (k + 1) << 4;
                     ce.done_y    = y;
                     ce.alpha_sum = alpha;
+                    {   // which row of the opaque set's alpha table (AlphaCell) this output row uses
+                        uint32_t bits;
+                        memcpy(&bits, &alpha, 4);
+                        size_t at = 0;
+                        while (at < alpha_vals.size() && alpha_vals[at] != bits) ++at;
+                        if (at == alpha_vals.size()) alpha_vals.push_back(bits);
+                        if (at > 0xffff) m_ok = false;
+                        ce.flags |= (int)(at & 0xffff) << 8;
+                    }
                     slot_y[k]    = -1;
                     if (k < kMSlots && slot_y[kMSlots] >= 0) {
                         ce.flags |= 0x80;
@@ -1391,12 +1507,47 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
         for (int k = 0; k < kMSlots; ++k) recs[i].keep[k] = keeps[i * kMSlots + k];
     }
     const size_t o_recs   = align(o_sched + sched.size() * sizeof(RowSched));
-    const size_t total    = align(o_recs + recs.size() * sizeof(RowRec));
+    // The opaque set's alpha table: per distinct vertical alpha sum and output column, stb's horizontal chain of
+    // HorizontalRowM evaluated on a row whose every column holds that sum -- even taps into one chain, odd taps
+    // into the other (padded taps add v * 0: nothing), their sum at the end; one chain for <= 3 taps.
+    std::vector<AlphaCell> atab;
+    if (m_ok && alpha_vals.size() * (size_t)p.out_w * sizeof(AlphaCell) > ((size_t)32 << 20)) m_ok = false;
+    if (m_ok) {
+        atab.resize(alpha_vals.size() * (size_t)p.out_w);
+        for (size_t d = 0; d < alpha_vals.size() && m_ok; ++d) {
+            float a;
+            memcpy(&a, &alpha_vals[d], 4);
+            for (int x = 0; x < p.out_w; ++x) {
+                const float *hc = &p.h_coeff[(size_t)x * p.h_width];
+                const int n     = std::min((int)p.h_taps[x].count, p.h_width);
+                float even = 0.0f, odd = 0.0f;
+                for (int k = 0; k < n; ++k) {
+                    const float prod = a * hc[k];
+                    if (p.h_sequential || !(k & 1)) even = even + prod;
+                    else odd = odd + prod;
+                }
+                const float alpha_h = p.h_sequential ? even : even + odd;
+                if (!(alpha_h >= TIMG_TINY_F32)) {  // (the kernel's table path assumes stb's "alpha present" branch)
+                    m_ok = false;
+                    break;
+                }
+                AlphaCell c;
+                c.inv     = 1.0f / alpha_h;
+                float q   = alpha_h * 255.0f + 0.5f;
+                q         = q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q);
+                c.byte_hi = (uint32_t)q << 24;
+                atab[d * (size_t)p.out_w + x] = c;
+            }
+        }
+    }
+    const size_t o_atab   = align(o_recs + recs.size() * sizeof(RowRec));
+    const size_t total    = align(o_atab + atab.size() * sizeof(AlphaCell) + 16);
     std::vector<char> host(total, 0);
     memcpy(&host[o_strips], strips.data(), strips.size() * sizeof(StripInfo));
     memcpy(&host[o_bands], bands.data(), bands.size() * sizeof(BandInfo));
     memcpy(&host[o_sched], sched.data(), sched.size() * sizeof(RowSched));
     memcpy(&host[o_recs], recs.data(), recs.size() * sizeof(RowRec));
+    if (!atab.empty()) memcpy(&host[o_atab], atab.data(), atab.size() * sizeof(AlphaCell));
     void *dev = nullptr;
     if (DevMalloc(&dev, total) != hipSuccess) return false;
     if (hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1410,6 +1561,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     out->t.n_strips = (int)strips.size();
     out->t.n_bands  = (int)bands.size();
     out->m.rec      = (const RowRec *)((char *)dev + o_recs);
+    out->m.alpha_tab = (const AlphaCell *)((char *)dev + o_atab);
     out->m_ok       = m_ok && wrows.size() == sched.size();
     out->m_ovf      = uses_ovf;
     out->band_rows  = band_rows;

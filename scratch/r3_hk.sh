@@ -1,0 +1,5 @@
+#!/bin/bash
+TIMG_SKIP_CANARY=1 timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q -p no:cacheprovider -k "scale or horizontal or streaming or random or golden or config or full_size or width or triangle or bgra" 2>&1 | tail -3
+for kind in photo alpha; do N=32 SW=7680 SH=4320 KIND=$kind timeout 200 python3 scratch/bench_scale.py 2>&1 | grep "^kernel"; done
+N=64 SW=640 SH=480 DW=67 DH=50 KIND=alpha timeout 100 python3 scratch/bench_scale.py 2>&1 | grep "^kernel"
+N=64 KIND=photo timeout 100 python3 scratch/bench_scale.py 2>&1 | grep "^kernel"

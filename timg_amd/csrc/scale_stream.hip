@@ -913,12 +913,19 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
                 for (int ch = 0; ch < kCh; ++ch) {
                     const f2v lo = {prod[b][ch].x, prod[b][ch].y}, hi = {prod[b][ch].z, prod[b][ch].w};
                     float *a      = acc[p0 + b][ch];
+#ifdef TIMG_M_PLAINFMA  // (experiment: the sums as four v_fma_f32 instead of two v_pk_fma_f32)
+                    a[0] = __builtin_fmaf(a[0], keep_lo.x, lo.x);
+                    a[1] = __builtin_fmaf(a[1], keep_lo.y, lo.y);
+                    a[2] = __builtin_fmaf(a[2], keep_hi.x, hi.x);
+                    a[3] = __builtin_fmaf(a[3], keep_hi.y, hi.y);
+#else
                     const f2v n01 = __builtin_elementwise_fma(f2v{a[0], a[1]}, keep_lo, lo);
                     const f2v n23 = __builtin_elementwise_fma(f2v{a[2], a[3]}, keep_hi, hi);
                     a[0] = n01.x;
                     a[1] = n01.y;
                     a[2] = n23.x;
                     a[3] = n23.y;
+#endif
                 }
             if (kOvf && (ctl.flags & 1)) {  // wave-uniform: the overflow row
 #pragma unroll
@@ -1109,10 +1116,20 @@ __device__ __forceinline__ float FromPartner(float v) {
 // weights in registers.
 // (three waves per SIMD for the opaque and the premultiplied set: the opaque one came out at 170 registers --
 // two over the budget of three waves -- and ran at two; the 40-tap instantiations spill at 168 and stay at two)
-template <int M, int TAPS>
+// LOADS: 16-byte loads per lane and source row -- 2 for windows of up to 512 source columns (8K -> 800: 350), 4 up to
+// kWinMaxH.  The raw rows travel through a register ring filled by inline assembly with hand-placed waits, as in the
+// matrix kernel above and for the same reason, only worse: written as C++ (a conditional 16-byte load per chunk) every
+// load came out behind an s_waitcnt vmcnt(0) -- no row was ever in flight while another was processed, a wave paid
+// the whole memory round trip twice per source row (8K -> 800x450: 3.3 us per row and wave, 130 us per frame, 13 % of
+// the bus).  Now every lane issues its LOADS loads unconditionally (a chunk outside the strip's window re-reads the
+// window's last chunk: same cache line, no extra traffic; only the DECODE is predicated), kDepthH rows ahead, and a
+// row is released by s_waitcnt vmcnt((kDepthH - 1) * LOADS): loads return in order.  check_ring_isa.py proves on the
+// generated code that nothing touches a register set between its load and its wait.
+template <int M, int TAPS, int LOADS>
 __global__ void __launch_bounds__(kThreadsH) __attribute__((amdgpu_waves_per_eu((M == kFull || TAPS > 20) ? 2 : 3, (M == kFull || TAPS > 20) ? 2 : 3)))
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
                    int gen, int win, int w4) {
+    static_assert(LOADS == 2 || LOADS == 4, "two or four 16-byte loads per lane and row");
     // One row buffer of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at
     // index n >> 2.  The decoder's lanes hold 4 consecutive pixels each, so plane q is written
     // by consecutive lanes at consecutive 16-byte slots (no bank conflicts; a linear layout
@@ -1159,23 +1176,31 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     // raw source rows: lane t owns the 4-pixel chunks t, t + 256, ... of the window
     const uint8_t *frame = batch.src + (size_t)f * batch.src_frame_stride;
     const int r_last     = min(bi.r1, plan.in_h - 1);
-    uint32_t chunk_off[kLoadsH];
-    bool chunk_in[kLoadsH];
-    int chunk_shift[kLoadsH];  // a chunk straddling the end of the row: see the vertical-first kernel
+    const uint8_t *chunk_ptr[LOADS];  // this lane's chunks in row 0 of the frame
+    bool chunk_in[LOADS];
+    int chunk_shift[LOADS];  // a chunk straddling the end of the row: see the vertical-first kernel
 #pragma unroll
-    for (int j = 0; j < kLoadsH; ++j) {
+    for (int j = 0; j < LOADS; ++j) {
         const int c    = tid + j * kThreadsH;  // chunk index inside the window
         const int col  = si.cx0 + 4 * c;
         chunk_in[j]    = 4 * c < win;
-        chunk_off[j]   = (uint32_t)min(col, plan.in_w - 4) * 4u;
+        // (outside the window: the window's last chunk -- a cache line the wave reads anyway)
+        chunk_ptr[j]   = frame + (size_t)min(min(col, si.cx0 + win - 4), plan.in_w - 4) * 4u;
         chunk_shift[j] = (col < plan.in_w && col + 4 > plan.in_w) ? col + 4 - plan.in_w : 0;
     }
-    auto load_row = [&](int r, uint4 raw[kLoadsH]) {
-        const uint8_t *row = frame + (size_t)min(r, r_last) * batch.src_stride;  // uniform
-#pragma unroll
-        for (int j = 0; j < kLoadsH; ++j)
-            if (chunk_in[j]) raw[j] = *reinterpret_cast<const uint4 *>(row + chunk_off[j]);
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    // rows are fetched in order through a byte offset that just advances (rows past the image's last one --
+    // virtual rows of the schedule -- re-read the last row); 64-bit: 8K frames with padded strides pass 4 GB... never,
+    // but nothing here depends on it
+    size_t next_off       = (size_t)min(bi.r0, r_last) * batch.src_stride;
+    const size_t last_off = (size_t)r_last * batch.src_stride;
+    // (the register sets are named variables handed over one by one, never arrays: an array of ring registers is an
+    // object the compiler copies around -- check_ring_isa.py caught exactly such copies behind the first loads)
+    auto issue_one = [&](u4v &q, int j) __attribute__((always_inline)) {
+        const uint8_t *p = chunk_ptr[j] + next_off;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q) : "v"(p) : "memory");
     };
+    auto advance_row = [&]() __attribute__((always_inline)) { next_off = min(next_off + batch.src_stride, last_off); };  // uniform
 
     // vertical sums of this lane's channels: gather channels par * kVc ... (kFull: 0-3 / 4-6)
     float acc[kSlots][kVc];
@@ -1187,14 +1212,16 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
 
     RowSched rs_next = LoadConstant(sched);
     // one source row: decode -> LDS, barrier, gather, vertical update
-    auto row_step = [&](const uint4 raw[kLoadsH], int r) __attribute__((always_inline)) -> bool {
+    const RowSched *sched_ptr = sched;
+    auto row_step = [&](const uint4 &r0, const uint4 &r1, const uint4 &r2, const uint4 &r3) __attribute__((always_inline)) -> bool {
+        const uint4 raw[4] = {r0, r1, r2, r3};
         const RowSched rs = rs_next;
         asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));
         __builtin_amdgcn_sched_barrier(0);
-        rs_next = LoadConstant(sched + (r + 1 - bi.r0));
+        rs_next = LoadConstant(++sched_ptr);
         float *buf = lds;
 #pragma unroll
-        for (int j = 0; j < kLoadsH; ++j) {
+        for (int j = 0; j < LOADS; ++j) {
             if (!chunk_in[j]) continue;
             uint4 q = raw[j];
             if (chunk_shift[j]) {
@@ -1299,20 +1326,65 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         return true;
     };
 
-    uint4 ra[kLoadsH], rb[kLoadsH];
-    load_row(bi.r0, ra);
-    load_row(bi.r0 + 1, rb);
-    bool good = true;
-    for (int r = bi.r0; r <= bi.r1 && good; r += 2) {
-        good = row_step(ra, r);
-        if (!good) break;
-        load_row(r + 2, ra);
-        if (r + 1 > bi.r1) break;
-        good = row_step(rb, r + 1);
-        if (!good) break;
-        load_row(r + 3, rb);
+    // kDepthH rows in flight per lane (register sets named, not rotated: see the matrix kernel)
+    constexpr int kDepthH = LOADS == 2 ? 4 : 2;
+    const u4v z4 = {0, 0, 0, 0};
+    // set k = (qka, qkb) for LOADS == 2, sets 0..3; (qka, qkb, qkc, qkd) for LOADS == 4, sets 0..1
+    u4v q0a, q0b, q1a, q1b, q2a = z4, q2b = z4, q3a = z4, q3b = z4, q0c = z4, q0d = z4, q1c = z4, q1d = z4;
+    u4v q2c = z4, q2d = z4, q3c = z4, q3d = z4;  // (named by the macros' discarded branches only)
+#define TIMG_H_ISSUE(K)                                   \
+    issue_one(q##K##a, 0);                                \
+    issue_one(q##K##b, 1);                                \
+    if constexpr (LOADS == 4) {                           \
+        issue_one(q##K##c, 2);                            \
+        issue_one(q##K##d, 3);                            \
+    }                                                     \
+    advance_row();
+#define TIMG_H_STEP(K)                                                                                                   \
+    if (left < K + 1) break;                                                                                             \
+    if constexpr (LOADS == 2)                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%2) ; ring %0 %1" : "+v"(q##K##a), "+v"(q##K##b) : "n"((kDepthH - 1) * LOADS) : "memory"); \
+    else                                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(%4) ; ring %0 %1 %2 %3"                                                            \
+                     : "+v"(q##K##a), "+v"(q##K##b), "+v"(q##K##c), "+v"(q##K##d)                                        \
+                     : "n"((kDepthH - 1) * LOADS)                                                                        \
+                     : "memory");                                                                                        \
+    if (!row_step(make_uint4(q##K##a.x, q##K##a.y, q##K##a.z, q##K##a.w), make_uint4(q##K##b.x, q##K##b.y, q##K##b.z, q##K##b.w), \
+                  make_uint4(q##K##c.x, q##K##c.y, q##K##c.z, q##K##c.w), make_uint4(q##K##d.x, q##K##d.y, q##K##d.z, q##K##d.w))) \
+        return;                                                                                                          \
+    TIMG_H_ISSUE(K)
+    TIMG_H_ISSUE(0)
+    TIMG_H_ISSUE(1)
+    if constexpr (kDepthH == 4) {
+        TIMG_H_ISSUE(2)
+        TIMG_H_ISSUE(3)
     }
-    if (!good) return;
+    for (int left = bi.r1 - bi.r0 + 1; left > 0; left -= kDepthH) {  // (rows still to do)
+        TIMG_H_STEP(0)
+        TIMG_H_STEP(1)
+        if constexpr (kDepthH == 4) {
+            // (sets 2 and 3 exist for LOADS == 2 only: their c / d halves are the zero constants)
+            if (left < 3) break;
+            asm volatile("s_waitcnt vmcnt(%2) ; ring %0 %1" : "+v"(q2a), "+v"(q2b) : "n"((kDepthH - 1) * LOADS) : "memory");
+            if (!row_step(make_uint4(q2a.x, q2a.y, q2a.z, q2a.w), make_uint4(q2b.x, q2b.y, q2b.z, q2b.w), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0))) return;
+            issue_one(q2a, 0);
+            issue_one(q2b, 1);
+            advance_row();
+            if (left < 4) break;
+            asm volatile("s_waitcnt vmcnt(%2) ; ring %0 %1" : "+v"(q3a), "+v"(q3b) : "n"((kDepthH - 1) * LOADS) : "memory");
+            if (!row_step(make_uint4(q3a.x, q3a.y, q3a.z, q3a.w), make_uint4(q3b.x, q3b.y, q3b.z, q3b.w), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0))) return;
+            issue_one(q3a, 0);
+            issue_one(q3b, 1);
+            advance_row();
+        }
+    }
+    // (loads still in flight must land before their registers mean anything else)
+    asm volatile("s_waitcnt vmcnt(0) ; ring all"
+                 : "+v"(q0a), "+v"(q0b), "+v"(q1a), "+v"(q1b), "+v"(q2a), "+v"(q2b), "+v"(q3a), "+v"(q3b), "+v"(q0c), "+v"(q0d), "+v"(q1c), "+v"(q1d)
+                 :
+                 : "memory");
+#undef TIMG_H_STEP
+#undef TIMG_H_ISSUE
     if (M != kFull && __any(!ok)) return;
     if (tid == 0) tile_state[tile] = gen;
 }
@@ -1748,9 +1820,9 @@ static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss
                    : LaunchModeMO<M, false>(s, ss, v, blend, batch, stream);
 }
 
-template <int M, int TAPS>
-static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
-                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+template <int M, int TAPS, int LOADS>
+static hipError_t LaunchModeHTL(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                                const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
     // pixels per plane: a quarter of (window + padded taps), rounded up to 4 mod 16
     int w4 = (ss->hwin + 2 * TAPS + 3) / 4 + 1;
     while ((w4 & 15) != 4) ++w4;
@@ -1759,13 +1831,21 @@ static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *s
     static std::once_flag attr_once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(attr_once, []() {
-        attr_err = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_err = hipFuncSetAttribute((const void *)ScaleStreamHKernel<M, TAPS, LOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     });
     if (attr_err != hipSuccess) return attr_err;
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
-    hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
+    hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS, LOADS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
                        batch, ss->tile_state[ss->slot], ss->gen[ss->slot], ss->hwin, w4);
     return hipGetLastError();
+}
+
+template <int M, int TAPS>
+static hipError_t LaunchModeHT(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    // windows of up to 512 source columns need two 16-byte loads per lane and row (and keep four rows in flight)
+    return ss->hwin <= 2 * 4 * kThreadsH ? LaunchModeHTL<M, TAPS, 2>(s, ss, v, blend, batch, stream)
+                                         : LaunchModeHTL<M, TAPS, 4>(s, ss, v, blend, batch, stream);
 }
 
 template <int M>

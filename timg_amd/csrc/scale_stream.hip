@@ -54,6 +54,8 @@ constexpr int kStripCols = kPix * kThreads;
 constexpr int kPrefetch  = 4;    // source rows in flight per lane
 constexpr int kLdsCoeffFloats = 12 * 1024;  // horizontal weights kept in LDS up to this many
 
+__device__ __forceinline__ uint32_t MinU32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 struct StripInfo {
     int ox0, ox1;  // output columns [ox0, ox1)
     int cx0;       // first source column held in LDS (multiple of kPix)
@@ -337,7 +339,7 @@ __device__ bool RunTile(const TileCtx &c) {
         // Fully transparent pixels announce filtered alphas of (or below) zero, which
         // need the straight RGB sums: give the tile to the full channel set right away
         // instead of discovering it output pixel by output pixel.
-        if (M == kPremult) ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
+        if (M == kPremult) ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
         float d[kPix][kCh];
         DecodeMode<M>(q.x, d[0]);
         DecodeMode<M>(q.y, d[1]);
@@ -849,7 +851,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         if (M == kOpaque) amin = min(min(min(min(amin, q.x), q.y), q.z), q.w);  // (a chain: two v_min3_u32)
         // (fully transparent pixels announce filtered alphas of zero: see RunTile)
         if (M == kPremult && need_straight)
-            ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
+            ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
 #if defined(TIMG_MABL) && TIMG_MABL == 3
         return true;  // (ablation: the loads and the alpha minimum alone)
 #endif
@@ -1092,7 +1094,6 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 constexpr int kColsH    = 32;    // output columns per workgroup = ONE WAVE
 constexpr int kThreadsH = 64;    // ... two lanes per column: stb's even and odd tap chains
 constexpr int kWinMaxH  = 1024;  // source columns of a strip's window (multiple of 4)
-constexpr int kLoadsH   = (kWinMaxH / 4 + kThreadsH - 1) / kThreadsH;  // 16-byte loads per lane per row
 
 // One float4 per pixel in the row buffer: kOpaque (R, G, B, 1), kPremult (A, RA, GA, BA),
 // kFull (R, G, B, A) -- its weighted channels RA GA BA are formed while gathering, by the
@@ -1231,7 +1232,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
             }
             if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
             if (M == kPremult)
-                ok = ok && (q.x >> 24) != 0 && (q.y >> 24) != 0 && (q.z >> 24) != 0 && (q.w >> 24) != 0;
+                ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
             float *dst = buf + (size_t)(tid + j * kThreadsH) * kStride;  // index (chunk) in plane 0
             DecodeToLds<M>(q.x, dst);
             DecodeToLds<M>(q.y, dst + (size_t)w4 * kStride);

@@ -10,8 +10,15 @@ namespace timg {
 
 constexpr std::chrono::milliseconds HeldRows::kIdle;
 
-HeldRows::HeldRows(timg_hip_ctx *ctx, std::function<void(HeldBatch &)> encode)
-    : ctx_(ctx), encode_(std::move(encode)), worker_(&HeldRows::Work, this) {}
+HeldRows::HeldRows(timg_hip_ctx *ctx, std::function<void(HeldBatch &, timg_hip_ctx *)> encode, int workers)
+    : ctx_(ctx), encode_(std::move(encode)) {
+    workers_.emplace_back(&HeldRows::Work, this, ctx_);
+    for (int k = 1; k < workers; ++k) {
+        timg_hip_ctx *c = ExtraHipContext(k);  // process-wide: its scratch and code objects stay warm between canvases
+        if (!c) break;                         // (fewer workers: still correct)
+        workers_.emplace_back(&HeldRows::Work, this, c);
+    }
+}
 
 void HeldRows::SealLocked() {
     sealed_.push_back(std::move(open_));
@@ -30,7 +37,7 @@ HeldRows::~HeldRows() {
         exiting_ = true;
     }
     wake_.notify_all();
-    worker_.join();  // (the worker empties sealed_ before it leaves)
+    for (auto &w : workers_) w.join();  // (the workers empty sealed_ before they leave)
 }
 
 int HeldRows::HoldLimit(int grid_columns, size_t sequencer_queue_len) {
@@ -88,10 +95,10 @@ void HeldRows::Seal() {
 void HeldRows::Drain() {
     Seal();
     std::unique_lock<std::mutex> l(mu_);
-    idle_.wait(l, [this]() { return sealed_.empty() && !busy_; });
+    idle_.wait(l, [this]() { return sealed_.empty() && busy_ == 0; });
 }
 
-void HeldRows::Work() {
+void HeldRows::Work(timg_hip_ctx *worker_ctx) {
     std::unique_lock<std::mutex> l(mu_);
     for (;;) {
         if (sealed_.empty()) {
@@ -110,13 +117,20 @@ void HeldRows::Work() {
         }
         HeldBatch batch = std::move(sealed_.front());
         sealed_.pop_front();
-        busy_ = true;
+        ++busy_;
         l.unlock();
-        encode_(batch);
-        if (batch.dev_pixels) HipPoolFree(ctx_, batch.dev_pixels);
+        // device frames were gathered with copies on the SHARED context's stream (Hold): they have to have
+        // landed before another context's stream reads them
+        if (batch.on_device && worker_ctx != ctx_ && timg_hip_sync(ctx_, nullptr) != TIMG_HIP_OK) abort();
+        encode_(batch, worker_ctx);
+        if (batch.dev_pixels) {
+            // (the pool hands the block out again at once: this worker's stream must be done with it)
+            if (worker_ctx != ctx_) (void)timg_hip_sync(worker_ctx, nullptr);
+            HipPoolFree(ctx_, batch.dev_pixels);
+        }
         l.lock();
-        busy_ = false;
-        if (sealed_.empty()) idle_.notify_all();
+        --busy_;
+        if (sealed_.empty() && busy_ == 0) idle_.notify_all();
     }
 }
 

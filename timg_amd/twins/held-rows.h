@@ -62,9 +62,13 @@ struct HeldBatch {
 
 class HeldRows {
 public:
-    // encode: runs on the worker thread; must fulfil every promise of the batch.
-    HeldRows(timg_hip_ctx *ctx, std::function<void(HeldBatch &)> encode);
-    ~HeldRows();  // encodes what is held, then joins the worker
+    // encode(batch, ctx): runs on a worker thread; must fulfil every promise of the batch with device calls on `ctx`.
+    // workers > 1 (canvases without state between frames: sixel): that many batches are encoded at the same time,
+    // each worker on a context of its own (own stream and scratch) -- the per-frame serial stages of one batch run
+    // beside the wide kernels of another, which is where a batched encoder leaves most of the chip idle.  The
+    // futures may be fulfilled in any order: the sequencer takes them in Send order.
+    HeldRows(timg_hip_ctx *ctx, std::function<void(HeldBatch &, timg_hip_ctx *)> encode, int workers = 1);
+    ~HeldRows();  // encodes what is held, then joins the workers
 
     // Largest number of Sends one device call may cover.
     static int HoldLimit(int grid_columns, size_t sequencer_queue_len);
@@ -79,20 +83,20 @@ public:
 
 private:
     static constexpr std::chrono::milliseconds kIdle{3};
-    void Work();
+    void Work(timg_hip_ctx *worker_ctx);
 
     void SealLocked();
     timg_hip_ctx *const ctx_;
-    const std::function<void(HeldBatch &)> encode_;
+    const std::function<void(HeldBatch &, timg_hip_ctx *)> encode_;
     std::mutex mu_;
     std::condition_variable wake_, idle_;
     std::deque<HeldBatch> sealed_;
     HeldBatch open_;
     bool have_open_ = false;
     std::chrono::steady_clock::time_point deadline_;
-    bool busy_    = false;
+    int busy_     = 0;  // batches being encoded
     bool exiting_ = false;
-    std::thread worker_;
+    std::vector<std::thread> workers_;
 };
 
 }  // namespace timg

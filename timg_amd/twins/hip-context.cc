@@ -26,6 +26,20 @@ timg_hip_ctx *SharedHipContext() {
     return ctx;
 }
 
+timg_hip_ctx *ExtraHipContext(int k) {
+    static std::mutex mu;
+    static std::vector<timg_hip_ctx *> extra;
+    if (k < 1 || !SharedHipContext()) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    while ((int)extra.size() < k) {
+        const char *d     = getenv("TIMG_HIP_DEVICE");
+        timg_hip_ctx *ctx = nullptr;
+        if (timg_hip_init(d ? atoi(d) : 0, &ctx) != TIMG_HIP_OK) return nullptr;
+        extra.push_back(ctx);
+    }
+    return extra[k - 1];
+}
+
 int HipScalerFilter() {
     static const int filter = []() {
         const char *v = getenv("TIMG_HIP_FILTER");

@@ -15,6 +15,10 @@ namespace timg {
 // "factory returns null, next one is tried" convention the reference uses
 // (src/image-source.cc:162-221, src/stb-image-source.cc:54-56).
 timg_hip_ctx *SharedHipContext();
+// Further process-wide contexts on the same device (k = 1, 2, ...: own stream, own scratch), created on first
+// use and kept: encoders that run several batches at the same time (held-rows.h) put each on one of them.
+// nullptr when it cannot be created (callers then make do with fewer).
+timg_hip_ctx *ExtraHipContext(int k);
 
 // GPU selection: TIMG_HIP_DEVICE=<n> (default 0), TIMG_HIP=0 disables.
 bool HipTwinsEnabled();

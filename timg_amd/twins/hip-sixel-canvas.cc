@@ -63,14 +63,14 @@ HipSixelCanvas::~HipSixelCanvas() {
 void HipSixelCanvas::SetGridColumns(int columns) {
     Flush();
     hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
-    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
+    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *c) { EncodeBatch(b, c); }, kEncodeWorkers));
 }
 
 void HipSixelCanvas::SetStreamHold(int frames) {
     Flush();
     const int by_queue = (int)write_sequencer_->max_queue_len();  // the writer's future + a full queue behind it
     stream_hold_       = std::max(1, std::min(frames, by_queue));
-    if (stream_hold_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
+    if (stream_hold_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *c) { EncodeBatch(b, c); }, kEncodeWorkers));
 }
 
 void HipSixelCanvas::Flush() {
@@ -78,7 +78,7 @@ void HipSixelCanvas::Flush() {
 }
 
 // A held-back row: one batched encode, every future of the row fulfilled (worker thread).
-void HipSixelCanvas::EncodeBatch(HeldBatch &batch) {
+void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     const size_t n    = batch.frames.size();
     const size_t slot = timg_hip_sixel_max_bytes(batch.w, batch.h) * 2;
     // (uninitialised on purpose: a std::vector would zero 3.6 MB per frame; only the bytes a frame produced are touched)
@@ -87,9 +87,9 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch) {
     const int flags = EncodeFlags();
     static const bool trace = getenv("TIMG_HIP_TWIN_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    if (timg_hip_sixel_encode(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
+    if (timg_hip_sixel_encode(ctx, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
                               bytes.get(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
-        HipFatal(ctx_, "timg_hip_sixel_encode");
+        HipFatal(ctx, "timg_hip_sixel_encode");
     const auto t1 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; ++i) {
         HeldFrame &f = batch.frames[i];

@@ -52,7 +52,10 @@ public:
     void Flush();
 
 private:
-    void EncodeBatch(HeldBatch &batch);
+    void EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx);
+    // held batches encoded at the same time, each on a context of its own (held-rows.h): a sixel batch keeps one CU
+    // per frame busy for most of its 1.1 ms
+    static constexpr int kEncodeWorkers = 3;
 
     const DisplayOptions &options_;
     const bool full_cell_jump_;

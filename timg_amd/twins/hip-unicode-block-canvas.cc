@@ -33,7 +33,7 @@ HipUnicodeBlockCanvas::~HipUnicodeBlockCanvas() {
 void HipUnicodeBlockCanvas::SetGridColumns(int columns) {
     Flush();
     hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
-    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b) { EncodeBatch(b); }));
+    if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *) { EncodeBatch(b); }));  // (one worker: the canvas has state)
 }
 
 void HipUnicodeBlockCanvas::Flush() {

@@ -91,7 +91,8 @@ def test_built_library_passes():
         pytest.skip("no kept assembly (library built elsewhere)")
     r = subprocess.run([sys.executable, CHECK, BUILT], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "4 kernels" in r.stdout
+    # 4 instantiations of the matrix kernel + 18 of the horizontal-first kernel (3 channel sets x 3 tap counts x 2 load widths)
+    assert "22 kernels" in r.stdout
     # the sixel diffusion keeps eight source pixels in flight the same way (two instantiations)
     sixel = BUILT.replace("scale_stream", "sixel_canvas")
     r = subprocess.run([sys.executable, CHECK, sixel], capture_output=True, text=True)

@@ -418,7 +418,10 @@ def test_full_size_4k_frames(hip, oracle, kind, dw, dh):
 
 @pytest.mark.parametrize("kind", ["photo", "alpha", "noise"])
 @pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 67, 50), (1000, 1000, 100, 100), (2048, 1536, 200, 150),
-                                         (1600, 1200, 133, 100)])
+                                         (1600, 1200, 133, 100),
+                                         # strips whose source window is wider than 512 columns: four 16-byte loads
+                                         # per lane and row, two rows in flight (the LOADS = 4 instantiations)
+                                         (4096, 300, 256, 150), (4608, 240, 256, 120), (5120, 128, 280, 64)])
 def test_horizontal_first_streaming_kernel(hip, oracle, kind, sw, sh, dw, dh):
     """Plans for which stb resamples horizontally first (BASELINE configs 1 and 5 are of that
     kind) have their own streaming kernel: every channel set (opaque / premultiplied / full)

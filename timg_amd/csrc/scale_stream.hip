@@ -718,7 +718,11 @@ __device__ __forceinline__ void HorizontalRowOpaque(const DevPlan &plan, const D
 // runs two per CU: a spilled kernel is not just slower here, the compiler spilled ring registers whose
 // loads were still in flight (see issue_next_row; check_ring_isa.py caught it).
 template <int M, bool kOvf> struct MKernelShape {
-    static constexpr int kWaves = (M == kOpaque && !kOvf) ? 4 : (M == kPremult && kOvf) ? 2 : 3;  // per SIMD = workgroups per CU
+    // (per SIMD = workgroups per CU)  Both sets without the overflow row run four: the opaque one needs 113 registers; the
+    // premultiplied one fits 125 with THREE source rows in flight instead of four (at four it needs 129 and spilled ring
+    // registers behind their loads: check_ring_isa.py refused it) -- 0.893 -> 0.868 ms per 64 S-alpha frames.
+    static constexpr int kWaves = !kOvf ? 4 : (M == kPremult) ? 2 : 3;
+    static constexpr int kDepth = (M == kPremult && !kOvf) ? 3 : 4;  // source rows in flight per lane
     static constexpr int kStage = kWaves == 4 ? 1 : 2;              // staging rows
 };
 template <int M, bool kOvf>
@@ -1030,14 +1034,14 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #ifdef TIMG_M_DEPTH
     constexpr int kDepth = TIMG_M_DEPTH;
 #else
-    constexpr int kDepth = 4;
+    constexpr int kDepth = MKernelShape<M, kOvf>::kDepth;
 #endif
-    static_assert(kDepth == 4 || kDepth == 8, "ring written out for 4 or 8 rows");
-    u4v q0, q1, q2, q3, q4 = {0, 0, 0, 0}, q5 = q4, q6 = q4, q7 = q4;
+    static_assert(kDepth == 3 || kDepth == 4 || kDepth == 8, "ring written out for 3, 4 or 8 rows");
+    u4v q0, q1, q2, q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = q4, q6 = q4, q7 = q4;
     issue_next_row(q0);
     issue_next_row(q1);
     issue_next_row(q2);
-    issue_next_row(q3);
+    if (kDepth >= 4) issue_next_row(q3);
     if (kDepth == 8) {
         issue_next_row(q4);
         issue_next_row(q5);
@@ -1053,7 +1057,9 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         TIMG_M_STEP(q0, 0)
         TIMG_M_STEP(q1, 1)
         TIMG_M_STEP(q2, 2)
-        TIMG_M_STEP(q3, 3)
+        if (kDepth >= 4) {
+            TIMG_M_STEP(q3, 3)
+        }
         if (kDepth == 8) {
             TIMG_M_STEP(q4, 4)
             TIMG_M_STEP(q5, 5)

@@ -24,11 +24,14 @@ emission -- the only exchange step the path has.  Prints ONE JSON line (rank 0).
 from __future__ import annotations
 
 import argparse
+import faulthandler
 import json
 import os
 import sys
 import threading
 import time
+
+faulthandler.enable()  # a fatal signal (a GPU memory fault aborts the process) leaves the Python stack in the log
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

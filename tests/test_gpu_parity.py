@@ -511,6 +511,29 @@ def test_horizontal_first_batch_with_bgra_and_blend(hip, oracle):
     sc.close()
 
 
+@pytest.mark.parametrize("no_matrix", [0, 1])
+@pytest.mark.parametrize("sw,sh,dw,dh", [(1280, 720, 400, 225), (1280, 960, 120, 90), (2048, 1536, 200, 150)])
+def test_composed_frames_with_transparent_pixels(hip, oracle, monkeypatch, no_matrix, sw, sh, dw, dh):
+    """Frames with fully transparent pixels (S-alpha: a transparent border and 2.5 % zero alphas) that are composed
+    over a background stay on the premultiplied channel set in all three streaming kernels (matrix-core, all-VALU
+    [TIMG_HIP_NO_MATRIX], horizontal-first): a filtered alpha below 2^-120 ends as alpha byte 0 = the background
+    alone.  Bands above start_row still need the straight sums.  Bytes against the oracle, all channel sets."""
+    monkeypatch.setenv("TIMG_HIP_NO_MATRIX", str(no_matrix))
+    src = synth.alpha(sw, sh, seed=sw + 3 * dh)
+    sc = hip.scaler(sw, sh, dw, dh)
+    assert sc.info()["streaming_ok"] == 1
+    scaled = oracle.scale(src, dw, dh)
+    for blend_args in ((BG,), (BG, PAT, 5, 7), (BG, PAT, 4, 4, 31)):
+        blend = timg_amd.Blend.make(*blend_args)
+        want, _ = oracle.alpha_compose(scaled.copy(), *blend_args)
+        for kernel in (2, 3, 4, 1):
+            sc.set_kernel(kernel)
+            got = np.empty((dh, dw, 4), np.uint8)
+            hip.scale_blend(sc, src, got, 1, blend)
+            assert np.array_equal(got, want), (blend_args, kernel, int(np.count_nonzero(got != want)))
+    sc.close()
+
+
 def test_streaming_batch_with_blend_matches_generic(hip):
     """Size-independent property at full batch shape: both kernel families give
     identical bytes on device-resident frames (the generic one is pinned to the

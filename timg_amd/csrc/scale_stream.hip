@@ -189,6 +189,13 @@ struct TileCtx {
     int *fail;       // LDS flag
 };
 
+// Straight RGB of pixels with (nearly) no alpha only shows when they are not composed: a composed
+// pixel whose filtered alpha is below 2^-120 has alpha byte 0 and becomes the background alone, so
+// the premultiplied channel set may keep such tiles when every row of the band is composed.
+__device__ __forceinline__ bool NeedStraight(const TileCtx &c) {
+    return !(c.blend->enabled && c.blend->start_row <= c.bi.oy0);
+}
+
 // Horizontal pass of one completed output row y over the strip's outputs:
 // stb's gather with an even and an odd accumulation chain (or one chain for
 // <= 3 taps), stb_image_resize2.h:5801-6009.  The staged row holds kHc floats
@@ -270,7 +277,7 @@ __device__ __forceinline__ void HorizontalRow(const TileCtx &c, const float *sta
             px.c[4] = even[1];
             px.c[5] = even[2];
             px.c[6] = even[3];
-            if (px.c[3] < TIMG_TINY_F32) *ok = false;  // needs the straight RGB sums
+            if (NeedStraight(c) && px.c[3] < TIMG_TINY_F32) *ok = false;  // needs the straight RGB sums
         } else {
 #pragma unroll
             for (int ch = 0; ch < 7; ++ch) px.c[ch] = even[ch < kHc ? ch : 0];
@@ -339,7 +346,7 @@ __device__ bool RunTile(const TileCtx &c) {
         // Fully transparent pixels announce filtered alphas of (or below) zero, which
         // need the straight RGB sums: give the tile to the full channel set right away
         // instead of discovering it output pixel by output pixel.
-        if (M == kPremult) ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
+        if (M == kPremult && NeedStraight(c)) ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
         float d[kPix][kCh];
         DecodeMode<M>(q.x, d[0]);
         DecodeMode<M>(q.y, d[1]);
@@ -1216,6 +1223,9 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
 #pragma unroll
         for (int ch = 0; ch < kVc; ++ch) acc[s][ch] = 0.0f;
     bool ok = true;
+    // straight RGB of pixels with (nearly) no alpha only shows when they are not composed (as in the matrix kernel:
+    // a composed pixel whose filtered alpha is below 2^-120 has alpha byte 0 and becomes the background alone)
+    const bool need_straight = !(blend.enabled && blend.start_row <= bi.oy0);
 
     RowSched rs_next = LoadConstant(sched);
     // one source row: decode -> LDS, barrier, gather, vertical update
@@ -1237,7 +1247,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
                 else q = make_uint4(q.w, q.w, q.w, q.w);
             }
             if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
-            if (M == kPremult)
+            if (M == kPremult && need_straight)
                 ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
             float *dst = buf + (size_t)(tid + j * kThreadsH) * kStride;  // index (chunk) in plane 0
             DecodeToLds<M>(q.x, dst);
@@ -1316,7 +1326,7 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
                     px.c[4] = all[1];
                     px.c[5] = all[2];
                     px.c[6] = all[3];
-                    if (has && !par && px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
+                    if (need_straight && has && !par && px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
                 } else {
 #pragma unroll
                     for (int ch = 0; ch < 7; ++ch) px.c[ch] = all[ch];

@@ -1116,14 +1116,19 @@ __device__ __forceinline__ void DecodeToLds(uint32_t px, float *dst) {
     constexpr int kCh = ModeTraits<M>::kCh;
     float d[kCh];
     DecodeMode<M>(px, d);
-    *reinterpret_cast<float4 *>(dst) =
-        make_float4(d[0], d[1], d[2], M == kOpaque ? 1.0f : d[kCh > 3 ? 3 : 0]);
+    // (premultiplied set: RA GA BA A -- the colour pair comes out of one packed multiply into an even-aligned
+    // register pair of the 16-byte store; with A in front the compiler moved every pair by one register)
+    if (M == kPremult)
+        *reinterpret_cast<float4 *>(dst) = make_float4(d[1], d[2], d[3], d[0]);
+    else
+        *reinterpret_cast<float4 *>(dst) = make_float4(d[0], d[1], d[2], M == kOpaque ? 1.0f : d[kCh > 3 ? 3 : 0]);
 }
 
 // value of the other lane of the pair (lanes 2i and 2i+1)
 __device__ __forceinline__ float FromPartner(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1 /* quad_perm [1,0,3,2] */,
-                                                      0xf, 0xf, false));
+    // (mov_dpp: no 'old' value -- every lane has a source under quad_perm -- so no register is zeroed first and the
+    // exchange folds into the add that consumes it)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
 }
 
 // TAPS = taps per LANE (the column's taps 2j + parity): the loop is unrolled with its
@@ -1202,6 +1207,11 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         chunk_ptr[j]   = frame + (size_t)min(min(col, si.cx0 + win - 4), plan.in_w - 4) * 4u;
         chunk_shift[j] = (col < plan.in_w && col + 4 > plan.in_w) ? col + 4 - plan.in_w : 0;
     }
+    // (wave-uniform: only a wave of the last strip of a frame whose width is no multiple of 4 shuffles anything; as a
+    // per-lane test the three-way shuffle cost every wave some 35 scalar and branch instructions per chunk and row)
+    bool any_shift = false;
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) any_shift = any_shift || __any(chunk_shift[j] != 0);
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     // rows are fetched in order through a byte offset that just advances (rows past the image's last one --
     // virtual rows of the schedule -- re-read the last row); 64-bit: 8K frames with padded strides pass 4 GB... never,
@@ -1222,10 +1232,13 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
         for (int ch = 0; ch < kVc; ++ch) acc[s][ch] = 0.0f;
-    bool ok = true;
+    uint32_t amin = 0xffffffffu;
+    bool tiny     = false;
     // straight RGB of pixels with (nearly) no alpha only shows when they are not composed (as in the matrix kernel:
     // a composed pixel whose filtered alpha is below 2^-120 has alpha byte 0 and becomes the background alone)
     const bool need_straight = !(blend.enabled && blend.start_row <= bi.oy0);
+
+    const uint32_t amin_limit = M == kOpaque ? 0xff000000u : need_straight ? 0x01000000u : 0u;
 
     RowSched rs_next = LoadConstant(sched);
     // one source row: decode -> LDS, barrier, gather, vertical update
@@ -1241,21 +1254,24 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
         for (int j = 0; j < LOADS; ++j) {
             if (!chunk_in[j]) continue;
             uint4 q = raw[j];
-            if (chunk_shift[j]) {
+            if (any_shift && chunk_shift[j]) {
                 if (chunk_shift[j] == 1) q = make_uint4(q.y, q.z, q.w, q.w);
                 else if (chunk_shift[j] == 2) q = make_uint4(q.z, q.w, q.w, q.w);
                 else q = make_uint4(q.w, q.w, q.w, q.w);
             }
-            if (M == kOpaque) ok = ok && ((q.x & q.y & q.z & q.w) >> 24) == 0xffu;
-            if (M == kPremult && need_straight)
-                ok = ok && MinU32(MinU32(q.x, q.y), MinU32(q.z, q.w)) >= 0x01000000u;  // (alpha is the top byte: every alpha != 0)
+            // smallest pixel word so far (alpha is the top byte: its top byte is the smallest alpha)
+            if (M != kFull) amin = MinU32(MinU32(MinU32(amin, q.x), q.y), MinU32(q.z, q.w));
             float *dst = buf + (size_t)(tid + j * kThreadsH) * kStride;  // index (chunk) in plane 0
             DecodeToLds<M>(q.x, dst);
             DecodeToLds<M>(q.y, dst + (size_t)w4 * kStride);
             DecodeToLds<M>(q.z, dst + (size_t)2 * w4 * kStride);
             DecodeToLds<M>(q.w, dst + (size_t)3 * w4 * kStride);
         }
-        if (M != kFull && __any(!ok)) return false;  // (the workgroup is this one wave)
+        // opaque set: every alpha 0xff; premultiplied set: no alpha of 0 (unless composed anyway: need_straight)
+        // (tiny: a filtered alpha below 2^-120, found by the row before this one -- see below.  ONE test and one
+        // branch per row whatever the channel set: a second branch on need_straight made the compiler merge the
+        // unrolled steps of the ring into a rotating loop that copies registers whose loads are still in flight)
+        if (M != kFull && __any(amin < amin_limit || tiny)) return false;  // (the workgroup is this one wave)
 
         // this lane's chain of the horizontal gather: taps n = nb + 2j alternate between two
         // planes, each advancing one slot every second tap
@@ -1322,11 +1338,13 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
                     px.c[6] = all[2];
                 } else if (M == kPremult) {
                     px.c[0] = px.c[1] = px.c[2] = 0.0f;
-                    px.c[3] = all[0];
-                    px.c[4] = all[1];
-                    px.c[5] = all[2];
-                    px.c[6] = all[3];
-                    if (need_straight && has && !par && px.c[3] < TIMG_TINY_F32) ok = false;  // needs the straight RGB sums
+                    px.c[3] = all[3];  // (row buffer order: RA GA BA A)
+                    px.c[4] = all[0];
+                    px.c[5] = all[1];
+                    px.c[6] = all[2];
+                    // a filtered alpha below 2^-120 needs the straight RGB sums (noted here, acted upon by the next
+                    // row's check)
+                    if (need_straight && has && !par && px.c[3] < TIMG_TINY_F32) tiny = true;
                 } else {
 #pragma unroll
                     for (int ch = 0; ch < 7; ++ch) px.c[ch] = all[ch];
@@ -1402,8 +1420,8 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
                  : "memory");
 #undef TIMG_H_STEP
 #undef TIMG_H_ISSUE
-    if (M != kFull && __any(!ok)) return;
-    if (tid == 0) tile_state[tile] = gen;
+    if (M == kPremult && __any(tiny)) return;  // (found by the last row)
+    if (tid == 0) tile_state[tile] = gen;  // (any other row that broke the channel set's assumption has left through row_step)
 }
 
 }  // namespace

@@ -1238,16 +1238,31 @@ __device__ __forceinline__ int RunBytes(int count) {
     return 5 * full + (rest > 3 ? 2 + NumLen((uint32_t)rest) : rest);
 }
 
+// LDS layout of BandNodesKernel for frames whose bands sort in LDS (words; shared by the kernel and its launch)
+__host__ __device__ inline int BandBitmapWords(int w) { return ((w + 31) >> 5) | 1; }
+__host__ __device__ inline int BandBucketWords(int w) { return (w + 8) & ~1; }
+__host__ __device__ inline int BandNodesSharedWords(int w, int ne) {  // bitmap phase and node phase, one after the other
+    const int nws = BandBitmapWords(w), nwp = (nws + 1) >> 1;
+    const int a = 256 * nws + 128 * nwp + 256, b = BandBucketWords(w) + ne + ne / 2;
+    return a > b ? a : b;
+}
+
+template <int kT = 256>
 __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_tmp, uint32_t *total) {
-    // 256 threads; s_tmp: 5 words of LDS.  Returns the exclusive prefix of v.
+    // kT threads; s_tmp: kT / 64 words of LDS.  Returns the exclusive prefix of v.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t incl = WaveInclusiveAdd(v);
     __syncthreads();  // s_tmp may still be read from a previous scan
     if (lane == 63) s_tmp[wv] = incl;
     __syncthreads();
-    uint32_t before = 0;
-    for (int q = 0; q < wv; ++q) before += s_tmp[q];
-    if (total) *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < kT / 64; ++q) {
+        const uint32_t t = s_tmp[q];
+        before += q < wv ? t : 0u;
+        all += t;
+    }
+    if (total) *total = all;
     return before + incl - v;
 }
 
@@ -1269,24 +1284,29 @@ __device__ __forceinline__ int ColumnEntries(const uint32_t c[6], int x, uint32_
     return n;
 }
 
-template <bool kWide>
-__global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b) {
+// kT lanes per band: 512 for bands whose sort buffers live in LDS (two workgroups per CU by their LDS: 16 waves per
+// CU instead of 8 -- the kernel is a chain of short phases between barriers, latency-bound), 256 for wide frames
+template <bool kWide, int kT>
+__global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b) {
+    static_assert(kT == 256 || (!kWide && kT == 512), "the wide path's radix counters are laid out for 256 lanes");
     extern __shared__ uint32_t lds[];
     const int NE = g.band_ne;
-    // aux: 4096 words of radix histogram, later two column-indexed bucket arrays
-    // (kBucket apart).  The sort buffers live in LDS, or -- for frames too wide for that --
-    // in this band's global scratch slots, which later kernels overwrite with their outputs
-    // (ent_a is the final home of the sorted entries anyway).
-    constexpr int kBucket = kWide ? 4096 : 2048;  // columns (<= kMaxSixelWidth resp. kLdsEntries / 6)
+    // aux: 4096 words of radix histogram (wide frames), later ONE column-indexed bucket word per column: nodes
+    // starting in the column (later: their base) in the low half, the fill counter in the high half.  The sort
+    // buffers live in LDS, or -- for frames too wide for that -- in this band's global scratch slots, which later
+    // kernels overwrite with their outputs (ent_a is the final home of the sorted entries anyway).
+    // Narrow frames are laid out for THREE workgroups per CU (BandNodesLdsWords: 52.5 KB at 800 columns; at 64.4 KB
+    // -- two bucket arrays of 2048 words and a prefix per bitmap word -- two fitted).
     uint32_t *aux      = lds;
     uint32_t *ent_a, *ent_b;
     uint16_t *nfirst_u;
-    // narrow frames, first phase: presence bitmap [256 colours][nws words], 16-bit word prefixes
-    // of the same shape, per-colour bases -- in the space the node phase reuses (aux, ent_b, nfirst_u)
-    const int nws       = ((g.w + 31) >> 5) | 1;  // odd row stride: a lane per colour walks its row conflict-free
+    // narrow frames, first phase: presence bitmap [256 colours][nws words], a 16-bit prefix per PAIR of words,
+    // per-colour bases -- in the space the node phase reuses (aux, ent_b, nfirst_u)
+    const int nws       = BandBitmapWords(g.w);  // odd row stride: a lane per colour walks its row conflict-free
+    const int nwp       = (nws + 1) >> 1;
     uint32_t *bitmap    = lds;
     uint16_t *wprefix   = reinterpret_cast<uint16_t *>(lds + 256 * nws);
-    uint32_t *cbase     = lds + 256 * nws + 128 * nws;
+    uint32_t *cbase     = lds + 256 * nws + 128 * nwp;
     {
         const size_t fslot = ((size_t)blockIdx.y * g.bands + blockIdx.x) * NE;
         if (kWide) {
@@ -1294,12 +1314,12 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             ent_b    = b.band_pi + fslot;
             nfirst_u = reinterpret_cast<uint16_t *>(b.band_rec + fslot);
         } else {
-            ent_b    = lds + 2 * kBucket;                         // the unsorted node keys
+            ent_b    = lds + BandBucketWords(g.w);                // the unsorted node keys
             nfirst_u = reinterpret_cast<uint16_t *>(ent_b + NE);  // first entry of node k
-            ent_a    = lds + max(384 * nws + 256, 2 * kBucket + NE + NE / 2);  // sorted entries
+            ent_a    = lds + BandNodesSharedWords(g.w, NE);       // sorted entries
         }
     }
-    __shared__ uint32_t s_tmp[5];
+    __shared__ uint32_t s_tmp[kT / 64];
 
     const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
@@ -1310,9 +1330,10 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     // ---- entries, column-major: count, scan, write.  A lane takes kGroups x 4 adjacent
     // columns; the six index rows of a group arrive as six 4-byte loads (the rows of the
     // index image are padded to 4) that are issued together and kept for both passes.
-    constexpr int kGroups = 4;  // 256 lanes x 4 groups x 4 columns >= kMaxSixelWidth
+    constexpr int kGroups = 1024 / kT;  // kT lanes x kGroups groups x 4 columns >= kMaxSixelWidth
+    static_assert(kT * kGroups * 4 >= kMaxSixelWidth, "a lane's column groups cover the widest frame");
     const int n_groups    = (W + 3) / 4;
-    const int per_g       = (n_groups + 255) / 256;
+    const int per_g       = (n_groups + kT - 1) / kT;
     const int g0 = min(n_groups, tid * per_g), g1 = min(n_groups, g0 + per_g);
     uint32_t cw[kGroups][6];
 #pragma unroll
@@ -1345,7 +1366,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         // x -- a popcount over c's row of a presence bitmap plus a per-word prefix.  No
         // per-lane chains of dependent LDS updates (which is what a counting sort over lane
         // chunks is), just atomics, one row scan per colour and one placement per entry.
-        for (int i = tid; i < 256 * nws; i += 256) bitmap[i] = 0;  // (while the index loads are in flight)
+        for (int i = tid; i < 256 * nws; i += kT) bitmap[i] = 0;  // (while the index loads are in flight)
         __syncthreads();
         for_columns([&](int n) {
             for (int j = 0; j < n; ++j) {
@@ -1355,19 +1376,24 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         });
         __syncthreads();
         uint32_t total = 0;
-        for (int w = 0; w < nws; ++w) {  // lane = colour
-            wprefix[tid * nws + w] = (uint16_t)total;
-            total += (uint32_t)__popc(bitmap[tid * nws + w]);
-        }
+        if (tid < 256)
+            for (int w = 0; w < nws; ++w) {  // lane = colour
+                if (!(w & 1)) wprefix[tid * nwp + (w >> 1)] = (uint16_t)total;
+                total += (uint32_t)__popc(bitmap[tid * nws + w]);
+            }
         uint32_t n_ent_u;
-        cbase[tid] = BlockExclusiveScan(total, s_tmp, &n_ent_u);
-        n_ent      = (int)n_ent_u;
+        const uint32_t cb = BlockExclusiveScan<kT>(total, s_tmp, &n_ent_u);
+        if (tid < 256) cbase[tid] = cb;
+        n_ent = (int)n_ent_u;
         __syncthreads();
         for_columns([&](int n) {
             for (int j = 0; j < n; ++j) {
                 const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
-                const uint32_t at = c * nws + (x >> 5);
-                ent_a[cbase[c] + wprefix[at] + (uint32_t)__popc(bitmap[at] & ((1u << (x & 31u)) - 1u))] = e6[j];
+                const uint32_t w = x >> 5, at = c * nws + w;
+                // (columns of c below x: the pair's prefix, the even word of the pair for an odd one, this word's bits)
+                const uint32_t below_pair = (w & 1u) ? (uint32_t)__popc(bitmap[at - 1]) : 0u;
+                ent_a[cbase[c] + wprefix[c * nwp + (w >> 1)] + below_pair +
+                      (uint32_t)__popc(bitmap[at] & ((1u << (x & 31u)) - 1u))] = e6[j];
             }
         });
         __syncthreads();
@@ -1375,7 +1401,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         uint32_t mine = 0;
         for_columns([&](int n) { mine += (uint32_t)n; });
         uint32_t n_ent_u;
-        uint32_t at = BlockExclusiveScan(mine, s_tmp, &n_ent_u);
+        uint32_t at = BlockExclusiveScan<kT>(mine, s_tmp, &n_ent_u);
         n_ent = (int)n_ent_u;
         for_columns([&](int n) {
             for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
@@ -1398,7 +1424,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             // exclusive scan over the 4096 counters in (digit, lane) order
             uint32_t sum = 0;
             for (int j = 0; j < 16; ++j) sum += aux[tid * 16 + j];
-            uint32_t run = BlockExclusiveScan(sum, s_tmp, nullptr);
+            uint32_t run = BlockExclusiveScan<kT>(sum, s_tmp, nullptr);
             for (int j = 0; j < 16; ++j) {
                 const uint32_t t  = aux[tid * 16 + j];
                 aux[tid * 16 + j] = run;
@@ -1416,7 +1442,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         }
 
     }
-    const int per_e = (n_ent + 255) / 256;
+    const int per_e = (n_ent + kT - 1) / kT;
     const int e0 = min(n_ent, tid * per_e), e1 = min(n_ent, e0 + per_e);
 
     // ---- nodes: a node starts at a new colour or after a gap of >= 10 empty columns
@@ -1433,7 +1459,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     auto run_break2 = [](uint32_t p, uint32_t e) {  // does a new run start at e, p being the entry before it?
         return (p >> 22) != (e >> 22) || ((e >> 6) & 0xffffu) != ((p >> 6) & 0xffffu) + 1 || ((e ^ p) & 0x3fu) != 0;
     };
-    constexpr bool kMasks = !kWide;  // per_e <= kLdsEntries / 256 = 32
+    constexpr bool kMasks = !kWide;  // per_e <= kLdsEntries / kT <= 32
     uint32_t node_bits = 0, run_bits = 0, starts = 0;  // starts: node starts << 16 | run starts
     {
         uint32_t prev = e0 > 0 ? ent_a[e0 - 1] : 0u;
@@ -1455,7 +1481,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
         return kMasks ? ((run_bits >> (i - e0)) & 1u) != 0 : (i == 0 || run_break2(ent_a[i - 1], ent_a[i]));
     };
     uint32_t totals;
-    const uint32_t before = BlockExclusiveScan(starts, s_tmp, &totals);
+    const uint32_t before = BlockExclusiveScan<kT>(starts, s_tmp, &totals);
     const int n_nodes = (int)(totals >> 16);
     uint16_t *run_first = reinterpret_cast<uint16_t *>(ent_b);       // [run] first entry   } both until the
     uint16_t *ent_bytes = reinterpret_cast<uint16_t *>(ent_b) + NE;  // [entry] its bytes   } node keys move in
@@ -1468,10 +1494,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             enode_g[i] = (uint16_t)(k - 1);
         }
     }
-    for (int x = tid; x <= W; x += 256) {
-        aux[x]           = 0;  // nodes starting in column x
-        aux[kBucket + x] = 0;  // fill counter
-    }
+    for (int x = tid; x <= W; x += kT) aux[x] = 0;  // nodes starting in column x | fill counter << 16
     if (kWide) __threadfence_block();
     __syncthreads();
     // bytes per entry: the gap in front of a run at the run's first entry, the run at its last
@@ -1494,7 +1517,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
             e    = next;
         }
         uint32_t body_total;
-        uint32_t at = BlockExclusiveScan(mine, s_tmp, &body_total);
+        uint32_t at = BlockExclusiveScan<kT>(mine, s_tmp, &body_total);
         uint32_t *ep_g = s.band_ep + slot;
         for (int i = e0; i < e1; ++i) {
             ep_g[i] = at;
@@ -1506,7 +1529,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     __syncthreads();
     uint32_t *key_u = ent_b;
     uint16_t *nf_g = s.band_nf + slot;
-    for (int n = tid; n < n_nodes; n += 256) {
+    for (int n = tid; n < n_nodes; n += kT) {
         const int first   = nfirst_u[n];
         const int last    = (n + 1 < n_nodes ? (int)nfirst_u[n + 1] : n_ent) - 1;
         nf_g[n]           = (uint16_t)first;
@@ -1519,11 +1542,11 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     __syncthreads();
     // bucket bases: exclusive scan over the columns
     {
-        const int per_x = (W + 256) / 256;
+        const int per_x = (W + kT) / kT;
         const int c0 = min(W + 1, tid * per_x), c1 = min(W + 1, c0 + per_x);
         uint32_t sum = 0;
         for (int x = c0; x < c1; ++x) sum += aux[x];
-        uint32_t run = BlockExclusiveScan(sum, s_tmp, nullptr);
+        uint32_t run = BlockExclusiveScan<kT>(sum, s_tmp, nullptr);
         for (int x = c0; x < c1; ++x) {
             const uint32_t t = aux[x];
             aux[x]           = run;
@@ -1534,10 +1557,11 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     __syncthreads();
     uint32_t *nkey   = s.band_nkey + slot;
     uint16_t *nfirst = s.band_nfirst + slot;
-    for (int n = tid; n < n_nodes; n += 256) {
+    for (int n = tid; n < n_nodes; n += kT) {
         const uint32_t key = key_u[n];
         const uint32_t sx  = key >> 20;
-        const uint32_t pos = aux[sx] + atomicAdd(&aux[kBucket + sx], 1u);
+        const uint32_t was = atomicAdd(&aux[sx], 0x10000u);  // (base in the low half: < 6 * kMaxSixelWidth < 2^16)
+        const uint32_t pos = (was & 0xffffu) + (was >> 16);
         nkey[pos]          = key;
         nfirst[pos]        = (uint16_t)n;
     }
@@ -1545,10 +1569,11 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     __syncthreads();  // (also orders the global writes above inside the workgroup)
     // nodes starting in the same column (at most 6: one per colour of the column):
     // order them by end desc, colour asc = ascending key
-    for (int x = tid; x < W; x += 256) {
-        const int c = (int)aux[kBucket + x];
+    for (int x = tid; x < W; x += kT) {
+        const uint32_t ax = aux[x];
+        const int c = (int)(ax >> 16);
         if (c < 2) continue;
-        const uint32_t base = aux[x];
+        const uint32_t base = ax & 0xffffu;
         uint32_t kk[6];
         uint16_t ff[6];
         for (int j = 0; j < c && j < 6; ++j) {
@@ -1574,7 +1599,7 @@ __global__ void __launch_bounds__(256) BandNodesKernel(SixelGeom g, SixelBatch b
     }
     if (!kWide) {
         uint32_t *ent_g = s.band_ent + slot;
-        for (int i = tid; i < n_ent; i += 256) ent_g[i] = ent_a[i];
+        for (int i = tid; i < n_ent; i += kT) ent_g[i] = ent_a[i];
     }
     if (tid == 0) {
         s.band_cnt[band * 4 + 0] = n_ent;
@@ -2073,18 +2098,20 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024 - 512) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
     const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
-    const int nodes_nws     = ((w + 31) >> 5) | 1;
+#ifndef TIMG_BAND_LANES
+#define TIMG_BAND_LANES 512
+#endif
+    constexpr int kBandLanes = TIMG_BAND_LANES;  // lanes per band of BandNodesKernel (narrow frames)
     const size_t nodes_lds =
         wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
-                   : (std::max((size_t)384 * nodes_nws + 256, (size_t)2 * 2048 + g.band_ne + g.band_ne / 2) +
-                      g.band_ne + 16) * sizeof(uint32_t);
+                   : ((size_t)BandNodesSharedWords(w, g.band_ne) + g.band_ne + 16) * sizeof(uint32_t);
     const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false> : (const void *)DitherKernel<true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dither_lds));
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true>
-                                                     : (const void *)BandNodesKernel<false>,
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true, 256>
+                                                     : (const void *)BandNodesKernel<false, kBandLanes>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)nodes_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)BandEmitKernel,
@@ -2167,9 +2194,9 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
                 hipLaunchKernelGGL(DitherKernel<true>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
         }
         if (wide_bands)
-            hipLaunchKernelGGL(BandNodesKernel<true>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
+            hipLaunchKernelGGL((BandNodesKernel<true, 256>), dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         else
-            hipLaunchKernelGGL(BandNodesKernel<false>, dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
+            hipLaunchKernelGGL((BandNodesKernel<false, kBandLanes>), dim3(g.bands, nfr), dim3(kBandLanes), nodes_lds, gs, g, gb);
         hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * nfr + 3) / 4), dim3(256), 0, gs, g, gb, nfr);
         hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, nfr), dim3(256), emit_lds, gs, g, gb);
         hipLaunchKernelGGL(AssembleFrameKernel, dim3(nfr), dim3(256), 0, gs, g, gb);

@@ -648,7 +648,12 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
                 if (!(m & kReady)) break;  // not prepared: next round
                 const int l       = __ffsll((long long)__ballot(best == m)) - 1;
                 const uint32_t qq = m & 3u, slot = qq * 64 + (uint32_t)l;
-                const CutBox box      = pool[slot];
+                // (the whole record in ONE round trip: left to itself the compiler fetched ind and buf a second time
+                // inside lane 0's branch below -- a second dependent LDS latency in every step of this serial chain)
+                uint4 rec0 = reinterpret_cast<const uint4 *>(&pool[slot])[0];
+                uint4 rec1 = reinterpret_cast<const uint4 *>(&pool[slot])[1];
+                asm volatile("" : "+v"(rec0.x), "+v"(rec0.y), "+v"(rec0.z), "+v"(rec0.w), "+v"(rec1.x), "+v"(rec1.y));
+                const CutBox box{rec0.x, rec0.y, rec0.z, rec0.w, rec1.x, rec1.y, 0, 0};
                 const uint32_t median = box.median, lowersum = box.lowersum;
                 // the low half takes the parent's slot, the high half the next free one
                 const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 256 - nb};

@@ -38,12 +38,14 @@ __device__ __forceinline__ uint32_t WaveSum(uint32_t v) { return ReadLane(WaveIn
 
 // maximum over the wave, as a scalar
 __device__ __forceinline__ uint32_t WaveMaxU32(uint32_t v) {
-    v = max(v, TIMG_DPPV(v, 0x111, 0xf));
-    v = max(v, TIMG_DPPV(v, 0x112, 0xf));
-    v = max(v, TIMG_DPPV(v, 0x114, 0xf));
-    v = max(v, TIMG_DPPV(v, 0x118, 0xf));
-    v = max(v, TIMG_DPPV(v, 0x142, 0xa));
-    v = max(v, TIMG_DPPV(v, 0x143, 0xc));
+    // (0 is the identity of an unsigned maximum: with 'old' = 0 the compiler folds each exchange into the v_max_u32
+    // that consumes it -- with 'old' = v it emitted a copy, a v_mov_dpp and the maximum, four instructions a stage)
+    v = max(v, TIMG_DPP0(v, 0x111, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x112, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x114, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x118, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x142, 0xa));
+    v = max(v, TIMG_DPP0(v, 0x143, 0xc));
     return ReadLane(v, 63);
 }
 

@@ -328,6 +328,28 @@ def test_sixel_geometry_corner_cases(hip, oracle, kind, w, h):
     assert len(got) == len(want) and got == want, (len(got), len(want))
 
 
+@pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])
+def test_sixel_diffusion_spread_over_several_cus(hip, oracle, monkeypatch, parts):
+    """Frames of eight row groups and more are diffused by several workgroups (CUs) per frame, the boundary row
+    between two of them handed over through memory by helper waves (DitherKernel<., true>; default: the fewest
+    parts that fit, from two).  Every part count gives the oracle's bytes -- on a batch large enough that parts of
+    many frames are in flight at once (80 frames x up to 4 workgroups), device-resident, and on single frames whose
+    row groups do not divide evenly."""
+    monkeypatch.setenv("TIMG_HIP_DITHER_PARTS", str(parts))
+    n, w, h = 80, 300, 282  # 9 row groups (47 bands of 6 rows)
+    frames = np.stack([synth.make(("photo", "noise", "alpha")[i % 3], w, h, seed=300 + i) for i in range(n)])
+    d = hip.upload(frames)
+    outs = hip.sixel_encode(d, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 4), n_frames=n,
+                            out_cap=hip.sixel_max_bytes(w, h) * 4)
+    hip.free(d)
+    for i in (0, 1, 2, 39, 40, 77, 78, 79):
+        assert outs[i] == oracle.sixel_encode(frames[i], BG, PAT, 4, 4, lookup_mode=1), (parts, i)
+    for kind, w1, h1 in (("photo", 800, 450), ("alpha", 257, 353), ("noise", 640, 480)):
+        fb = synth.make(kind, w1, h1, seed=parts)
+        got = hip.sixel_encode(fb, w1, h1, pad_blend=timg_amd.Blend.make(BG), out_cap=hip.sixel_max_bytes(w1, h1) * 4)[0]
+        assert got == oracle.sixel_encode(fb, BG, lookup_mode=1), (parts, kind, w1, h1)
+
+
 @pytest.mark.parametrize("kind,w,h", [("photo", 320, 203), ("alpha", 200, 100), ("noise", 97, 61), ("photo", 64, 7),
                                       ("noise", 33, 6), ("photo", 2, 13), ("alpha", 1, 1), ("photo", 800, 450)])
 def test_sixel_first_hit_lookup_is_libsixels_cache(hip, oracle, kind, w, h):

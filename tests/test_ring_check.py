@@ -97,7 +97,7 @@ def test_built_library_passes():
     sixel = BUILT.replace("scale_stream", "sixel_canvas")
     r = subprocess.run([sys.executable, CHECK, sixel], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "2 kernels" in r.stdout
+    assert "3 kernels" in r.stdout
 
 
 def test_single_register_ring_is_checked_too(tmp_path):

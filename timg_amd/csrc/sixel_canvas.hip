@@ -33,6 +33,11 @@ constexpr int kMaxColors     = 256;
 // kernels sort in LDS; wider frames (up to kMaxSixelWidth: columns travel in 12-bit fields)
 // use the same code on global-memory scratch.
 constexpr int kLdsEntries    = 8192;
+// The diffusion of a frame spread over several workgroups (CUs): hand-over buffer of one boundary between two of them -- the
+// boundary row's (W + 2) x 3 words, then (in a cache line of its own) the producer's progress counter
+constexpr int kDitherMaxParts = 8;
+__host__ __device__ inline int XwgData(int w) { return ((w + 2) * 3 + 31) & ~31; }
+__host__ __device__ inline int XwgStride(int w) { return XwgData(w) + 32; }
 constexpr int kMaxSixelWidth = 4095;
 
 struct SixelGeom {
@@ -91,6 +96,7 @@ struct SixelBatch {
     uint16_t *band_erl, *band_enode, *band_nf;
     int *band_cnt;
     uint32_t *pad_rows;          // [frames][5][w] the rows appended below the frame, as pixels (K4)
+    uint32_t *xwg;               // [frames][kDitherMaxParts - 1][XwgStride(w)] boundary rows handed from CU to CU (K4)
     int *error;                  // [1] set when a device-side wait gives up
     char *out;
     size_t out_cap;
@@ -774,6 +780,10 @@ __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b)
     const int b0 = k0 & 255, b1 = k1 & 255;
     s.lut[cell0] = (uint32_t)b0 | (pal[b0].x << 8);
     s.lut[cell1] = (uint32_t)b1 | (pal[b1].x << 8);
+    // the hand-over counters of a diffusion spread over several CUs start at zero (the kernel boundary in
+    // front of DitherKernel publishes these plain stores)
+    if (blockIdx.x == 0 && threadIdx.x < kDitherMaxParts - 1)
+        b.xwg[((size_t)f * (kDitherMaxParts - 1) + threadIdx.x) * XwgStride(g.w) + XwgData(g.w)] = 0u;
 }
 
 // ---- K4: lookup + Floyd-Steinberg -----------------------------------------------------
@@ -839,11 +849,32 @@ constexpr int kDitherSpinLimit = 1 << 22;
 
 // kNarrow: frames of 1 or 2 columns, where the row-wrap term and the 7/16 term come from
 // the same pixel and arrive in the other order
-template <bool kNarrow>
+//
+// kSplit: the frame's waves are spread over gridDim.x workgroups = CUs (part p takes the p-th share of the
+// frame's row groups; every wave of the frame exists at once, no rounds).  With 13-15 waves on one CU the
+// SIMDs are saturated by the instructions of the steps (0.38 us per step against 0.29-0.32 with one or two
+// waves per SIMD: profiles/r2/sixel_rows_sweep.txt).  The boundary between two parts travels through memory,
+// and NOT through the waves that diffuse: the last wave of part p publishes in LDS exactly as it does for a
+// wave of its own workgroup, a helper wave (the "flusher") follows that counter, writes the finished slots
+// through to memory (sc0 sc1 stores, drained, then the counter: MI355X_MICROARCH.md, inter-workgroup
+// visibility) and in part p + 1 another helper (the "fetcher") polls that counter, copies the new slots into
+// ITS workgroup's boundary row 0 and publishes them in LDS -- the diffusing waves run the same code in either
+// mode and never wait for a memory round trip.  Block x = part is the fastest index: a part is dispatched
+// after the part it follows, and every wait is bounded (kDitherSpinLimit -> the batch's error word).
+template <bool kNarrow, bool kSplit>
 __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t lds[];
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
+    // roles (kSplit): [fetcher (parts > 0)] [nd diffusing waves] [flusher (parts before the last)] [idle]
+    const int parts    = kSplit ? (int)gridDim.x : 1;
+    const int part     = kSplit ? (int)blockIdx.x : 0;
+    const int n_all    = (H + kPairRows - 1) / kPairRows;  // row groups of the frame
+    const int nd       = kSplit ? n_all / parts + (part < n_all % parts ? 1 : 0) : n_waves;
+    const int group0   = kSplit ? part * (n_all / parts) + min(part, n_all % parts) : 0;  // first row group of this part
+    const int lw0      = (kSplit && part > 0) ? 1 : 0;  // local index of the first diffusing wave
+    const int n_local  = lw0 + nd;                      // boundary rows written in this workgroup
+    const bool flushes = kSplit && part < parts - 1;
     const int n_pad    = H - g.h;
     uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);  // [cell ^ kCellBias] -> palette index
     uint32_t *pal      = lds + 8192;                        // [2][256]: 16 * (colour - 128) as (r, g) / (b, 0)
@@ -853,9 +884,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // writes into slots x + 2, x + 1 and x.  Slots nobody writes (1/16 left of column 0, 3/16
     // right of column W-1) keep the zero they are initialised with.
     const int brow     = (W + 2) * 3;
-    uint32_t *boundary = pal + 512;  // [n_waves + 1][W + 2][3]
+    uint32_t *boundary = pal + 512;  // [n_local + 1][W + 2][3]
     __shared__ int progress[kDitherMaxWaves];
-    const int f   = blockIdx.x;
+    const int f   = kSplit ? blockIdx.y : blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (in a scalar register: what depends on it branches for free)
@@ -888,29 +919,96 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // steps then fetch every row the same way (written and read by this workgroup only)
     uint32_t *pad_rows = b.pad_rows + (size_t)f * 5 * W;
     for (int i = tid; i < n_pad * W; i += blockDim.x) pad_rows[i] = PaddedPixel(frame, g, i % W, g.h + i / W);
-    for (int i = tid; i < (n_waves + 1) * brow; i += blockDim.x) boundary[i] = 0u;
-    if (tid < n_waves) progress[tid] = 0;
+    for (int i = tid; i < (n_local + 1) * brow; i += blockDim.x) boundary[i] = 0u;
+    if (tid < n_local) progress[tid] = 0;
     const bool dither = s.meta[1] != 0;
     __syncthreads();
+
+    if (kSplit) {
+        if (wave >= n_local + (flushes ? 1 : 0)) return;  // (the block is sized for the largest part)
+        if (flushes && wave == n_local) {
+            // ---- flusher: LDS boundary row of the part's last wave -> memory, as its counter advances
+            const uint32_t *row = boundary + (size_t)(n_local - 1) * brow;
+            uint32_t *xw        = b.xwg + ((size_t)f * (kDitherMaxParts - 1) + part) * XwgStride(W);
+            int *xflag          = reinterpret_cast<int *>(xw + XwgData(W));
+            int done = 0, spins = 0;
+            for (;;) {
+                const int p = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&progress[n_local - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                asm volatile("" ::: "memory");
+                // (slot c + 1 is final once the producer has finished column c + 1; the last two with the row)
+                const int limit = p >= W ? W + 2 : p;
+                if (limit > done) {
+                    for (int i = done * 3 + lane; i < limit * 3; i += 64)
+                        __hip_atomic_store(xw + i, row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slots have left before the counter does
+                    if (lane == 0) __hip_atomic_store(xflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    done = limit;
+                    if (p >= W) break;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kDitherSpinLimit) {
+                        if (lane == 0) atomicExch(b.error, 1);
+                        break;
+                    }
+                }
+            }
+            return;
+        }
+        if (lw0 && wave == 0) {
+            // ---- fetcher: the previous part's boundary row, memory -> this workgroup's boundary row 0
+            uint32_t *row      = boundary;
+            const uint32_t *xw = b.xwg + ((size_t)f * (kDitherMaxParts - 1) + part - 1) * XwgStride(W);
+            const int *xflag   = reinterpret_cast<const int *>(xw + XwgData(W));
+            int done = 0, spins = 0;
+            for (;;) {
+                const int p     = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                const int limit = p >= W ? W + 2 : p;
+                if (limit > done) {
+                    for (int i = done * 3 + lane; i < limit * 3; i += 64)
+                        row[i] = __hip_atomic_load(xw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
+                    if (lane == 0)
+                        __hip_atomic_store(&progress[0], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = limit;
+                    if (p >= W) break;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kDitherSpinLimit) {
+                        if (lane == 0) {
+                            atomicExch(b.error, 1);
+                            // (let the waves behind this one run to their end instead of into their own limit)
+                            __hip_atomic_store(&progress[0], W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        break;
+                    }
+                }
+            }
+            return;
+        }
+    }
 
     const uint32_t *pal_half = pal + (odd ? 256 : 0);
     // the term bytes of a boundary word as this half's pair of q << 8
     auto unpack_term = [&](uint32_t q) -> uint32_t { return __builtin_amdgcn_perm(q, q, sel_hi); };
 
-    const int rows_per_round = n_waves * kPairRows;
+    const int rows_per_round = (kSplit ? n_all : n_waves) * kPairRows;  // (kSplit: one round)
+    const int first_row      = (group0 + wave - lw0) * kPairRows;
     const int steps          = W + 2 * (kPairRows - 1);
     bool gave_up             = false;
-    for (int round = 0; round * rows_per_round + wave * kPairRows < H; ++round) {
-        const int row      = round * rows_per_round + wave * kPairRows + rl;
+    for (int round = 0; round * rows_per_round + first_row < H; ++round) {
+        const int row      = round * rows_per_round + first_row + rl;
         const bool has_row = row < H;
         const uint8_t *src_row  = row < g.h ? frame + (size_t)row * g.stride
                                             : reinterpret_cast<const uint8_t *>(pad_rows + (size_t)(min(row, H - 1) - g.h) * W);
         uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
         const bool diffuses     = dither && row < H - 1;
-        const int producer       = wave == 0 ? n_waves - 1 : wave - 1;
+        // (kSplit: local wave 0 is either the frame's first wave or the fetcher, which writes row 0 like a wave)
+        const int producer       = wave == 0 ? n_local - 1 : wave - 1;
         const int producer_round = wave == 0 ? round - 1 : round;
         const bool follows       = producer_round >= 0;
-        const uint32_t *b_in     = boundary + (size_t)(follows ? producer : n_waves) * brow;
+        const uint32_t *b_in     = boundary + (size_t)(follows ? producer : n_local) * brow;
         uint8_t *b_out           = reinterpret_cast<uint8_t *>(boundary + (size_t)wave * brow) + (odd ? 2 : 0);
         const int in_base        = producer_round * W;
         const int out_base       = round * W;
@@ -2059,6 +2157,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_bnf   = carve(n_band * g.band_ne * 2);
     const size_t o_bcnt  = carve(n_band * 4 * sizeof(int));
     const size_t o_prow  = carve(nf * (size_t)w * 5 * sizeof(uint32_t));
+    const size_t o_xwg   = carve(nf * (kDitherMaxParts - 1) * (size_t)XwgStride(w) * sizeof(uint32_t));
     const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
     char *base = (char *)ctx->dev[5].ptr;
@@ -2086,6 +2185,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     b.band_nf     = (uint16_t *)(base + o_bnf);
     b.band_cnt    = (int *)(base + o_bcnt);
     b.pad_rows    = (uint32_t *)(base + o_prow);
+    b.xwg         = (uint32_t *)(base + o_xwg);
     b.error       = (int *)(base + o_len + nf * sizeof(unsigned long long));
     b.out        = dout;
     b.out_cap    = out_cap;
@@ -2099,9 +2199,31 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         return (8192 + 512 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
     };
     if (const char *cap = getenv("TIMG_HIP_DITHER_WAVES")) dither_waves = std::max(1, std::min(dither_waves, atoi(cap)));
+    const bool waves_capped = getenv("TIMG_HIP_DITHER_WAVES") != nullptr;
     // (the kernel's static LDS -- the progress counters -- comes on top of the dynamic part)
     while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024 - 512) --dither_waves;
     const size_t dither_lds = dither_bytes(dither_waves);
+    // Frames of eight row groups and more are spread over several workgroups = CUs (DitherKernel<., true>): about
+    // four row groups a part (one wave per SIMD: 800x450 measured 644 / 587 / 557 / 522 us per 64 frames with
+    // 1 / 2 / 3 / 4 parts), no more parts than the batch leaves CUs for (parts of frames that wait for a CU while
+    // others spin cost more than they win), or what TIMG_HIP_DITHER_PARTS asks for; then the fewest parts from
+    // there whose largest share of the row groups (+ fetcher + flusher) fits a workgroup and its LDS; 1: one
+    // workgroup per frame.
+    const int dither_groups = (g.h6 + kPairRows - 1) / kPairRows;
+    int dither_parts        = 1;
+    if (w > 2 && dither_groups >= 8 && !waves_capped) {
+        int want = std::min(std::min((dither_groups + 3) / 4, kDitherMaxParts), std::max(1, ctx->cu_count / n_frames));
+        if (const char *e = getenv("TIMG_HIP_DITHER_PARTS")) want = atoi(e);
+        for (int p = std::max(want, 1); p > 1 && p <= kDitherMaxParts; ++p) {
+            const int share = (dither_groups + p - 1) / p;
+            if (share + 2 <= kDitherMaxWaves && dither_bytes(share + 1) <= 160 * 1024 - 512) {
+                dither_parts = p;
+                break;
+            }
+        }
+    }
+    const int split_share     = dither_parts > 1 ? (dither_groups + dither_parts - 1) / dither_parts : 0;
+    const size_t split_lds    = dither_parts > 1 ? dither_bytes(split_share + 1) : 0;
     const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
 #ifndef TIMG_BAND_LANES
 #define TIMG_BAND_LANES 512
@@ -2112,9 +2234,13 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
                    : ((size_t)BandNodesSharedWords(w, g.band_ne) + g.band_ne + 16) * sizeof(uint32_t);
     const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
     // both kernels need more than the default 64 KiB of dynamic LDS
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false> : (const void *)DitherKernel<true>,
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false, false>
+                                                : (const void *)DitherKernel<true, false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)dither_lds));
+    if (dither_parts > 1)
+        TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel<false, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true, 256>
                                                      : (const void *)BandNodesKernel<false, kBandLanes>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2179,6 +2305,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         gb.band_nf     = b.band_nf + o * g.bands * g.band_ne;
         gb.band_cnt    = b.band_cnt + o * g.bands * 4;
         gb.pad_rows    = b.pad_rows + o * w * 5;
+        gb.xwg         = b.xwg + o * (kDitherMaxParts - 1) * XwgStride(w);
         gb.out         = b.out + o * b.out_cap;
         gb.out_len     = b.out_len + o;
 
@@ -2193,10 +2320,13 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
             hipLaunchKernelGGL(DitherFirstHitKernel, dim3(nfr), dim3(64), first_hit_lds, gs, g, gb);
         } else {
             hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
-            if (w > 2)
-                hipLaunchKernelGGL(DitherKernel<false>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+            if (dither_parts > 1)
+                hipLaunchKernelGGL((DitherKernel<false, true>), dim3(dither_parts, nfr), dim3((split_share + 2) * 64),
+                                   split_lds, gs, g, gb);
+            else if (w > 2)
+                hipLaunchKernelGGL((DitherKernel<false, false>), dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
             else
-                hipLaunchKernelGGL(DitherKernel<true>, dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+                hipLaunchKernelGGL((DitherKernel<true, false>), dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
         }
         if (wide_bands)
             hipLaunchKernelGGL((BandNodesKernel<true, 256>), dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);

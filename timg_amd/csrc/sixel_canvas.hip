@@ -2192,8 +2192,9 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     b.out_len    = (unsigned long long *)(base + o_len);
 
     // one wave per 32 rows, as many as the boundary rows leave room for next to the tables.
-    // (MEASURED, MI355X 800x450: spreading a frame over two workgroups / CUs with a global-memory
-    // bridge between them was not faster.)
+    // (one workgroup per frame: small frames, and the fallback of the multi-CU placement below.  Round 1's
+    // two-CU version, whose DIFFUSING waves read the bridge in global memory themselves, was not faster;
+    // the one below keeps the memory round trips in helper waves)
     int dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + kPairRows - 1) / kPairRows));
     auto dither_bytes = [&](int waves) {
         return (8192 + 512 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);

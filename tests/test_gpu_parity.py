@@ -359,6 +359,53 @@ def test_sixel_diffusion_spread_over_several_cus(hip, oracle, monkeypatch, parts
         assert got == oracle.sixel_encode(fb, BG, lookup_mode=1), (parts, kind, w1, h1)
 
 
+def test_sixel_diffusion_hand_over_under_uneven_load(hip):
+    """The memory hand-over between the parts of a frame, with the chip shared unevenly: three contexts on three host
+    threads encode batches of different sizes at the same time (192 + 64 + 7 frames' worth of workgroups queue for 256
+    CUs, parts of different batches interleave on the queues) while a fourth thread keeps a scale kernel streaming.
+    Every byte of every step equals what the same context produced alone."""
+    import threading
+    import torch
+    from timg_amd.pipeline import synth_frames_on_device
+    w, h = 800, 450
+    sizes = (48, 16, 7)
+    ctxs = [timg_amd.TimgHip(0) for _ in sizes]
+    srcs = [synth_frames_on_device(n, w, h, ("photo", "noise", "alpha")[i], seed=60 + i) for i, n in enumerate(sizes)]
+    torch.cuda.synchronize()
+    blend = timg_amd.Blend.make(BG, PAT, 4, 4)
+
+    def encode(i):
+        return ctxs[i].sixel_encode(srcs[i].data_ptr(), w, h, pad_blend=blend, n_frames=sizes[i],
+                                    out_cap=ctxs[i].sixel_max_bytes(w, h) * 4)
+    alone = [encode(i) for i in range(len(sizes))]
+    big = synth_frames_on_device(16, 3840, 2160, "photo", seed=9)
+    dst = torch.empty((16, 450, 800, 4), dtype=torch.uint8, device="cuda")
+    sc = hip.scaler(3840, 2160, 800, 450)
+    stop, bad = threading.Event(), []
+
+    def streamer():
+        st = torch.cuda.Stream()
+        while not stop.is_set():
+            hip.scale_blend(sc, big.data_ptr(), dst.data_ptr(), 16, blend, stream=st.cuda_stream)
+            st.synchronize()
+
+    def worker(i):
+        for rep in range(6):
+            if encode(i) != alone[i]:
+                bad.append((i, rep))
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(sizes))] + [threading.Thread(target=streamer)]
+    for t in ths:
+        t.start()
+    for t in ths[:-1]:
+        t.join()
+    stop.set()
+    ths[-1].join()
+    sc.close()
+    for c in ctxs:
+        c.close()
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("kind,w,h", [("photo", 320, 203), ("alpha", 200, 100), ("noise", 97, 61), ("photo", 64, 7),
                                       ("noise", 33, 6), ("photo", 2, 13), ("alpha", 1, 1), ("photo", 800, 450)])
 def test_sixel_first_hit_lookup_is_libsixels_cache(hip, oracle, kind, w, h):

@@ -642,8 +642,8 @@ def main():
 
     if n_extra > 1:
         # Same K steps on n_extra concurrent batched streams (extra information, outside the
-        # timed region above): the serial stages of the sixel canvas keep only ~64 CUs busy, so
-        # consecutive batches overlap on the chip.  Kernel durations are NOT comparable with the
+        # timed region above): the serial stages of the sixel canvas keep only part of the chip busy (the
+        # median cut one CU per frame, the diffusion four), so consecutive batches overlap on the chip.  Kernel durations are NOT comparable with the
         # roofline object in this mode (concurrent kernels share the chip).
         run_steps(max(args.warmup, n_extra), None, n_extra)
         k_extra = max(args.steps, 2 * n_extra)

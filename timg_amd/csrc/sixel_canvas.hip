@@ -236,7 +236,7 @@ constexpr int kCutLdsEntries = 12288;             // colour table kept in LDS up
 // words of per-wave scratch: [64][33] 16-bit counters (a lane's segment of a box and every
 // exclusive prefix stay below 65536: a box has at most 32768 colours) plus 32 + 32 key totals /
 // bases; the medium path uses the first 256 words as its permutation buffer instead
-constexpr int kCutScratch    = 64 * 33 / 2 + 64;
+constexpr int kCutScratch    = 64 * 17;  // per wave: 64 rows of 16 words (32 packed 16-bit counters) + 1 spare word
 constexpr size_t kCutLdsBytes =
     ((size_t)2 * kCutLdsEntries + (size_t)kCutWaves * kCutScratch) * sizeof(uint32_t);
 
@@ -259,9 +259,12 @@ struct CutBox {
 // the median.  scratch: kCutScratch words owned by this wave.
 __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *scratch, int lane,
                          uint32_t *median_out, uint32_t *lowersum_out) {
-    uint16_t *lane_cnt    = reinterpret_cast<uint16_t *>(scratch);  // [64][33]
-    uint32_t *s_key_total = scratch + 64 * 33 / 2;                  // [32]
-    uint32_t *s_key_base  = s_key_total + 32;                       // [32]
+    // large path: lane l counts its segment's keys in row l -- 32 sixteen-bit counters packed into 16 words, rows 17
+    // words apart (an odd stride: the lanes' rows start on different banks); the spare 17th word of row k holds the
+    // base of key k in the sorted box
+    uint16_t *lane_cnt    = reinterpret_cast<uint16_t *>(scratch);  // [64][34]
+    constexpr int kRow16  = 34;
+    auto key_base  = [&](uint32_t k) -> uint32_t & { return scratch[k * 17 + 16]; };
     uint32_t *perm        = scratch;  // [256]: the medium path's permutation buffer (never together with lane_cnt)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t *src = tab[box.buf] + box.ind;
@@ -271,10 +274,15 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
 
     // per-plane extent of the box (5-bit keys): which key values occur, OR-ed over the wave
     uint32_t seen[3] = {0, 0, 0};
-    for (uint32_t i = lane; i < box.colors; i += 64) {
-        const uint32_t e = src[i];
+    // (eight loads in flight: one load per iteration makes a box of thousands of colours a chain of LDS round trips)
+    for (uint32_t i = lane; i < box.colors; i += 8 * 64) {
+        uint32_t e[8];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) seen[p] |= 1u << PlaneKey(e, p);
+        for (int q = 0; q < 8; ++q) e[q] = src[min(i + q * 64, box.colors - 1)];  // (past the end: the last colour again)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) seen[p] |= 1u << PlaneKey(e[q], p);
     }
     uint32_t mn[3], mx[3];
 #pragma unroll
@@ -391,55 +399,96 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
     } else {
         // ---- large box: stable counting sort, one contiguous segment per lane -
         // (odd segment length keeps the lanes on different LDS banks)
+        // A chain of "load an entry, read-modify-write its counter" per entry made the root box (6 000 colours, 92
+        // entries a lane) cost 33 us and the first six rounds 78 of the kernel's 290: every step waited for two LDS
+        // round trips.  Now the entries are fetched four at a time, counting is a fire-and-forget ds_add on the packed
+        // counters (no result, nothing to wait for), the prefix over the lanes reads its 32 counters into registers and
+        // writes them back once, and the scatter's four fetch-and-adds are in flight together.
         const uint32_t seg = (((box.colors + 63) / 64) | 1u);
         const uint32_t a   = min(box.colors, (uint32_t)lane * seg);
         const uint32_t z   = min(box.colors, a + seg);
-        uint16_t *mine     = lane_cnt + lane * 33;
-        for (int k = 0; k < 32; ++k) mine[k] = 0;
-        for (uint32_t i = a; i < z; ++i) mine[PlaneKey(src[i], plane)] += 1;
+        uint32_t *mine_w   = scratch + lane * 17;  // counters of keys 2w and 2w + 1 in the halves of word w
+        for (int k = 0; k < 16; ++k) mine_w[k] = 0;
+        for (uint32_t i = a; i < z; i += 4) {
+            uint32_t e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = src[min(i + q, z - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t k = PlaneKey(e[q], plane);
+                if (i + q < z)
+                    (void)__hip_atomic_fetch_add(&mine_w[k >> 1], 1u << ((k & 1u) * 16), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
         TIMG_WAVE_SYNC();
         // exclusive prefix over the lanes, per key: lanes 0-31 take key = lane for the
         // lower half of the lanes, lanes 32-63 the same key for the upper half
         {
             const int key = lane & 31, l0 = (lane >> 5) * 32;
-            uint32_t run = 0;
-            for (int l = l0; l < l0 + 32; ++l) {
-                const uint32_t t       = lane_cnt[l * 33 + key];
-                lane_cnt[l * 33 + key] = (uint16_t)run;
-                run += t;
+            uint32_t t[32], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) t[q] = lane_cnt[(l0 + q) * kRow16 + key];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) sum += t[q];
+            const uint32_t other = __shfl_xor(sum, 32);  // the other half's total for this key
+            uint32_t run         = lane < 32 ? 0u : other;  // (the lower lanes' entries stand in front)
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                lane_cnt[(l0 + q) * kRow16 + key] = (uint16_t)run;
+                run += t[q];
             }
-            TIMG_WAVE_SYNC();
-            const uint32_t other = __shfl_xor(run, 32);     // the other half's total for this key
-            const uint32_t lower = lane < 32 ? run : other;  // total of lanes 0-31 for this key
-            if (lane >= 32)
-                for (int l = 32; l < 64; ++l) lane_cnt[l * 33 + key] = (uint16_t)(lane_cnt[l * 33 + key] + lower);
-            const uint32_t total = run + other;
-            if (lane < 32) s_key_total[lane] = total;
+            const uint32_t total = sum + other;
             const uint32_t incl = WaveInclusiveAdd(lane < 32 ? total : 0u);
-            if (lane < 32) s_key_base[lane] = incl - total;
+            if (lane < 32) key_base(lane) = incl - total;
         }
         TIMG_WAVE_SYNC();
-        for (uint32_t i = a; i < z; ++i) {
-            const uint32_t e   = src[i];
-            const uint32_t k   = PlaneKey(e, plane);
-            const uint32_t off = mine[k];
-            mine[k]            = (uint16_t)(off + 1);
-            dst[s_key_base[k] + off] = e;
+        for (uint32_t i = a; i < z; i += 4) {
+            uint32_t e[4], k[4], was[4], kb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = src[min(i + q, z - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                k[q]   = PlaneKey(e[q], plane);
+                kb[q]  = key_base(k[q]);
+                // (issued in order: two entries of one key take consecutive places; an entry past the segment adds 0)
+                was[q] = __hip_atomic_fetch_add(&mine_w[k[q] >> 1], i + q < z ? 1u << ((k[q] & 1u) * 16) : 0u,
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q < z) dst[kb[q] + ((was[q] >> ((k[q] & 1u) * 16)) & 0xffffu)] = e[q];
         }
         __threadfence_block();
         TIMG_WAVE_SYNC();
-        // median: the lane whose segment of the sorted box holds the crossing walks it
+        // median: the lane whose segment of the sorted box holds the crossing finds it (no early exit: the loads
+        // of a loop that may leave cannot be issued ahead)
         uint32_t seg_sum = 0;
-        for (uint32_t i = a; i < z; ++i) seg_sum += dst[i] >> 15;
+        for (uint32_t i = a; i < z; i += 8) {
+            uint32_t c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c[q] = dst[min(i + q, z - 1)] >> 15;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) seg_sum += i + q < z ? c[q] : 0u;
+        }
         uint32_t run  = WaveInclusiveAdd(seg_sum) - seg_sum;  // P(a)
         uint32_t cand = 0xffffffffu, cand_sum = 0;
-        for (uint32_t i = a; i < z; ++i) {
-            if (i >= 1 && run >= half) {
-                cand     = i;
-                cand_sum = run;
-                break;
+        // (a lane whose segment ends below half has no candidate; the lanes behind the crossing find theirs at their
+        // first entry, the lane of the crossing inside its segment -- the walk ends, wave-uniformly, when they all have)
+        const bool mine = run + seg_sum >= half;
+        for (uint32_t i = a; i < z; i += 8) {
+            if (!__any(mine && cand == 0xffffffffu)) break;
+            uint32_t c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c[q] = dst[min(i + q, z - 1)] >> 15;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (i + q < z && cand == 0xffffffffu && i + q >= 1 && run >= half) {
+                    cand     = i + q;
+                    cand_sum = run;
+                }
+                run += i + q < z ? c[q] : 0u;
             }
-            run += dst[i] >> 15;
         }
         const unsigned long long hit = __ballot(cand != 0xffffffffu);
         if (hit) {

@@ -8,6 +8,7 @@
 
 #include "gfx_layout.h"
 #include "resample_plan.h"
+#include "sixel_launch.h"
 
 extern "C" int timg_hip_debug_plan_dump(int sw, int sh, int in_fmt, int dw, int dh, int filter,
                                         int *header, int *h_taps, float *h_coeff,
@@ -99,4 +100,25 @@ extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, i
         for (uint32_t c = 1; c < f.n_kitty_chunks; ++c) KittySeparator(f, c, out + KittySeparatorOffset(f, c));
     GfxTrailer(f, out);
     return (long)f.total;
+}
+
+// The sixel kernels' launch geometry for a frame of w x h6 (padded height) in a batch of n_frames on a device of
+// cu_count CUs (sixel_launch.h; waves_cap / parts_env as TIMG_HIP_DITHER_WAVES / TIMG_HIP_DITHER_PARTS, 0 / -1: not
+// set).  out[12]: band_ne, dither_waves, dither_lds, dither_parts, split_share, split_lds, wide_bands, nodes_lds,
+// emit_lds, lds budget of a workgroup, the diffusion's static LDS allowance, kDitherMaxWaves.
+extern "C" void timg_hip_debug_sixel_launch(int w, int h6, int n_frames, int cu_count, int waves_cap, int parts_env,
+                                            long out[12]) {
+    const timg_amd::SixelLaunch L = timg_amd::PlanSixelLaunch(w, h6, n_frames, cu_count, waves_cap, parts_env);
+    out[0]  = L.band_ne;
+    out[1]  = L.dither_waves;
+    out[2]  = (long)L.dither_lds;
+    out[3]  = L.dither_parts;
+    out[4]  = L.split_share;
+    out[5]  = (long)L.split_lds;
+    out[6]  = L.wide_bands ? 1 : 0;
+    out[7]  = (long)L.nodes_lds;
+    out[8]  = (long)L.emit_lds;
+    out[9]  = timg_amd::kSixelLdsBudget;
+    out[10] = (long)timg_amd::kDitherStaticLds;
+    out[11] = timg_amd::kDitherMaxWaves;
 }

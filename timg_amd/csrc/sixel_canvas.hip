@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "context.h"
+#include "sixel_launch.h"
 #include "wave_ops.h"
 #include "pixel_math.h"
 
@@ -29,16 +30,7 @@ namespace timg_amd {
 namespace {
 
 constexpr int kMaxColors     = 256;
-// A band has at most 6 * width (colour, column) entries.  Up to kLdsEntries of them the band
-// kernels sort in LDS; wider frames (up to kMaxSixelWidth: columns travel in 12-bit fields)
-// use the same code on global-memory scratch.
-constexpr int kLdsEntries    = 8192;
-// The diffusion of a frame spread over several workgroups (CUs): hand-over buffer of one boundary between two of them -- the
-// boundary row's (W + 2) x 3 words, then (in a cache line of its own) the producer's progress counter
-constexpr int kDitherMaxParts = 8;
-__host__ __device__ inline int XwgData(int w) { return ((w + 2) * 3 + 31) & ~31; }
-__host__ __device__ inline int XwgStride(int w) { return XwgData(w) + 32; }
-constexpr int kMaxSixelWidth = 4095;
+// (kLdsEntries, kMaxSixelWidth, the diffusion's and the band kernels' launch geometry: sixel_launch.h)
 
 struct SixelGeom {
     int w, h, h6;        // frame, padded height
@@ -868,7 +860,6 @@ __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b)
 //  * all hand-over traffic is LDS traffic of the form "data, then counter" from ONE wave,
 //    which the LDS executes in order: no fence (a workgroup fence would drain the wave's
 //    global prefetches), only relaxed atomics and compiler barriers.
-constexpr int kDitherMaxWaves = 16;
 constexpr int kDitherAhead    = 8;  // source pixels are requested this many steps early
 
 // wave_shr:1 -- every lane receives the value of the lane below it in index
@@ -893,7 +884,6 @@ __device__ __forceinline__ PairI16 ApplyPair(PairI16 v, uint32_t q) {
     return __builtin_elementwise_add_sat(v, AsPair(q));
 }
 
-constexpr int kPairRows       = 32;  // rows per wave
 constexpr int kDitherSpinLimit = 1 << 22;
 
 // kNarrow: frames of 1 or 2 columns, where the row-wrap term and the 7/16 term come from
@@ -1388,15 +1378,6 @@ __device__ __forceinline__ int RunBytes(int count) {
     const int full = count > 255 ? (count - 1) / 255 : 0;
     const int rest = count - 255 * full;  // 1..255 (0 only for count == 0)
     return 5 * full + (rest > 3 ? 2 + NumLen((uint32_t)rest) : rest);
-}
-
-// LDS layout of BandNodesKernel for frames whose bands sort in LDS (words; shared by the kernel and its launch)
-__host__ __device__ inline int BandBitmapWords(int w) { return ((w + 31) >> 5) | 1; }
-__host__ __device__ inline int BandBucketWords(int w) { return (w + 8) & ~1; }
-__host__ __device__ inline int BandNodesSharedWords(int w, int ne) {  // bitmap phase and node phase, one after the other
-    const int nws = BandBitmapWords(w), nwp = (nws + 1) >> 1;
-    const int a = 256 * nws + 128 * nwp + 256, b = BandBucketWords(w) + ne + ne / 2;
-    return a > b ? a : b;
 }
 
 template <int kT = 256>
@@ -2192,7 +2173,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_bb    = carve(nf * g.bands * g.band_cap);
     const size_t o_bm    = carve(nf * g.bands * 4 * sizeof(int));
     const size_t o_bo    = carve(nf * g.bands * 2 * sizeof(uint32_t));
-    g.band_ne            = ((6 * w + 63) / 64) * 64;
+    g.band_ne            = BandEntries(w);
     const size_t n_band  = nf * g.bands;
     const size_t o_bent  = carve(n_band * g.band_ne * 4);
     const size_t o_bkey  = carve(n_band * g.band_ne * 4);
@@ -2240,49 +2221,17 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     b.out_cap    = out_cap;
     b.out_len    = (unsigned long long *)(base + o_len);
 
-    // one wave per 32 rows, as many as the boundary rows leave room for next to the tables.
-    // (one workgroup per frame: small frames, and the fallback of the multi-CU placement below.  Round 1's
-    // two-CU version, whose DIFFUSING waves read the bridge in global memory themselves, was not faster;
-    // the one below keeps the memory round trips in helper waves)
-    int dither_waves = std::max(1, std::min(kDitherMaxWaves, (g.h6 + kPairRows - 1) / kPairRows));
-    auto dither_bytes = [&](int waves) {
-        return (8192 + 512 + (size_t)(waves + 1) * 3 * (w + 2)) * sizeof(uint32_t);
-    };
-    if (const char *cap = getenv("TIMG_HIP_DITHER_WAVES")) dither_waves = std::max(1, std::min(dither_waves, atoi(cap)));
-    const bool waves_capped = getenv("TIMG_HIP_DITHER_WAVES") != nullptr;
-    // (the kernel's static LDS -- the progress counters -- comes on top of the dynamic part)
-    while (dither_waves > 1 && dither_bytes(dither_waves) > 160 * 1024 - 512) --dither_waves;
-    const size_t dither_lds = dither_bytes(dither_waves);
-    // Frames of eight row groups and more are spread over several workgroups = CUs (DitherKernel<., true>): about
-    // four row groups a part (one wave per SIMD: 800x450 measured 644 / 587 / 557 / 522 us per 64 frames with
-    // 1 / 2 / 3 / 4 parts), no more parts than the batch leaves CUs for (parts of frames that wait for a CU while
-    // others spin cost more than they win), or what TIMG_HIP_DITHER_PARTS asks for; then the fewest parts from
-    // there whose largest share of the row groups (+ fetcher + flusher) fits a workgroup and its LDS; 1: one
-    // workgroup per frame.
-    const int dither_groups = (g.h6 + kPairRows - 1) / kPairRows;
-    int dither_parts        = 1;
-    if (w > 2 && dither_groups >= 8 && !waves_capped) {
-        int want = std::min(std::min((dither_groups + 3) / 4, kDitherMaxParts), std::max(1, ctx->cu_count / n_frames));
-        if (const char *e = getenv("TIMG_HIP_DITHER_PARTS")) want = atoi(e);
-        for (int p = std::max(want, 1); p > 1 && p <= kDitherMaxParts; ++p) {
-            const int share = (dither_groups + p - 1) / p;
-            if (share + 2 <= kDitherMaxWaves && dither_bytes(share + 1) <= 160 * 1024 - 512) {
-                dither_parts = p;
-                break;
-            }
-        }
-    }
-    const int split_share     = dither_parts > 1 ? (dither_groups + dither_parts - 1) / dither_parts : 0;
-    const size_t split_lds    = dither_parts > 1 ? dither_bytes(split_share + 1) : 0;
-    const bool wide_bands   = g.band_ne > kLdsEntries;  // sort buffers in global scratch
-#ifndef TIMG_BAND_LANES
-#define TIMG_BAND_LANES 512
-#endif
-    constexpr int kBandLanes = TIMG_BAND_LANES;  // lanes per band of BandNodesKernel (narrow frames)
-    const size_t nodes_lds =
-        wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
-                   : ((size_t)BandNodesSharedWords(w, g.band_ne) + g.band_ne + 16) * sizeof(uint32_t);
-    const size_t emit_lds   = (size_t)g.band_ne * sizeof(uint32_t);
+    // which kernels, how many waves / workgroups per frame, how much LDS: sixel_launch.h.  (One workgroup per frame
+    // for the diffusion: small frames, and the fallback of the multi-CU placement.  Round 1's two-CU version, whose
+    // DIFFUSING waves read the bridge in global memory themselves, was not faster; DitherKernel<., true> keeps the
+    // memory round trips in helper waves.)
+    const char *waves_env = getenv("TIMG_HIP_DITHER_WAVES"), *parts_env = getenv("TIMG_HIP_DITHER_PARTS");
+    const SixelLaunch plan = PlanSixelLaunch(w, g.h6, n_frames, ctx->cu_count, waves_env ? std::max(1, atoi(waves_env)) : 0,
+                                             parts_env ? std::max(0, atoi(parts_env)) : -1);
+    const int dither_waves = plan.dither_waves, dither_parts = plan.dither_parts, split_share = plan.split_share;
+    const size_t dither_lds = plan.dither_lds, split_lds = plan.split_lds;
+    const bool wide_bands   = plan.wide_bands;  // sort buffers in global scratch
+    const size_t nodes_lds = plan.nodes_lds, emit_lds = plan.emit_lds;
     // both kernels need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false, false>
                                                 : (const void *)DitherKernel<true, false>,

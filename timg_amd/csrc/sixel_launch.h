@@ -1,0 +1,104 @@
+// timg_amd/csrc/sixel_launch.h -- launch geometry of the sixel kernels as a function of the frame size: which
+// kernel variants run, with how many waves / workgroups per frame and how much dynamic LDS.  Shared by
+// sixel_canvas.hip (which launches by it) and the test-only libtimg_hip_debug.so (tests/test_sixel_launch.py sweeps
+// every width and a ladder of heights on the CPU: a geometry whose tables fill the LDS to the byte failed to launch
+// once -- 766 columns, round 2 -- and was found by a random stress run on the GPU, not by a test).
+#ifndef TIMG_AMD_SIXEL_LAUNCH_H_
+#define TIMG_AMD_SIXEL_LAUNCH_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace timg_amd {
+
+constexpr int kSixelLdsBudget = 160 * 1024;  // LDS of one CU = the most one workgroup can have (static + dynamic)
+
+// A band has at most 6 * width (colour, column) entries.  Up to kLdsEntries of them the band
+// kernels sort in LDS; wider frames (up to kMaxSixelWidth: columns travel in 12-bit fields)
+// use the same code on global-memory scratch.
+constexpr int kLdsEntries    = 8192;
+constexpr int kMaxSixelWidth = 4095;
+constexpr int kBandLanes     = 512;  // lanes per band of BandNodesKernel (frames whose bands sort in LDS)
+
+// diffusion (DitherKernel)
+constexpr int kDitherMaxWaves = 16;
+constexpr int kPairRows       = 32;  // rows per wave
+// The diffusion of a frame spread over several workgroups (CUs): hand-over buffer of one boundary between two of
+// them -- the boundary row's (W + 2) x 3 words, then (in a cache line of its own) the producer's progress counter
+constexpr int kDitherMaxParts = 8;
+__host__ __device__ inline int XwgData(int w) { return ((w + 2) * 3 + 31) & ~31; }
+__host__ __device__ inline int XwgStride(int w) { return XwgData(w) + 32; }
+// dynamic LDS of a diffusion workgroup that writes `rows` boundary rows (+ the one that stays zero): the 15-bit
+// table (32 KB), the palette (2 KB), the boundary rows
+inline size_t DitherLdsBytes(int w, int rows) {
+    return (8192 + 512 + (size_t)(rows + 1) * 3 * (size_t)(w + 2)) * sizeof(uint32_t);
+}
+constexpr size_t kDitherStaticLds = 512;  // (the progress counters, rounded up generously)
+
+// LDS layout of BandNodesKernel for frames whose bands sort in LDS (words)
+__host__ __device__ inline int BandBitmapWords(int w) { return ((w + 31) >> 5) | 1; }
+__host__ __device__ inline int BandBucketWords(int w) { return (w + 8) & ~1; }
+__host__ __device__ inline int BandNodesSharedWords(int w, int ne) {  // bitmap phase and node phase, one after the other
+    const int nws = BandBitmapWords(w), nwp = (nws + 1) >> 1;
+    const int a = 256 * nws + 128 * nwp + 256, b = BandBucketWords(w) + ne + ne / 2;
+    return a > b ? a : b;
+}
+inline int BandEntries(int w) { return ((6 * w + 63) / 64) * 64; }
+
+struct SixelLaunch {
+    int band_ne;          // entries a band can have (rounded up to 64)
+    int dither_waves;     // one workgroup per frame: its waves (frames with more row groups go round again) ...
+    size_t dither_lds;    // ... and its dynamic LDS
+    int dither_parts;     // > 1: DitherKernel<., true> with this many workgroups per frame ...
+    int split_share;      // ... the largest part's row groups (its block has split_share + 2 waves) ...
+    size_t split_lds;     // ... and its dynamic LDS
+    bool wide_bands;      // the band kernels sort in global scratch
+    size_t nodes_lds, emit_lds;
+};
+
+// waves_cap: TIMG_HIP_DITHER_WAVES (0: not set); parts_env: TIMG_HIP_DITHER_PARTS (< 0: not set)
+inline SixelLaunch PlanSixelLaunch(int w, int h6, int n_frames, int cu_count, int waves_cap, int parts_env) {
+    SixelLaunch L{};
+    L.band_ne = BandEntries(w);
+    // one wave per 32 rows, as many as the boundary rows leave room for next to the tables
+    const int groups = (h6 + kPairRows - 1) / kPairRows;
+    int waves        = groups < 1 ? 1 : (groups > kDitherMaxWaves ? kDitherMaxWaves : groups);
+    if (waves_cap > 0 && waves > waves_cap) waves = waves_cap;
+    while (waves > 1 && DitherLdsBytes(w, waves) > kSixelLdsBudget - kDitherStaticLds) --waves;
+    L.dither_waves = waves;
+    L.dither_lds   = DitherLdsBytes(w, waves);
+    // Frames of eight row groups and more are spread over several workgroups = CUs (DitherKernel<., true>): about
+    // four row groups a part (one wave per SIMD: 800x450 measured 644 / 587 / 557 / 522 us per 64 frames with
+    // 1 / 2 / 3 / 4 parts), no more parts than the batch leaves CUs for (parts of frames that wait for a CU while
+    // others spin cost more than they win), or what TIMG_HIP_DITHER_PARTS asks for; then the fewest parts from
+    // there whose largest share of the row groups (+ fetcher + flusher) fits a workgroup and its LDS; 1: one
+    // workgroup per frame.
+    L.dither_parts = 1;
+    if (w > 2 && groups >= 8 && waves_cap <= 0) {
+        int by_cus = n_frames > 0 ? cu_count / n_frames : cu_count;
+        if (by_cus < 1) by_cus = 1;
+        int want = (groups + 3) / 4;
+        if (want > kDitherMaxParts) want = kDitherMaxParts;
+        if (want > by_cus) want = by_cus;
+        if (parts_env >= 0) want = parts_env;
+        for (int p = want < 1 ? 1 : want; p > 1 && p <= kDitherMaxParts; ++p) {
+            const int share = (groups + p - 1) / p;
+            if (share + 2 <= kDitherMaxWaves && DitherLdsBytes(w, share + 1) <= kSixelLdsBudget - kDitherStaticLds) {
+                L.dither_parts = p;
+                break;
+            }
+        }
+    }
+    L.split_share = L.dither_parts > 1 ? (groups + L.dither_parts - 1) / L.dither_parts : 0;
+    L.split_lds   = L.dither_parts > 1 ? DitherLdsBytes(w, L.split_share + 1) : 0;
+    L.wide_bands  = L.band_ne > kLdsEntries;
+    L.nodes_lds   = L.wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
+                                 : ((size_t)BandNodesSharedWords(w, L.band_ne) + L.band_ne + 16) * sizeof(uint32_t);
+    L.emit_lds    = (size_t)L.band_ne * sizeof(uint32_t);
+    return L;
+}
+
+}  // namespace timg_amd
+
+#endif  // TIMG_AMD_SIXEL_LAUNCH_H_

@@ -328,6 +328,40 @@ def test_sixel_geometry_corner_cases(hip, oracle, kind, w, h):
     assert len(got) == len(want) and got == want, (len(got), len(want))
 
 
+@pytest.mark.parametrize("trips", [1, 2])
+@pytest.mark.parametrize("kind,w,h,parts", [
+    ("photo", 800, 450, -1),   # the bench frame: four parts of four row groups
+    ("noise", 800, 450, 1),    # ... in one workgroup (five waves beside the colour tables, twelve beside the small ones)
+    ("alpha", 320, 203, -1),   # seven row groups: one workgroup
+    ("photo", 100, 56, -1),    # narrower than a wave's skew + the index delay (no column is ever "steady")
+    ("noise", 33, 6, -1),
+    ("photo", 3, 130, -1),
+    ("alpha", 801, 77, -1),    # odd width: the last group of four indices is completed by junk in the row's padding
+    ("photo", 802, 64, -1), ("photo", 803, 64, -1),
+    ("photo", 1920, 1080, -1), # a full-HD frame alone: twelve parts of three row groups (small tables)
+    ("noise", 1000, 500, -1),
+    ("photo", 4095, 40, -1),   # the widest frame: one wave, ONE boundary row beside the colour tables (it follows itself)
+    ("photo", 2600, 100, -1),  # one wave going round four times on that one row
+    ("photo", 64, 1100, 3),    # parts of 12 / 12 / 11 row groups
+])
+def test_sixel_both_lookup_forms(hip, oracle, monkeypatch, kind, w, h, parts, trips):
+    """DitherKernel<., ., kOneTrip>: the palette colour of a cell in ONE LDS round trip on the serial chain (96 KB of
+    colour tables, the palette index from memory kDitherAhead steps later) or in two (cell -> index -> colour, 34 KB).
+    sixel_launch.h picks by geometry; TIMG_HIP_DITHER_TRIPS forces either -- both give the oracle's bytes for every
+    placement (one workgroup, parts, a single wave that follows itself)."""
+    monkeypatch.setenv("TIMG_HIP_DITHER_TRIPS", str(trips))
+    if parts >= 0:
+        monkeypatch.setenv("TIMG_HIP_DITHER_PARTS", str(parts))
+    fb = synth.make(kind, w, h, seed=23)
+    got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3),
+                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 5, 3, lookup_mode=1)
+    if got != want:
+        n = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
+        raise AssertionError(f"len {len(got)} vs {len(want)}, first diff at {n}: "
+                             f"{got[max(0, n - 20):n + 20]!r} vs {want[max(0, n - 20):n + 20]!r}")
+
+
 @pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])
 def test_sixel_diffusion_spread_over_several_cus(hip, oracle, monkeypatch, parts):
     """Frames of eight row groups and more are diffused by several workgroups (CUs) per frame, the boundary row

@@ -18,7 +18,7 @@ import sys
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"global_load_dwordx4 v\[(\d+):(\d+)\]")
-LOAD1 = re.compile(r"global_load_dword v(\d+),")  # (the sixel diffusion's one-pixel ring)
+LOAD1 = re.compile(r"global_load_(?:dword|ubyte) v(\d+),")  # (the sixel diffusion's one-pixel ring)
 WAIT = re.compile(r"s_waitcnt vmcnt\(\d+\) ; ring (.*)")
 
 

@@ -104,11 +104,12 @@ extern "C" long timg_hip_debug_gfx_emulate(int kind, const uint8_t *fb, int w, i
 
 // The sixel kernels' launch geometry for a frame of w x h6 (padded height) in a batch of n_frames on a device of
 // cu_count CUs (sixel_launch.h; waves_cap / parts_env as TIMG_HIP_DITHER_WAVES / TIMG_HIP_DITHER_PARTS, 0 / -1: not
-// set).  out[12]: band_ne, dither_waves, dither_lds, dither_parts, split_share, split_lds, wide_bands, nodes_lds,
-// emit_lds, lds budget of a workgroup, the diffusion's static LDS allowance, kDitherMaxWaves.
+// set; trips: TIMG_HIP_DITHER_TRIPS, 0: chosen by the plan).  out[13]: band_ne, dither_waves, dither_lds, dither_parts,
+// split_share, split_lds, wide_bands, nodes_lds, emit_lds, lds budget of a workgroup, the diffusion's static LDS
+// allowance, kDitherMaxWaves, one_trip.
 extern "C" void timg_hip_debug_sixel_launch(int w, int h6, int n_frames, int cu_count, int waves_cap, int parts_env,
-                                            long out[12]) {
-    const timg_amd::SixelLaunch L = timg_amd::PlanSixelLaunch(w, h6, n_frames, cu_count, waves_cap, parts_env);
+                                            int trips, long out[13]) {
+    const timg_amd::SixelLaunch L = timg_amd::PlanSixelLaunch(w, h6, n_frames, cu_count, waves_cap, parts_env, trips);
     out[0]  = L.band_ne;
     out[1]  = L.dither_waves;
     out[2]  = (long)L.dither_lds;
@@ -121,4 +122,5 @@ extern "C" void timg_hip_debug_sixel_launch(int w, int h6, int n_frames, int cu_
     out[9]  = timg_amd::kSixelLdsBudget;
     out[10] = (long)timg_amd::kDitherStaticLds;
     out[11] = timg_amd::kDitherMaxWaves;
+    out[12] = L.one_trip ? 1 : 0;
 }

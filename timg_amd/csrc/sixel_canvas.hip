@@ -51,6 +51,7 @@ struct SixelFrameScratch {
     uint32_t *tab_a;       // [32768]
     uint32_t *tab_b;       // [32768]
     uint32_t *lut;         // [32768] idx | r<<8 | g<<16 | b<<24
+    uint8_t *lut8;         // [32768] idx alone, indexed by the BIASED cell (cell ^ kCellBias): what the diffusion looks up
     uint8_t *palette;      // [768]
     int *meta;             // [0]=ncolors [1]=dither
     uint8_t *index;        // [h6 * w]
@@ -75,6 +76,7 @@ struct SixelFrameScratch {
 struct SixelBatch {
     const uint8_t *fb;
     uint32_t *entries, *tab_a, *tab_b, *lut;
+    uint8_t *lut8;
     uint8_t *palette;
     int *meta;
     uint8_t *index;
@@ -102,6 +104,7 @@ __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, c
     s.tab_a      = b.tab_a + (size_t)f * 32768;
     s.tab_b      = b.tab_b + (size_t)f * 32768;
     s.lut        = b.lut + (size_t)f * 32768;
+    s.lut8       = b.lut8 + (size_t)f * 32768;
     s.palette    = b.palette + (size_t)f * 768;
     s.meta       = b.meta + (size_t)f * 4;
     s.index      = b.index + (size_t)f * g.h6 * g.idx_stride;
@@ -789,6 +792,9 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 }
 
 // ---- K3: 15-bit cell -> nearest palette entry ----------------------------------------
+// The diffusion holds a channel c as the signed number c - 128 (see "Number format" there), so the 5-bit field it
+// cuts out of a channel is (c >> 3) ^ 16: it indexes its tables with the BIASED cell = cell ^ kCellBias.
+constexpr uint32_t kCellBias = 0x4210u;
 __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b) {
     const int f               = blockIdx.y;
     const SixelFrameScratch s = FrameScratch(b, g, f);
@@ -821,6 +827,8 @@ __global__ void __launch_bounds__(256) BuildLutKernel(SixelGeom g, SixelBatch b)
     const int b0 = k0 & 255, b1 = k1 & 255;
     s.lut[cell0] = (uint32_t)b0 | (pal[b0].x << 8);
     s.lut[cell1] = (uint32_t)b1 | (pal[b1].x << 8);
+    s.lut8[cell0 ^ kCellBias] = (uint8_t)b0;
+    s.lut8[cell1 ^ kCellBias] = (uint8_t)b1;
     // the hand-over counters of a diffusion spread over several CUs start at zero (the kernel boundary in
     // front of DitherKernel publishes these plain stores)
     if (blockIdx.x == 0 && threadIdx.x < kDitherMaxParts - 1)
@@ -900,8 +908,15 @@ constexpr int kDitherSpinLimit = 1 << 22;
 // ITS workgroup's boundary row 0 and publishes them in LDS -- the diffusing waves run the same code in either
 // mode and never wait for a memory round trip.  Block x = part is the fastest index: a part is dispatched
 // after the part it follows, and every wait is bounded (kDitherSpinLimit -> the batch's error word).
-template <bool kNarrow, bool kSplit>
+//
+// kOneTrip: the lookup form (sixel_launch.h).  The chain of a step runs pixel -> cell -> palette colour -> error ->
+// the next pixel of the row; with the cell's COLOUR in LDS that is one LDS round trip (the palette index, which
+// only the output needs, is requested from BuildLut's byte table in memory and consumed kDitherAhead steps later);
+// the two-trip form reads cell -> index -> colour from 34 KB of tables and leaves the LDS to the boundary rows.
+template <bool kNarrow, bool kSplit, bool kOneTrip>
 __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
+    static_assert(!(kNarrow && kOneTrip), "the narrow kernel keeps the small tables");
+    constexpr int kDitherTabWords = DitherTabWords(kOneTrip);
     extern __shared__ uint32_t lds[];
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
@@ -915,15 +930,18 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const int n_local  = lw0 + nd;                      // boundary rows written in this workgroup
     const bool flushes = kSplit && part < parts - 1;
     const int n_pad    = H - g.h;
-    uint8_t *lut8      = reinterpret_cast<uint8_t *>(lds);  // [cell ^ kCellBias] -> palette index
-    uint32_t *pal      = lds + 8192;                        // [2][256]: 16 * (colour - 128) as (r, g) / (b, 0)
+    // one trip: [2 * biased cell] r, g; from kDitherTabB on: [biased cell] b -- the even lane of a pair reads (r, g) of
+    // its cell as two bytes, the odd lane b.  Two trips: [biased cell] -> palette index, then pal[2][256]: 16 * colour
+    // as (r, g) / (b, 0)
+    uint8_t *tab8      = reinterpret_cast<uint8_t *>(lds);
+    uint32_t *pal      = lds + 8192;
     // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it
     // reads): slot c + 1 holds, for the CONSUMER at column c, the three terms it needs as three
     // consecutive words {1/16 of e(c-1), 5/16 of e(c), 3/16 of e(c+1)} -- the producer at column x
     // writes into slots x + 2, x + 1 and x.  Slots nobody writes (1/16 left of column 0, 3/16
     // right of column W-1) keep the zero they are initialised with.
     const int brow     = (W + 2) * 3;
-    uint32_t *boundary = pal + 512;  // [n_local + 1][W + 2][3]
+    uint32_t *boundary = lds + kDitherTabWords;  // [n_local + 1][W + 2][3]
     __shared__ int progress[kDitherMaxWaves];
     const int f   = kSplit ? blockIdx.y : blockIdx.x;
     const int tid = threadIdx.x;
@@ -940,25 +958,33 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const uint32_t sel_hi   = odd ? 0x0c0c020cu : 0x010c000cu;
     const uint32_t px_bias  = odd ? 0x00008000u : 0x80008000u;  // c -> c - 128 (the unused half stays 0)
     const int cell_shift    = odd ? 0 : 10;
-    constexpr uint32_t kCellBias = 0x4210u;  // (c - 128) >> 3 as an unsigned field is (c >> 3) ^ 16
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
-    for (int i = tid; i < 8192; i += blockDim.x) {  // four cells per word; the bias leaves the low 2 bits alone
-        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i ^ (kCellBias >> 2)];
-        lds[i]        = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
+    for (int i = tid; i < 8192; i += blockDim.x) {  // four cells a turn; the bias leaves the low 2 bits alone
+        const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i ^ (kCellBias >> 2)];  // idx | r << 8 | g << 16 | b << 24
+        if (kOneTrip) {
+            lds[2 * i]     = ((v.x >> 8) & 0xffffu) | ((v.y >> 8) << 16);
+            lds[2 * i + 1] = ((v.z >> 8) & 0xffffu) | ((v.w >> 8) << 16);
+            lds[kDitherTabB / 4 + i] = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
+        } else {
+            lds[i] = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
+        }
     }
-    for (int i = tid; i < 256; i += blockDim.x) {
-        const bool in = i < s.meta[0];
-        const int pr = in ? s.palette[i * 3] : 128, pg = in ? s.palette[i * 3 + 1] : 128,
-                  pb = in ? s.palette[i * 3 + 2] : 128;
-        pal[i]       = ((uint32_t)((pr - 128) * 16) & 0xffffu) | ((uint32_t)((pg - 128) * 16) << 16);
-        pal[256 + i] = (uint32_t)((pb - 128) * 16) & 0xffffu;
-    }
+    if (!kOneTrip)
+        for (int i = tid; i < 256; i += blockDim.x) {
+            const bool in = i < s.meta[0];
+            const uint32_t pr = in ? s.palette[i * 3] : 128, pg = in ? s.palette[i * 3 + 1] : 128,
+                           pb = in ? s.palette[i * 3 + 2] : 128;
+            pal[i]       = (pr * 16) | ((pg * 16) << 16);
+            pal[256 + i] = pb * 16;
+        }
     // the rows SixelCanvas::Send appends below the frame, as pixels in scratch memory: the
     // steps then fetch every row the same way (written and read by this workgroup only)
     uint32_t *pad_rows = b.pad_rows + (size_t)f * 5 * W;
     for (int i = tid; i < n_pad * W; i += blockDim.x) pad_rows[i] = PaddedPixel(frame, g, i % W, g.h + i / W);
-    for (int i = tid; i < (n_local + 1) * brow; i += blockDim.x) boundary[i] = 0u;
+    // (the row that stays zero: row n_local -- or, for a workgroup of one wave, that wave's own row: sixel_launch.h)
+    const int zero_row = n_local > 1 ? n_local : 0;
+    for (int i = tid; i < (zero_row + 1) * brow; i += blockDim.x) boundary[i] = 0u;
     if (tid < n_local) progress[tid] = 0;
     const bool dither = s.meta[1] != 0;
     __syncthreads();
@@ -1028,27 +1054,47 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         }
     }
 
-    const uint32_t *pal_half = pal + (odd ? 256 : 0);
+    // this lane's half of the tables
+    const uint32_t tab_base  = odd ? (uint32_t)kDitherTabB : 0u;  // (one trip)
+    const uint32_t tab_shift = odd ? 0u : 1u;
+    const uint8_t *lut8g     = s.lut8;
+    const uint32_t *pal_half = pal + (odd ? 256 : 0);             // (two trips)
     // the term bytes of a boundary word as this half's pair of q << 8
     auto unpack_term = [&](uint32_t q) -> uint32_t { return __builtin_amdgcn_perm(q, q, sel_hi); };
 
     const int rows_per_round = (kSplit ? n_all : n_waves) * kPairRows;  // (kSplit: one round)
     const int first_row      = (group0 + wave - lw0) * kPairRows;
-    const int steps          = W + 2 * (kPairRows - 1);
+    // a row's W pixels, skewed by two columns per row; the palette index of a pixel arrives kDitherAhead steps
+    // after the pixel's own step, and a row's last group of four indices is completed by up to three junk ones
+    // (the index rows are padded to a multiple of four and nobody reads the pad)
+    const int steps          = g.idx_stride + 2 * (kPairRows - 1) + kDitherAhead;
     bool gave_up             = false;
     for (int round = 0; round * rows_per_round + first_row < H; ++round) {
         const int row      = round * rows_per_round + first_row + rl;
         const bool has_row = row < H;
         const uint8_t *src_row  = row < g.h ? frame + (size_t)row * g.stride
                                             : reinterpret_cast<const uint8_t *>(pad_rows + (size_t)(min(row, H - 1) - g.h) * W);
-        uint8_t *idx_row        = s.index + (size_t)min(row, H - 1) * g.idx_stride;
+        // (the lane's index row as a 32-bit offset from the frame's index image, already moved back to where the group
+        // of four that ends kDitherAhead columns behind x begins: base + offset addressing, no 64-bit arithmetic)
+        const uint32_t idx_off  = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride - (uint32_t)(2 * rl + kDitherAhead + 3);
         const bool diffuses     = dither && row < H - 1;
+        // a lane that never spreads an error (no row, the last row, an exact palette) multiplies by zero:
+        // 16 * err = 16 * c - 16 * p as ONE v_pk_mad_u16 of the table bytes
+        const bool lane_spreads = has_row && diffuses;
+        // (one trip: times -16, and the byte the odd lane reads second meets a 0; two trips: the table holds 16 * p)
+        const uint32_t k_err    = !lane_spreads ? 0u : !kOneTrip ? 0xffffffffu : odd ? 0x0000fff0u : 0xfff0fff0u;
+        const uint32_t c16_mask = lane_spreads ? (odd ? 0x00000ff0u : 0x0ff00ff0u) : 0u;
+        // which lanes complete a group of four indices at the steps k & 3 == 3 / k & 3 == 1 of the unrolled body
+        const bool store_even   = has_row && !odd && !(rl & 1);
+        const bool store_odd    = has_row && !odd && (rl & 1);
+        const bool hands_down   = has_row && rl == kPairRows - 1;  // the row above the next wave's first row
         // (kSplit: local wave 0 is either the frame's first wave or the fetcher, which writes row 0 like a wave)
         const int producer       = wave == 0 ? n_local - 1 : wave - 1;
         const int producer_round = wave == 0 ? round - 1 : round;
         const bool follows       = producer_round >= 0;
-        const uint32_t *b_in     = boundary + (size_t)(follows ? producer : n_local) * brow;
-        uint8_t *b_out           = reinterpret_cast<uint8_t *>(boundary + (size_t)wave * brow) + (odd ? 2 : 0);
+        const uint32_t *b_in     = boundary + (size_t)(follows ? producer : zero_row) * brow;
+        // (this wave's boundary row as a byte offset into the dynamic LDS: 32-bit address arithmetic in the step)
+        const uint32_t b_out_off = (uint32_t)(kDitherTabWords + wave * brow) * 4u + (odd ? 2u : 0u);
         const int in_base        = producer_round * W;
         const int out_base       = round * W;
         int avail = follows ? 0 : W;  // columns of the row above known to be published
@@ -1106,10 +1152,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // with hand-placed waits.  Left to the compiler, the ring of 8 loads in flight loses its
         // count at the loop header (and at any branch around a load) and the step waits for
         // vmcnt(0): a memory round trip every step or every 8 steps, depending on the version.
-        // The loads return in order, so "at most 7 younger operations outstanding" means the
-        // oldest has arrived (the index stores in between only make the wait more conservative).
+        // The loads return in order, so "at most 14 younger operations outstanding" (seven steps' pixel and
+        // index requests; 7 in the two-trip form, which requests pixels only) means the oldest pixel -- and the index
+        // requested before it -- has arrived (the index stores in between only make the wait more conservative).
         auto fetch = [&](int t) -> uint32_t {
-            const uint32_t x = (uint32_t)min(max(t - 2 * rl, 0), W - 1);
+            uint32_t x;  // the column, clamped into the row (one v_med3: the compiler cannot know 0 <= W - 1)
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(t - 2 * rl), "s"(W - 1));
             const uint8_t *p = src_row + (size_t)x * 4;
             uint32_t v;
             asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));
@@ -1117,13 +1165,27 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         };
         // One step.  Everything is computed by every lane, in range or not (the loads are
         // clamped, the tables indexed with clamped values): straight-line code the compiler can
-        // schedule across the two dependent LDS reads; only the stores are predicated, and a
-        // lane outside its row produces zero terms.
-        // (k_odd: the parity of the step inside the unrolled body = the parity of every lane's column)
-        auto step = [&](int t, uint32_t px, bool k_odd) __attribute__((always_inline)) {
+        // schedule across the LDS reads; only the stores are predicated, and a lane outside its row
+        // produces zero terms.  `lidx` receives the step's request for the palette index of its pixel (consumed
+        // kDitherAhead steps later, with the wait for that step's pixel).
+        // (k: the step's position in the unrolled body -- t - k is a multiple of eight)
+        auto step = [&](int t, uint32_t px, uint32_t &lidx, auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            const int x = t - 2 * rl;
+            // What can branch goes first -- the index store and the poll inside request() -- so that everything
+            // from the pixel to the error terms is ONE basic block: the table reads and their uses are then
+            // scheduled together (split by a branch, the byte reads came back through a v_and each, and their
+            // latency covered nothing).
+            // (x - 8) & 3 == (k - 2 * rl) & 3: a group of four indices ends at k & 3 == 3 in the even rows of the
+            // wave, at k & 3 == 1 in the odd ones -- nothing to decide in the other steps
+            if constexpr ((k & 1) != 0) {
+                if (((k & 3) == 3 ? store_even : store_odd) && (unsigned)(x - kDitherAhead) < (unsigned)g.idx_stride)
+                    *reinterpret_cast<uint32_t *>(s.index + (idx_off + (uint32_t)t)) = packed_idx;
+            }
+            // the first row's terms for the next step (requested a step ago), and the request for the step after it
+            const uint32_t q_l = n_bl, q_c = n_bc, q_r = n_br;
+            request(t + 2);
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
-            const int x       = t - 2 * rl;
-            const bool active = has_row && (unsigned)x < (unsigned)W;
             if (rl == 0) {
                 up_l = bl;
                 up_c = bc;
@@ -1145,20 +1207,28 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             }
             const uint32_t c5   = AsBits(__builtin_bit_cast(PairU16, v) >> 11);  // 5 bits per channel, biased
             const uint32_t part = ((c5 & 0xffffu) << cell_shift) | ((c5 >> 16) << 5);
-            const uint32_t cell = part | FromPairPartner(part);
-            const uint32_t i8   = lut8[cell];
-            // the first row's terms for the next step (requested a step ago), and the request for
-            // the step after it, while the table lookups are in flight
-            bl = unpack_term(n_bl);
-            bc = unpack_term(n_bc);
-            br = unpack_term(n_br);
-            request(t + 2);
-            const uint32_t e    = pal_half[i8];  // 16 * (palette colour - 128)
-            const bool spread   = active && diffuses && x < W - 1;
+            const uint32_t cell = part | FromPairPartner(part);  // the biased cell, in both lanes of the pair
+            uint32_t p_cell;  // the cell's palette colour as this lane's pair, times 1 (one trip) or 16
+            if constexpr (kOneTrip) {
+                const uint32_t at = (cell << tab_shift) + tab_base;
+                const uint32_t t0 = tab8[at];      // r / b
+                const uint32_t t1 = tab8[at + 1];  // g / (a byte nobody uses: it meets k_err's 0)
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
+                p_cell = t0 | (t1 << 16);
+            } else {
+                lidx   = tab8[cell];
+                p_cell = pal_half[lidx];
+            }
+            bl = unpack_term(q_l);
+            bc = unpack_term(q_c);
+            br = unpack_term(q_r);
+            // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
+            // zero in lanes that never spread (k_err, c16_mask) and outside the columns 0 .. W - 2 of the row
+            const PairU16 p8  = __builtin_bit_cast(PairU16, p_cell);
+            const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);
+            const PairI16 e0  = __builtin_bit_cast(PairI16, p8 * __builtin_bit_cast(PairU16, k_err) + c16);
             const PairI16 zero  = {0, 0};
-            // 16 * err = 16 * (c - 128) - 16 * (p - 128); |16 * err * 7 + 240| fits 16 bits
-            const PairI16 c16   = AsPair(AsBits(v >> 4) & 0xfff0fff0u);
-            const PairI16 err   = spread ? c16 - AsPair(e) : zero;
+            const PairI16 err   = (unsigned)x < (unsigned)(W - 1) ? e0 : zero;
             // trunc(err * n / 16) << 8 == (16 * err * n + (err < 0 ? 240 : 0)) & 0xff00: two channels at a time
             const PairI16 k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
             const PairI16 sgn = AsPair(AsBits(err >> 15) & 0x00f000f0u);
@@ -1167,16 +1237,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t m3 = AsBits(err * k3 + sgn) & 0xff00ff00u;
             const uint32_t m1 = AsBits(err + sgn) & 0xff00ff00u;
             first_q3 = x == 0 ? m3 : first_q3;
-            // four indices per 32-bit store: the newest enters at the top byte
-            packed_idx = __builtin_amdgcn_alignbyte(i8, packed_idx, 1);
-            // (a group of four ends in an odd column; the row's last column is odd unless W is)
-            if (k_odd || (W & 1))
-                if (active && ((x & 3) == 3 || x == W - 1) && !odd)
-                    *reinterpret_cast<uint32_t *>(idx_row + (x & ~3)) = packed_idx >> (8 * (3 - (x & 3)));
-            if (active && rl == kPairRows - 1) {  // the row above the next wave's first row
+            if (hands_down && (unsigned)x < (unsigned)W) {
                 // term word r | g << 8 | b << 16: the even lane writes its low half (r, g), the
                 // odd lane the high half (b, 0), each the low bytes of its two 16-bit values
-                uint8_t *o = b_out + x * 12;
+                uint8_t *o = tab8 + (b_out_off + (uint32_t)x * 12u);
                 *reinterpret_cast<uint16_t *>(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0301u);
                 *reinterpret_cast<uint16_t *>(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0301u);
                 *reinterpret_cast<uint16_t *>(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0301u);
@@ -1197,25 +1261,44 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         asm volatile("" ::: "memory");
         uint32_t p0 = fetch(0), p1 = fetch(1), p2 = fetch(2), p3 = fetch(3), p4 = fetch(4), p5 = fetch(5),
                  p6 = fetch(6), p7 = fetch(7);
+        uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;  // (nothing in flight yet: not consumed before step 8)
+        // "At most 14 younger operations" names the oldest pixel only once the ring is full: with the eight requests of
+        // the prologue alone in flight the first seven waits would let their steps through with nothing arrived.  The
+        // first pixels are awaited as a whole (a wave's first step waits a memory round trip either way).
+        if constexpr (kOneTrip)
+            asm volatile("s_waitcnt vmcnt(0) ; ring all"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         :
+                         : "memory");
         // (no early exit inside the unrolled body: with one the compiler loses count of the
         // loads in flight; the up to 7 extra steps find every lane out of range)
-#define TIMG_DITHER_STEP(k, P)                                    \
-    asm volatile("s_waitcnt vmcnt(7) ; ring %0" : "+v"(P) : : "memory"); \
-    step(t + k, P, (k & 1) != 0);                                 \
+        // The index that arrived goes into packed_idx -- four per 32-bit store, the newest (pixel x - kDitherAhead) at
+        // the top byte -- INSIDE the wait's asm statement: as a value the compiler could see between its wait and
+        // the step's own request into the same variable, it was given a second register and copied, in flight, at
+        // the back edge (check_ring_isa.py refused the build).
+#define TIMG_DITHER_STEP(k, P, L)                                                             \
+    if constexpr (kOneTrip)                                                                   \
+        asm volatile("s_waitcnt vmcnt(14) ; ring %0 %2\n\tv_alignbyte_b32 %1, %2, %1, 1"      \
+                     : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory");                        \
+    else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
+        asm volatile("s_waitcnt vmcnt(7) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1"          \
+                     : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory");                        \
+    step(t + k, P, L, std::integral_constant<int, k>());                                      \
     P = fetch(t + k + kDitherAhead);
         for (int t = 0; t < steps; t += 8) {
-            TIMG_DITHER_STEP(0, p0)
-            TIMG_DITHER_STEP(1, p1)
-            TIMG_DITHER_STEP(2, p2)
-            TIMG_DITHER_STEP(3, p3)
-            TIMG_DITHER_STEP(4, p4)
-            TIMG_DITHER_STEP(5, p5)
-            TIMG_DITHER_STEP(6, p6)
-            TIMG_DITHER_STEP(7, p7)
+            TIMG_DITHER_STEP(0, p0, l0)
+            TIMG_DITHER_STEP(1, p1, l1)
+            TIMG_DITHER_STEP(2, p2, l2)
+            TIMG_DITHER_STEP(3, p3, l3)
+            TIMG_DITHER_STEP(4, p4, l4)
+            TIMG_DITHER_STEP(5, p5, l5)
+            TIMG_DITHER_STEP(6, p6, l6)
+            TIMG_DITHER_STEP(7, p7, l7)
         }
-        // the 8 requests still in flight must land before their registers are used for anything else
+        // the 16 requests still in flight must land before their registers are used for anything else
         asm volatile("s_waitcnt vmcnt(0) ; ring all"
-                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(l0), "+v"(l1),
+                       "+v"(l2), "+v"(l3), "+v"(l4), "+v"(l5), "+v"(l6), "+v"(l7)
                      :
                      : "memory");
 #undef TIMG_DITHER_STEP
@@ -2166,6 +2249,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_ta    = carve(nf * 32768 * 4);
     const size_t o_tb    = carve(nf * 32768 * 4);
     const size_t o_lut   = carve(nf * 32768 * 4);
+    const size_t o_lut8  = carve(nf * 32768);
     const size_t o_pal   = carve(nf * 768);
     const size_t o_meta  = carve(nf * 4 * sizeof(int));
     g.idx_stride         = (w + 3) & ~3;
@@ -2197,6 +2281,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     b.tab_a      = (uint32_t *)(base + o_ta);
     b.tab_b      = (uint32_t *)(base + o_tb);
     b.lut        = (uint32_t *)(base + o_lut);
+    b.lut8       = (uint8_t *)(base + o_lut8);
     b.palette    = (uint8_t *)(base + o_pal);
     b.meta       = (int *)(base + o_meta);
     b.index      = (uint8_t *)(base + o_idx);
@@ -2225,21 +2310,30 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     // for the diffusion: small frames, and the fallback of the multi-CU placement.  Round 1's two-CU version, whose
     // DIFFUSING waves read the bridge in global memory themselves, was not faster; DitherKernel<., true> keeps the
     // memory round trips in helper waves.)
-    const char *waves_env = getenv("TIMG_HIP_DITHER_WAVES"), *parts_env = getenv("TIMG_HIP_DITHER_PARTS");
+    const char *waves_env = getenv("TIMG_HIP_DITHER_WAVES"), *parts_env = getenv("TIMG_HIP_DITHER_PARTS"),
+               *trips_env = getenv("TIMG_HIP_DITHER_TRIPS");
     const SixelLaunch plan = PlanSixelLaunch(w, g.h6, n_frames, ctx->cu_count, waves_env ? std::max(1, atoi(waves_env)) : 0,
-                                             parts_env ? std::max(0, atoi(parts_env)) : -1);
+                                             parts_env ? std::max(0, atoi(parts_env)) : -1, trips_env ? atoi(trips_env) : 0);
     const int dither_waves = plan.dither_waves, dither_parts = plan.dither_parts, split_share = plan.split_share;
     const size_t dither_lds = plan.dither_lds, split_lds = plan.split_lds;
     const bool wide_bands   = plan.wide_bands;  // sort buffers in global scratch
     const size_t nodes_lds = plan.nodes_lds, emit_lds = plan.emit_lds;
-    // both kernels need more than the default 64 KiB of dynamic LDS
-    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(w > 2 ? (const void *)DitherKernel<false, false>
-                                                : (const void *)DitherKernel<true, false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)dither_lds));
-    if (dither_parts > 1)
-        TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherKernel<false, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds));
+    // the diffusion kernel that serves this geometry, its grid, block and dynamic LDS
+    const void *dither_fn = nullptr;
+    dim3 dither_block;
+    size_t dither_dyn = 0;
+    if (dither_parts > 1) {
+        dither_fn    = plan.one_trip ? (const void *)DitherKernel<false, true, true> : (const void *)DitherKernel<false, true, false>;
+        dither_block = dim3((split_share + 2) * 64);
+        dither_dyn   = split_lds;
+    } else {
+        dither_fn = w <= 2 ? (const void *)DitherKernel<true, false, false>
+                           : plan.one_trip ? (const void *)DitherKernel<false, false, true> : (const void *)DitherKernel<false, false, false>;
+        dither_block = dim3(dither_waves * 64);
+        dither_dyn   = dither_lds;
+    }
+    // the kernels below need more than the default 64 KiB of dynamic LDS
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute(dither_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dither_dyn));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true, 256>
                                                      : (const void *)BandNodesKernel<false, kBandLanes>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2286,6 +2380,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         gb.tab_a       = b.tab_a + o * 32768;
         gb.tab_b       = b.tab_b + o * 32768;
         gb.lut         = b.lut + o * 32768;
+        gb.lut8        = b.lut8 + o * 32768;
         gb.palette     = b.palette + o * 768;
         gb.meta        = b.meta + o * 4;
         gb.index       = b.index + o * g.h6 * g.idx_stride;
@@ -2319,13 +2414,13 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
             hipLaunchKernelGGL(DitherFirstHitKernel, dim3(nfr), dim3(64), first_hit_lds, gs, g, gb);
         } else {
             hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
-            if (dither_parts > 1)
-                hipLaunchKernelGGL((DitherKernel<false, true>), dim3(dither_parts, nfr), dim3((split_share + 2) * 64),
-                                   split_lds, gs, g, gb);
-            else if (w > 2)
-                hipLaunchKernelGGL((DitherKernel<false, false>), dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
-            else
-                hipLaunchKernelGGL((DitherKernel<true, false>), dim3(nfr), dim3(dither_waves * 64), dither_lds, gs, g, gb);
+            {
+                SixelGeom kg       = g;
+                SixelBatch kb      = gb;
+                void *kargs[]      = {&kg, &kb};
+                const dim3 grid    = dither_parts > 1 ? dim3(dither_parts, nfr) : dim3(nfr);
+                TIMG_HIP_TRY(ctx, hipLaunchKernel(dither_fn, grid, dither_block, kargs, dither_dyn, gs));
+            }
         }
         if (wide_bands)
             hipLaunchKernelGGL((BandNodesKernel<true, 256>), dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);

@@ -26,13 +26,22 @@ constexpr int kDitherMaxWaves = 16;
 constexpr int kPairRows       = 32;  // rows per wave
 // The diffusion of a frame spread over several workgroups (CUs): hand-over buffer of one boundary between two of
 // them -- the boundary row's (W + 2) x 3 words, then (in a cache line of its own) the producer's progress counter
-constexpr int kDitherMaxParts = 8;
+constexpr int kDitherMaxParts = 16;
 __host__ __device__ inline int XwgData(int w) { return ((w + 2) * 3 + 31) & ~31; }
 __host__ __device__ inline int XwgStride(int w) { return XwgData(w) + 32; }
-// dynamic LDS of a diffusion workgroup that writes `rows` boundary rows (+ the one that stays zero): the 15-bit
-// table (32 KB), the palette (2 KB), the boundary rows
-inline size_t DitherLdsBytes(int w, int rows) {
-    return (8192 + 512 + (size_t)(rows + 1) * 3 * (size_t)(w + 2)) * sizeof(uint32_t);
+// Two forms of the diffusion's table lookup (DitherKernel<., ., kOneTrip>):
+//  * one trip: the palette COLOUR of every 15-bit cell in LDS -- (r, g) byte pairs (64 KB), then b (32 KB); one LDS
+//    round trip on the serial chain, the palette index comes from memory off the chain.  96 KB of tables leave room
+//    for six boundary rows of 800 columns;
+//  * two trips: cell -> palette index (32 KB), index -> colour (2 KB), two dependent LDS round trips; for geometries
+//    whose boundary rows do not fit beside the colour tables in the placement that is wanted.
+constexpr int kDitherTabB = 65536;  // one trip: byte offset of the b table
+__host__ __device__ constexpr int DitherTabWords(bool one_trip) { return one_trip ? (65536 + 32768) / 4 : 8192 + 512; }
+// dynamic LDS of a diffusion workgroup that writes `rows` boundary rows (+ the one that stays zero): the tables, then
+// the boundary rows.  (A workgroup of ONE wave follows itself from round to round, 62 columns ahead of its own
+// writes: the row that "stays zero" is its own row, freshly cleared.)
+inline size_t DitherLdsBytes(int w, int rows, bool one_trip) {
+    return (DitherTabWords(one_trip) + (size_t)(rows > 1 ? rows + 1 : 1) * 3 * (size_t)(w + 2)) * sizeof(uint32_t);
 }
 constexpr size_t kDitherStaticLds = 512;  // (the progress counters, rounded up generously)
 
@@ -48,27 +57,27 @@ inline int BandEntries(int w) { return ((6 * w + 63) / 64) * 64; }
 
 struct SixelLaunch {
     int band_ne;          // entries a band can have (rounded up to 64)
+    bool one_trip;        // the diffusion's lookup form (above)
     int dither_waves;     // one workgroup per frame: its waves (frames with more row groups go round again) ...
     size_t dither_lds;    // ... and its dynamic LDS
-    int dither_parts;     // > 1: DitherKernel<., true> with this many workgroups per frame ...
+    int dither_parts;     // > 1: DitherKernel<., true, .> with this many workgroups per frame ...
     int split_share;      // ... the largest part's row groups (its block has split_share + 2 waves) ...
     size_t split_lds;     // ... and its dynamic LDS
     bool wide_bands;      // the band kernels sort in global scratch
     size_t nodes_lds, emit_lds;
 };
 
-// waves_cap: TIMG_HIP_DITHER_WAVES (0: not set); parts_env: TIMG_HIP_DITHER_PARTS (< 0: not set)
-inline SixelLaunch PlanSixelLaunch(int w, int h6, int n_frames, int cu_count, int waves_cap, int parts_env) {
-    SixelLaunch L{};
-    L.band_ne = BandEntries(w);
+// the diffusion's placement for one lookup form
+inline void PlanDither(SixelLaunch &L, int w, int h6, int n_frames, int cu_count, int waves_cap, int parts_env, bool one_trip) {
+    L.one_trip = one_trip;
     // one wave per 32 rows, as many as the boundary rows leave room for next to the tables
     const int groups = (h6 + kPairRows - 1) / kPairRows;
     int waves        = groups < 1 ? 1 : (groups > kDitherMaxWaves ? kDitherMaxWaves : groups);
     if (waves_cap > 0 && waves > waves_cap) waves = waves_cap;
-    while (waves > 1 && DitherLdsBytes(w, waves) > kSixelLdsBudget - kDitherStaticLds) --waves;
+    while (waves > 1 && DitherLdsBytes(w, waves, one_trip) > kSixelLdsBudget - kDitherStaticLds) --waves;
     L.dither_waves = waves;
-    L.dither_lds   = DitherLdsBytes(w, waves);
-    // Frames of eight row groups and more are spread over several workgroups = CUs (DitherKernel<., true>): about
+    L.dither_lds   = DitherLdsBytes(w, waves, one_trip);
+    // Frames of eight row groups and more are spread over several workgroups = CUs (DitherKernel<., true, .>): about
     // four row groups a part (one wave per SIMD: 800x450 measured 644 / 587 / 557 / 522 us per 64 frames with
     // 1 / 2 / 3 / 4 parts), no more parts than the batch leaves CUs for (parts of frames that wait for a CU while
     // others spin cost more than they win), or what TIMG_HIP_DITHER_PARTS asks for; then the fewest parts from
@@ -82,16 +91,40 @@ inline SixelLaunch PlanSixelLaunch(int w, int h6, int n_frames, int cu_count, in
         if (want > kDitherMaxParts) want = kDitherMaxParts;
         if (want > by_cus) want = by_cus;
         if (parts_env >= 0) want = parts_env;
-        for (int p = want < 1 ? 1 : want; p > 1 && p <= kDitherMaxParts; ++p) {
+        if (want > groups) want = groups;  // (no part without a row group)
+        for (int p = want < 1 ? 1 : want; p > 1 && p <= kDitherMaxParts && p <= groups; ++p) {
             const int share = (groups + p - 1) / p;
-            if (share + 2 <= kDitherMaxWaves && DitherLdsBytes(w, share + 1) <= kSixelLdsBudget - kDitherStaticLds) {
+            if (share + 2 <= kDitherMaxWaves && DitherLdsBytes(w, share + 1, one_trip) <= kSixelLdsBudget - kDitherStaticLds) {
                 L.dither_parts = p;
                 break;
             }
         }
     }
     L.split_share = L.dither_parts > 1 ? (groups + L.dither_parts - 1) / L.dither_parts : 0;
-    L.split_lds   = L.dither_parts > 1 ? DitherLdsBytes(w, L.split_share + 1) : 0;
+    L.split_lds   = L.dither_parts > 1 ? DitherLdsBytes(w, L.split_share + 1, one_trip) : 0;
+}
+
+// waves_cap: TIMG_HIP_DITHER_WAVES (0: not set); parts_env: TIMG_HIP_DITHER_PARTS (< 0: not set); trips_env:
+// TIMG_HIP_DITHER_TRIPS (1 / 2: that lookup form; anything else: chosen here)
+inline SixelLaunch PlanSixelLaunch(int w, int h6, int n_frames, int cu_count, int waves_cap, int parts_env, int trips_env = 0) {
+    SixelLaunch L{};
+    L.band_ne = BandEntries(w);
+    // The one-trip lookup where its tables do not cost the placement: as many parts as the two-trip form would get
+    // (or, one workgroup per frame, as many waves -- a CU that diffuses a frame alone is bound by what its waves
+    // issue together, and twelve waves issue more than five).  Never for the narrow kernel (w <= 2).
+    SixelLaunch one = L, two = L;
+    PlanDither(two, w, h6, n_frames, cu_count, waves_cap, parts_env, false);
+    PlanDither(one, w, h6, n_frames, cu_count, waves_cap, parts_env, true);
+    bool use_one;
+    if (one.dither_parts > 1 || two.dither_parts > 1)  // (more parts than the other form needs only if all are resident at once)
+        use_one = one.dither_parts > 1 && (one.dither_parts <= two.dither_parts ||
+                                           (long)one.dither_parts * (n_frames > 0 ? n_frames : 1) <= cu_count);
+    else
+        use_one = one.dither_waves >= two.dither_waves;
+    if (w <= 2) use_one = false;
+    if (trips_env == 1 && w > 2) use_one = true;
+    if (trips_env == 2) use_one = false;
+    L = use_one ? one : two;
     L.wide_bands  = L.band_ne > kLdsEntries;
     L.nodes_lds   = L.wide_bands ? (size_t)(2 * 4096 + 16) * sizeof(uint32_t)
                                  : ((size_t)BandNodesSharedWords(w, L.band_ne) + L.band_ne + 16) * sizeof(uint32_t);

@@ -81,8 +81,8 @@ def test_known_geometries():
     assert (p["one_trip"], p["dither_parts"], p["split_share"]) == (0, 2, 8)
     p = plan(800, 450, 300)
     assert (p["one_trip"], p["dither_parts"], p["dither_waves"]) == (0, 1, 12)
-    # 766 columns: 13 boundary rows + the zero row fill the 160 KB to the byte and leave nothing for the static part
-    assert plan(766, 450, 300)["dither_waves"] == 12 and plan(762, 450, 300)["dither_waves"] == 13
+    # the last width at which 13 waves' boundary rows + the zero row + the overrun slack fit beside the small tables
+    assert plan(756, 450, 300)["dither_waves"] == 12 and plan(755, 450, 300)["dither_waves"] == 13
     assert plan(800, 222, 64)["dither_parts"] == 1             # seven row groups: one workgroup
     assert plan(800, 228, 64)["dither_parts"] == 2             # eight: two parts of four
     assert plan(64, 1104, 64)["dither_parts"] == 4 and plan(64, 1104, 1)["dither_parts"] == 9

@@ -917,7 +917,11 @@ template <bool kNarrow, bool kSplit, bool kOneTrip>
 __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
     static_assert(!(kNarrow && kOneTrip), "the narrow kernel keeps the small tables");
     constexpr int kDitherTabWords = DitherTabWords(kOneTrip);
-    extern __shared__ uint32_t lds[];
+    // All of the kernel's LDS is dynamic and starts at address 0: [progress counters: kDitherLdsHead bytes][tables]
+    // [boundary rows][slack].  (With a static array in front, every LDS address the steps form from a running offset
+    // paid a v_add of the static part's size.)
+    extern __shared__ uint32_t lds_all[];
+    uint32_t *lds = lds_all + kDitherLdsHead / 4;
     const int W = g.w, H = g.h6;
     const int n_waves  = blockDim.x >> 6;
     // roles (kSplit): [fetcher (parts > 0)] [nd diffusing waves] [flusher (parts before the last)] [idle]
@@ -930,9 +934,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const int n_local  = lw0 + nd;                      // boundary rows written in this workgroup
     const bool flushes = kSplit && part < parts - 1;
     const int n_pad    = H - g.h;
-    // one trip: [2 * biased cell] r, g; from kDitherTabB on: [biased cell] b -- the even lane of a pair reads (r, g) of
-    // its cell as two bytes, the odd lane b.  Two trips: [biased cell] -> palette index, then pal[2][256]: 16 * colour
-    // as (r, g) / (b, 0)
+    // one trip: three byte tables indexed by the biased cell -- b, r, g, 32 KB each: a lane reads [its base + cell] and
+    // 32 KB further on with ONE address (the even lane of a pair r then g, the odd lane b and a byte nobody uses).
+    // Two trips: [biased cell] -> palette index, then pal[2][256]: 16 * colour as (r, g) / (b, 0)
     uint8_t *tab8      = reinterpret_cast<uint8_t *>(lds);
     uint32_t *pal      = lds + 8192;
     // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it
@@ -942,7 +946,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // right of column W-1) keep the zero they are initialised with.
     const int brow     = (W + 2) * 3;
     uint32_t *boundary = lds + kDitherTabWords;  // [n_local + 1][W + 2][3]
-    __shared__ int progress[kDitherMaxWaves];
+    int *progress = reinterpret_cast<int *>(lds_all);  // [kDitherMaxWaves]
+    // The steps' running addresses are absolute LDS addresses (this array's own address added once, outside the
+    // loops) used through address-space-3 pointers: formed as `array + offset` each step paid a v_add of the array's
+    // link-time address.
+    typedef __attribute__((address_space(3))) uint32_t LdsU32;
+    typedef __attribute__((address_space(3))) uint16_t LdsU16;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
     const int f   = kSplit ? blockIdx.y : blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -957,15 +967,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // or of a term word -> HIGH byte of each 16-bit half
     const uint32_t sel_hi   = odd ? 0x0c0c020cu : 0x010c000cu;
     const uint32_t px_bias  = odd ? 0x00008000u : 0x80008000u;  // c -> c - 128 (the unused half stays 0)
-    const int cell_shift    = odd ? 0 : 10;
+    // the lane's share of the cell as ONE v_dot2_u32_u16 of its two 5-bit fields: r5 << 10 | g5 << 5 / b5
+    const uint32_t cell_mul = odd ? 0x00000001u : 0x00200400u;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
     for (int i = tid; i < 8192; i += blockDim.x) {  // four cells a turn; the bias leaves the low 2 bits alone
         const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i ^ (kCellBias >> 2)];  // idx | r << 8 | g << 16 | b << 24
         if (kOneTrip) {
-            lds[2 * i]     = ((v.x >> 8) & 0xffffu) | ((v.y >> 8) << 16);
-            lds[2 * i + 1] = ((v.z >> 8) & 0xffffu) | ((v.w >> 8) << 16);
-            lds[kDitherTabB / 4 + i] = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
+            lds[i]         = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);                              // b
+            lds[8192 + i]  = ((v.x >> 8) & 0xffu) | (((v.y >> 8) & 0xffu) << 8) | (((v.z >> 8) & 0xffu) << 16) | (((v.w >> 8) & 0xffu) << 24);    // r
+            lds[16384 + i] = ((v.x >> 16) & 0xffu) | (((v.y >> 16) & 0xffu) << 8) | (((v.z >> 16) & 0xffu) << 16) | (((v.w >> 16) & 0xffu) << 24);  // g
         } else {
             lds[i] = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
         }
@@ -1055,8 +1066,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     }
 
     // this lane's half of the tables
-    const uint32_t tab_base  = odd ? (uint32_t)kDitherTabB : 0u;  // (one trip)
-    const uint32_t tab_shift = odd ? 0u : 1u;
+    const uint32_t tab_base  = odd ? 0u : 32768u;                 // (one trip: b / r, and g 32 KB behind r)
     const uint8_t *lut8g     = s.lut8;
     const uint32_t *pal_half = pal + (odd ? 256 : 0);             // (two trips)
     // the term bytes of a boundary word as this half's pair of q << 8
@@ -1076,7 +1086,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                                             : reinterpret_cast<const uint8_t *>(pad_rows + (size_t)(min(row, H - 1) - g.h) * W);
         // (the lane's index row as a 32-bit offset from the frame's index image, already moved back to where the group
         // of four that ends kDitherAhead columns behind x begins: base + offset addressing, no 64-bit arithmetic)
-        const uint32_t idx_off  = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride - (uint32_t)(2 * rl + kDitherAhead + 3);
+        uint32_t idx_addr       = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride - (uint32_t)(2 * rl + kDitherAhead + 3);
         const bool diffuses     = dither && row < H - 1;
         // a lane that never spreads an error (no row, the last row, an exact palette) multiplies by zero:
         // 16 * err = 16 * c - 16 * p as ONE v_pk_mad_u16 of the table bytes
@@ -1092,12 +1102,17 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         const int producer       = wave == 0 ? n_local - 1 : wave - 1;
         const int producer_round = wave == 0 ? round - 1 : round;
         const bool follows       = producer_round >= 0;
-        const uint32_t *b_in     = boundary + (size_t)(follows ? producer : zero_row) * brow;
+        // Addresses that advance by a constant per step are kept per BLOCK of eight steps (in_addr, out_addr, idx_addr
+        // below, bumped at the end of the unrolled body): the steps then address with immediate offsets instead of a
+        // multiply-add each.  in_addr: the row above, as a byte offset into the dynamic LDS, at column t.
+        uint32_t in_addr         = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + (follows ? producer : zero_row) * brow) * 4u;
+        asm("" : "+v"(in_addr));  // (wave-uniform, but wanted in a vector register: it is a ds_read address)
         // (this wave's boundary row as a byte offset into the dynamic LDS: 32-bit address arithmetic in the step)
-        const uint32_t b_out_off = (uint32_t)(kDitherTabWords + wave * brow) * 4u + (odd ? 2u : 0u);
-        const int in_base        = producer_round * W;
+        uint32_t out_addr        = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + wave * brow) * 4u + (odd ? 2u : 0u) -
+                                   24u * (uint32_t)rl;  // (at x = t - 2 * rl)
+        // (a wave with no row above it finds every column "published": its own counter, against a base far below)
+        const int in_base        = follows ? producer_round * W : -(1 << 30);
         const int out_base       = round * W;
-        int avail = follows ? 0 : W;  // columns of the row above known to be published
 
         // terms of this row's own recent errors (pairs of q << 8):
         //   own7 = 7/16 of e(x-1)  -> this row's next pixel
@@ -1107,46 +1122,50 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         uint32_t packed_idx = 0;
         uint32_t bl = 0, bc = 0, br = 0;        // terms from above for the wave's first row, this step
         uint32_t n_bl = 0, n_bc = 0, n_br = 0;  // ... and, still packed, for the next step
-        // A poll is an LDS round trip in the middle of a step: when the producer is not far
-        // enough ahead, wait until it is kPollBatch columns further than needed, so that a wave
-        // that runs right behind its producer polls every kPollBatch steps, not every step.
-#ifndef TIMG_DITHER_POLL
-#define TIMG_DITHER_POLL 4
-#endif
-        constexpr int kPollBatch = TIMG_DITHER_POLL;
+        // The producer's progress counter is read EVERY step, one step before it is looked at (two instructions, no
+        // wait: the value has long arrived), so a wave follows its producer as closely as the data allows and the
+        // common case -- the producer is far enough -- is a branch that is NOT taken.  (Measured with
+        // scratch/ubench/wave_latency.hip: a wave alone on its SIMD issues one instruction of any kind per 4 clocks,
+        // dependent or not, but a TAKEN branch costs ~80; the previous form polled in batches of four columns behind
+        // a taken branch per step: ~80 clocks a step for the branch and ~50 a step for the polls, of ~600.)
         int spins = 0;
+        uint32_t prog_raw = 0;
+        auto peek = [&]() __attribute__((always_inline)) {
+            prog_raw = (uint32_t)__hip_atomic_load(&progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
         auto wait_for = [&](int need) __attribute__((always_inline)) {
-            if (avail < need) {
-                const int target = min(W, need + kPollBatch - 1);
-                while (avail < target) {
+            int avail = __builtin_amdgcn_readfirstlane((int)prog_raw) - in_base;
+            if (__builtin_expect(avail < need, 0)) {
+                do {
+                    __builtin_amdgcn_s_sleep(1);
                     avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                 &progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - in_base;
-                    if (avail < target) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > kDitherSpinLimit) {  // never on a healthy run: give up (reported below), do not hang
-                            gave_up = true;
-                            avail   = W;
-                        }
+                    if (++spins > kDitherSpinLimit) {  // never on a healthy run: give up (reported below), do not hang
+                        gave_up = true;
+                        break;
                     }
-                }
+                } while (avail < need);
             }
             asm volatile("" ::: "memory");
         };
         // the first row's terms for column c are complete once the producer has finished column
         // c + 1; they are requested one step before they are unpacked
-        auto request = [&](int c) __attribute__((always_inline)) {
-            c = min(c, W - 1);
-            wait_for(min(W, c + 2));
-            const uint32_t *slot = b_in + (c + 1) * 3;
+        // (the slot is not clamped to the row: past its end the slots of the following row -- or the slack behind the
+        // last one, sixel_launch.h -- are read, for lanes that are outside their rows by then)
+        auto request = [&](int c, uint32_t slot_addr) __attribute__((always_inline)) {
+            wait_for(min(c + 2, W));
+            peek();
+            const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = row above + (c + 1) * 12
             n_bl = slot[0];
             n_bc = slot[1];
             n_br = slot[2];
         };
-        request(0);
+        peek();
+        request(0, in_addr + 12u);
         bl = unpack_term(n_bl);
         bc = unpack_term(n_bc);
         br = unpack_term(n_br);
-        request(1);
+        request(1, in_addr + 24u);
 
         // Source pixels: unconditional, from clamped addresses, 8 steps ahead, as inline assembly
         // with hand-placed waits.  Left to the compiler, the ring of 8 loads in flight loses its
@@ -1169,7 +1188,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // produces zero terms.  `lidx` receives the step's request for the palette index of its pixel (consumed
         // kDitherAhead steps later, with the wait for that step's pixel).
         // (k: the step's position in the unrolled body -- t - k is a multiple of eight)
-        auto step = [&](int t, uint32_t px, uint32_t &lidx, auto k_tag) __attribute__((always_inline)) {
+        auto step = [&](int t, uint32_t &px, uint32_t &lidx, auto k_tag) __attribute__((always_inline)) {
             constexpr int k = decltype(k_tag)::value;
             const int x = t - 2 * rl;
             // What can branch goes first -- the index store and the poll inside request() -- so that everything
@@ -1180,18 +1199,18 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // wave, at k & 3 == 1 in the odd ones -- nothing to decide in the other steps
             if constexpr ((k & 1) != 0) {
                 if (((k & 3) == 3 ? store_even : store_odd) && (unsigned)(x - kDitherAhead) < (unsigned)g.idx_stride)
-                    *reinterpret_cast<uint32_t *>(s.index + (idx_off + (uint32_t)t)) = packed_idx;
+                    *reinterpret_cast<uint32_t *>(s.index + (idx_addr + (uint32_t)k)) = packed_idx;
             }
             // the first row's terms for the next step (requested a step ago), and the request for the step after it
             const uint32_t q_l = n_bl, q_c = n_bc, q_r = n_br;
-            request(t + 2);
+            request(t + 2, in_addr + (uint32_t)(k + 3) * 12u);
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
             if (rl == 0) {
                 up_l = bl;
                 up_c = bc;
                 up_r = br;
             }
-            PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_hi) ^ px_bias);
+            PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_hi) ^ px_bias);  // (px is dead from here: its register takes the next request)
             v = ApplyPair(v, up_l);
             v = ApplyPair(v, up_c);
             v = ApplyPair(v, up_r);
@@ -1206,17 +1225,21 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 v = ApplyPair(v, wrap);
             }
             const uint32_t c5   = AsBits(__builtin_bit_cast(PairU16, v) >> 11);  // 5 bits per channel, biased
-            const uint32_t part = ((c5 & 0xffffu) << cell_shift) | ((c5 >> 16) << 5);
+            const uint32_t part = __builtin_amdgcn_udot2(__builtin_bit_cast(PairU16, c5), __builtin_bit_cast(PairU16, cell_mul), 0u, false);
             const uint32_t cell = part | FromPairPartner(part);  // the biased cell, in both lanes of the pair
             uint32_t p_cell;  // the cell's palette colour as this lane's pair, times 1 (one trip) or 16
             if constexpr (kOneTrip) {
-                const uint32_t at = (cell << tab_shift) + tab_base;
-                const uint32_t t0 = tab8[at];      // r / b
-                const uint32_t t1 = tab8[at + 1];  // g / (a byte nobody uses: it meets k_err's 0)
+                const uint32_t at = cell + tab_base;
+                const uint32_t t0 = tab8[at];          // r / b
+                const uint32_t t1 = tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
                 asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
+                // (the pixel for kDitherAhead steps on is requested HERE, in the shadow of the table reads, with the
+                // unpacking below: ~48 clocks of LDS latency otherwise spent in s_waitcnt)
+                px     = fetch(t + kDitherAhead);
                 p_cell = t0 | (t1 << 16);
             } else {
                 lidx   = tab8[cell];
+                px     = fetch(t + kDitherAhead);
                 p_cell = pal_half[lidx];
             }
             bl = unpack_term(q_l);
@@ -1236,14 +1259,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t m5 = AsBits(err * k5 + sgn) & 0xff00ff00u;
             const uint32_t m3 = AsBits(err * k3 + sgn) & 0xff00ff00u;
             const uint32_t m1 = AsBits(err + sgn) & 0xff00ff00u;
-            first_q3 = x == 0 ? m3 : first_q3;
+            if constexpr ((k & 1) == 0) first_q3 = x == 0 ? m3 : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
             if (hands_down && (unsigned)x < (unsigned)W) {
                 // term word r | g << 8 | b << 16: the even lane writes its low half (r, g), the
                 // odd lane the high half (b, 0), each the low bytes of its two 16-bit values
-                uint8_t *o = tab8 + (b_out_off + (uint32_t)x * 12u);
-                *reinterpret_cast<uint16_t *>(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0301u);
-                *reinterpret_cast<uint16_t *>(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0301u);
-                *reinterpret_cast<uint16_t *>(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0301u);
+                const uint32_t o = out_addr + (uint32_t)k * 12u;
+                *(LdsU16 *)(uintptr_t)(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0301u);
+                *(LdsU16 *)(uintptr_t)(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0301u);
+                *(LdsU16 *)(uintptr_t)(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0301u);
                 asm volatile("" ::: "memory");
                 if (!odd)
                     __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
@@ -1283,8 +1306,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
         asm volatile("s_waitcnt vmcnt(7) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1"          \
                      : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory");                        \
-    step(t + k, P, L, std::integral_constant<int, k>());                                      \
-    P = fetch(t + k + kDitherAhead);
+    step(t + k, P, L, std::integral_constant<int, k>());
         for (int t = 0; t < steps; t += 8) {
             TIMG_DITHER_STEP(0, p0, l0)
             TIMG_DITHER_STEP(1, p1, l1)
@@ -1294,6 +1316,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             TIMG_DITHER_STEP(5, p5, l5)
             TIMG_DITHER_STEP(6, p6, l6)
             TIMG_DITHER_STEP(7, p7, l7)
+            in_addr += 96u;
+            out_addr += 96u;
+            idx_addr += 8u;
         }
         // the 16 requests still in flight must land before their registers are used for anything else
         asm volatile("s_waitcnt vmcnt(0) ; ring all"

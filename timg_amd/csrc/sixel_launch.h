@@ -30,20 +30,24 @@ constexpr int kDitherMaxParts = 16;
 __host__ __device__ inline int XwgData(int w) { return ((w + 2) * 3 + 31) & ~31; }
 __host__ __device__ inline int XwgStride(int w) { return XwgData(w) + 32; }
 // Two forms of the diffusion's table lookup (DitherKernel<., ., kOneTrip>):
-//  * one trip: the palette COLOUR of every 15-bit cell in LDS -- (r, g) byte pairs (64 KB), then b (32 KB); one LDS
+//  * one trip: the palette COLOUR of every 15-bit cell in LDS -- three byte tables b, r, g of 32 KB each; one LDS
 //    round trip on the serial chain, the palette index comes from memory off the chain.  96 KB of tables leave room
 //    for six boundary rows of 800 columns;
 //  * two trips: cell -> palette index (32 KB), index -> colour (2 KB), two dependent LDS round trips; for geometries
 //    whose boundary rows do not fit beside the colour tables in the placement that is wanted.
-constexpr int kDitherTabB = 65536;  // one trip: byte offset of the b table
 __host__ __device__ constexpr int DitherTabWords(bool one_trip) { return one_trip ? (65536 + 32768) / 4 : 8192 + 512; }
 // dynamic LDS of a diffusion workgroup that writes `rows` boundary rows (+ the one that stays zero): the tables, then
 // the boundary rows.  (A workgroup of ONE wave follows itself from round to round, 62 columns ahead of its own
 // writes: the row that "stays zero" is its own row, freshly cleared.)
+// The steps read the row above up to kDitherOverrun slots past its end (unclamped: the lanes that receive them are
+// outside their rows by then): slack behind the last row.
+constexpr int kDitherOverrun = 96;
+constexpr int kDitherLdsHead = 64;  // bytes in front of the tables: the waves' progress counters
 inline size_t DitherLdsBytes(int w, int rows, bool one_trip) {
-    return (DitherTabWords(one_trip) + (size_t)(rows > 1 ? rows + 1 : 1) * 3 * (size_t)(w + 2)) * sizeof(uint32_t);
+    return kDitherLdsHead +
+           (DitherTabWords(one_trip) + (size_t)(rows > 1 ? rows + 1 : 1) * 3 * (size_t)(w + 2) + 3 * kDitherOverrun) * sizeof(uint32_t);
 }
-constexpr size_t kDitherStaticLds = 512;  // (the progress counters, rounded up generously)
+constexpr size_t kDitherStaticLds = 512;  // (kept free of a workgroup's LDS: nothing static is left in the kernel)
 
 // LDS layout of BandNodesKernel for frames whose bands sort in LDS (words)
 __host__ __device__ inline int BandBitmapWords(int w) { return ((w + 31) >> 5) | 1; }

@@ -82,7 +82,7 @@ def test_known_geometries():
     p = plan(800, 450, 300)
     assert (p["one_trip"], p["dither_parts"], p["dither_waves"]) == (0, 1, 12)
     # the last width at which 13 waves' boundary rows + the zero row + the overrun slack fit beside the small tables
-    assert plan(756, 450, 300)["dither_waves"] == 12 and plan(755, 450, 300)["dither_waves"] == 13
+    assert plan(755, 450, 300)["dither_waves"] == 12 and plan(754, 450, 300)["dither_waves"] == 13
     assert plan(800, 222, 64)["dither_parts"] == 1             # seven row groups: one workgroup
     assert plan(800, 228, 64)["dither_parts"] == 2             # eight: two parts of four
     assert plan(64, 1104, 64)["dither_parts"] == 4 and plan(64, 1104, 1)["dither_parts"] == 9

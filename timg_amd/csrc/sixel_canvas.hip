@@ -939,19 +939,26 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // Two trips: [biased cell] -> palette index, then pal[2][256]: 16 * colour as (r, g) / (b, 0)
     uint8_t *tab8      = reinterpret_cast<uint8_t *>(lds);
     uint32_t *pal      = lds + 8192;
-    // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it
-    // reads): slot c + 1 holds, for the CONSUMER at column c, the three terms it needs as three
-    // consecutive words {1/16 of e(c-1), 5/16 of e(c), 3/16 of e(c+1)} -- the producer at column x
-    // writes into slots x + 2, x + 1 and x.  Slots nobody writes (1/16 left of column 0, 3/16
-    // right of column W-1) keep the zero they are initialised with.
-    const int brow     = (W + 2) * 3;
-    uint32_t *boundary = lds + kDitherTabWords;  // [n_local + 1][W + 2][3]
+    // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it reads).  A row holds one
+    // 12-byte RECORD per column of the producer's last row -- the three terms its error sends down -- at slot x + 1:
+    //     bytes 0..3   3/16 as (r, g, 0, 0)            } written by the even lane of the pair as ONE two-word store
+    //     bytes 4..7   1/16 as (r, g), 5/16 as (r, g)  }
+    //     bytes 8..11  (1/16, 5/16, 3/16) of b, 0      -- the odd lane's store, whose upper half spills into the next
+    //                                                     slot's first word and is overwritten a step later
+    // Slot 0 (column -1) stays zero; column W -- outside the row, all terms zero -- is written like any other, so that
+    // what spilled into slot W + 1 is replaced before the consumer's last column reads it: W + 3 slots, and W + 1
+    // columns to publish.  The consumer reads one record per step (column c needs 1/16 of c - 1, 5/16 of c, 3/16 of
+    // c + 1) and keeps what it unpacked until its column comes.  (Until round 4 the producer scattered its terms
+    // over the three slots of their consumers, six bytes at a time in three stores: 28 clocks of LDS issue a step
+    // against 9, scratch/ubench/wave_latency.hip.)
+    const int brow     = (W + 3) * 3;
+    const int n_pub    = W + 1;                     // columns a row publishes
+    uint32_t *boundary = lds + kDitherTabWords;  // [n_local + 1][W + 3][3]
     int *progress = reinterpret_cast<int *>(lds_all);  // [kDitherMaxWaves]
     // The steps' running addresses are absolute LDS addresses (this array's own address added once, outside the
     // loops) used through address-space-3 pointers: formed as `array + offset` each step paid a v_add of the array's
     // link-time address.
     typedef __attribute__((address_space(3))) uint32_t LdsU32;
-    typedef __attribute__((address_space(3))) uint16_t LdsU16;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
     const int f   = kSplit ? blockIdx.y : blockIdx.x;
     const int tid = threadIdx.x;
@@ -1012,15 +1019,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 const int p = __builtin_amdgcn_readfirstlane(
                     __hip_atomic_load(&progress[n_local - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 asm volatile("" ::: "memory");
-                // (slot c + 1 is final once the producer has finished column c + 1; the last two with the row)
-                const int limit = p >= W ? W + 2 : p;
+                // (slot x + 1 is final once the producer has finished column x; the last one with the row)
+                const int limit = p >= n_pub ? W + 3 : p + 1;
                 if (limit > done) {
                     for (int i = done * 3 + lane; i < limit * 3; i += 64)
                         __hip_atomic_store(xw + i, row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slots have left before the counter does
                     if (lane == 0) __hip_atomic_store(xflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     done = limit;
-                    if (p >= W) break;
+                    if (p >= n_pub) break;
                 } else {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > kDitherSpinLimit) {
@@ -1040,7 +1047,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             for (;;) {
                 const int p     = __builtin_amdgcn_readfirstlane(
                     __hip_atomic_load(xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-                const int limit = p >= W ? W + 2 : p;
+                const int limit = p >= n_pub ? W + 3 : p + 1;
                 if (limit > done) {
                     for (int i = done * 3 + lane; i < limit * 3; i += 64)
                         row[i] = __hip_atomic_load(xw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1048,14 +1055,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     if (lane == 0)
                         __hip_atomic_store(&progress[0], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     done = limit;
-                    if (p >= W) break;
+                    if (p >= n_pub) break;
                 } else {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > kDitherSpinLimit) {
                         if (lane == 0) {
                             atomicExch(b.error, 1);
                             // (let the waves behind this one run to their end instead of into their own limit)
-                            __hip_atomic_store(&progress[0], W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&progress[0], n_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         break;
                     }
@@ -1069,8 +1076,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const uint32_t tab_base  = odd ? 0u : 32768u;                 // (one trip: b / r, and g 32 KB behind r)
     const uint8_t *lut8g     = s.lut8;
     const uint32_t *pal_half = pal + (odd ? 256 : 0);             // (two trips)
-    // the term bytes of a boundary word as this half's pair of q << 8
-    auto unpack_term = [&](uint32_t q) -> uint32_t { return __builtin_amdgcn_perm(q, q, sel_hi); };
+    // Record <-> term words (a term word is this half's pair of q << 8: 0xGG00RR00 / 0x0000BB00).  Packing, two
+    // v_perm: w1 = (1/16, 5/16) of this half [odd: b of both, still without the 3/16]; w2 = the 3/16 [odd: w1's two
+    // bytes and the 3/16 -- the finished word]; the 8-byte store takes (w2, w1).  Unpacking, one v_perm per term
+    // from the 8 bytes read (v_perm_b32(hi, lo, .): bytes 0-3 of the selector's index space are lo, 4-7 hi).
+    const uint32_t sel_w1 = odd ? 0x0c0c0501u : 0x07050301u;
+    const uint32_t sel_w2 = odd ? 0x0c050100u : 0x0c0c0705u;
+    const uint32_t sel_u1 = odd ? 0x0c0c000cu : 0x050c040cu;
+    const uint32_t sel_u5 = odd ? 0x0c0c010cu : 0x070c060cu;
+    const uint32_t sel_u3 = odd ? 0x0c0c020cu : 0x010c000cu;
 
     const int rows_per_round = (kSplit ? n_all : n_waves) * kPairRows;  // (kSplit: one round)
     const int first_row      = (group0 + wave - lw0) * kPairRows;
@@ -1104,15 +1118,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         const bool follows       = producer_round >= 0;
         // Addresses that advance by a constant per step are kept per BLOCK of eight steps (in_addr, out_addr, idx_addr
         // below, bumped at the end of the unrolled body): the steps then address with immediate offsets instead of a
-        // multiply-add each.  in_addr: the row above, as a byte offset into the dynamic LDS, at column t.
-        uint32_t in_addr         = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + (follows ? producer : zero_row) * brow) * 4u;
-        asm("" : "+v"(in_addr));  // (wave-uniform, but wanted in a vector register: it is a ds_read address)
-        // (this wave's boundary row as a byte offset into the dynamic LDS: 32-bit address arithmetic in the step)
-        uint32_t out_addr        = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + wave * brow) * 4u + (odd ? 2u : 0u) -
-                                   24u * (uint32_t)rl;  // (at x = t - 2 * rl)
+        // multiply-add each.  in_addr: this half's part of slot t of the row above (absolute LDS address).
+        uint32_t in_addr         = lds0 + (uint32_t)kDitherLdsHead +
+                                   (uint32_t)(kDitherTabWords + (follows ? producer : zero_row) * brow) * 4u + (odd ? 8u : 0u);
+        // out_addr: this half's part of the record of column x = t - 2 * rl in this wave's own row
+        uint32_t out_addr        = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + wave * brow) * 4u + 12u +
+                                   (odd ? 8u : 0u) - 24u * (uint32_t)rl;
         // (a wave with no row above it finds every column "published": its own counter, against a base far below)
-        const int in_base        = follows ? producer_round * W : -(1 << 30);
-        const int out_base       = round * W;
+        const int in_base        = follows ? producer_round * n_pub : -(1 << 30);
+        const int out_base       = round * n_pub;
 
         // terms of this row's own recent errors (pairs of q << 8):
         //   own7 = 7/16 of e(x-1)  -> this row's next pixel
@@ -1120,8 +1134,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;
         uint32_t first_q3 = 0;
         uint32_t packed_idx = 0;
-        uint32_t bl = 0, bc = 0, br = 0;        // terms from above for the wave's first row, this step
-        uint32_t n_bl = 0, n_bc = 0, n_br = 0;  // ... and, still packed, for the next step
+        // terms from above for the wave's first row: at step t (column t) it adds 1/16 of the error of column t - 1, 5/16
+        // of column t, 3/16 of column t + 1; record t + 2 is unpacked, record t + 3 requested
+        uint32_t up1_a = 0, up1_b = 0, up1_c = 0;  // 1/16 of columns t - 1, t, t + 1
+        uint32_t up5_a = 0, up5_b = 0;             // 5/16 of columns t, t + 1
+        uint32_t up3_a = 0;                        // 3/16 of column t + 1
+        uint32_t n_lo = 0, n_hi = 0;               // the record requested a step ago, still packed
         // The producer's progress counter is read EVERY step, one step before it is looked at (two instructions, no
         // wait: the value has long arrived), so a wave follows its producer as closely as the data allows and the
         // common case -- the producer is far enough -- is a branch that is NOT taken.  (Measured with
@@ -1148,24 +1166,31 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             }
             asm volatile("" ::: "memory");
         };
-        // the first row's terms for column c are complete once the producer has finished column
-        // c + 1; they are requested one step before they are unpacked
-        // (the slot is not clamped to the row: past its end the slots of the following row -- or the slack behind the
-        // last one, sixel_launch.h -- are read, for lanes that are outside their rows by then)
-        auto request = [&](int c, uint32_t slot_addr) __attribute__((always_inline)) {
-            wait_for(min(c + 2, W));
+        // record x is complete once the producer has finished column x (x + 1 columns published); a record is
+        // requested one step before it is unpacked.  (The slot is not clamped to the row: past its end the slots of the
+        // following row -- or the slack behind the last one, sixel_launch.h -- are read, for lanes that are outside
+        // their rows by then.)
+        auto request = [&](int x_rec, uint32_t slot_addr) __attribute__((always_inline)) {
+            wait_for(min(x_rec + 1, n_pub));
             peek();
-            const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = row above + (c + 1) * 12
-            n_bl = slot[0];
-            n_bc = slot[1];
-            n_br = slot[2];
+            const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = this half's part of slot x_rec + 1
+            n_lo = slot[0];
+            n_hi = slot[1];
+        };
+        auto unpack = [&](uint32_t &m1, uint32_t &m5, uint32_t &m3) __attribute__((always_inline)) {
+            m1 = __builtin_amdgcn_perm(n_hi, n_lo, sel_u1);
+            m5 = __builtin_amdgcn_perm(n_hi, n_lo, sel_u5);
+            m3 = __builtin_amdgcn_perm(n_hi, n_lo, sel_u3);
         };
         peek();
-        request(0, in_addr + 12u);
-        bl = unpack_term(n_bl);
-        bc = unpack_term(n_bc);
-        br = unpack_term(n_br);
-        request(1, in_addr + 24u);
+        {
+            uint32_t unused;
+            request(0, in_addr + 12u);
+            unpack(up1_b, up5_a, unused);  // column 0: its 1/16 goes to column 1, its 5/16 to column 0
+            request(1, in_addr + 24u);
+            unpack(up1_c, up5_b, up3_a);   // column 1
+            request(2, in_addr + 36u);     // (unpacked by step 0)
+        }
 
         // Source pixels: unconditional, from clamped addresses, 8 steps ahead, as inline assembly
         // with hand-placed waits.  Left to the compiler, the ring of 8 loads in flight loses its
@@ -1201,14 +1226,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 if (((k & 3) == 3 ? store_even : store_odd) && (unsigned)(x - kDitherAhead) < (unsigned)g.idx_stride)
                     *reinterpret_cast<uint32_t *>(s.index + (idx_addr + (uint32_t)k)) = packed_idx;
             }
-            // the first row's terms for the next step (requested a step ago), and the request for the step after it
-            const uint32_t q_l = n_bl, q_c = n_bc, q_r = n_br;
-            request(t + 2, in_addr + (uint32_t)(k + 3) * 12u);
+            // the record requested a step ago (column t + 2), and the request for column t + 3
+            const uint32_t q_lo = n_lo, q_hi = n_hi;
+            request(t + 3, in_addr + (uint32_t)(k + 4) * 12u);
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
             if (rl == 0) {
-                up_l = bl;
-                up_c = bc;
-                up_r = br;
+                up_l = up1_a;
+                up_c = up5_a;
+                up_r = up3_a;
             }
             PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_hi) ^ px_bias);  // (px is dead from here: its register takes the next request)
             v = ApplyPair(v, up_l);
@@ -1242,9 +1267,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 px     = fetch(t + kDitherAhead);
                 p_cell = pal_half[lidx];
             }
-            bl = unpack_term(q_l);
-            bc = unpack_term(q_c);
-            br = unpack_term(q_r);
+            up1_a = up1_b;
+            up1_b = up1_c;
+            up5_a = up5_b;
+            up1_c = __builtin_amdgcn_perm(q_hi, q_lo, sel_u1);
+            up5_b = __builtin_amdgcn_perm(q_hi, q_lo, sel_u5);
+            up3_a = __builtin_amdgcn_perm(q_hi, q_lo, sel_u3);
             // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
             // zero in lanes that never spread (k_err, c16_mask) and outside the columns 0 .. W - 2 of the row
             const PairU16 p8  = __builtin_bit_cast(PairU16, p_cell);
@@ -1260,13 +1288,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t m3 = AsBits(err * k3 + sgn) & 0xff00ff00u;
             const uint32_t m1 = AsBits(err + sgn) & 0xff00ff00u;
             if constexpr ((k & 1) == 0) first_q3 = x == 0 ? m3 : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
-            if (hands_down && (unsigned)x < (unsigned)W) {
-                // term word r | g << 8 | b << 16: the even lane writes its low half (r, g), the
-                // odd lane the high half (b, 0), each the low bytes of its two 16-bit values
-                const uint32_t o = out_addr + (uint32_t)k * 12u;
-                *(LdsU16 *)(uintptr_t)(o + 24) = (uint16_t)__builtin_amdgcn_perm(m1, m1, 0x0c0c0301u);
-                *(LdsU16 *)(uintptr_t)(o + 16) = (uint16_t)__builtin_amdgcn_perm(m5, m5, 0x0c0c0301u);
-                *(LdsU16 *)(uintptr_t)(o + 8)  = (uint16_t)__builtin_amdgcn_perm(m3, m3, 0x0c0c0301u);
+            if (hands_down && (unsigned)x < (unsigned)n_pub) {  // (column W: outside the row, a record of zeros)
+                const uint32_t w1 = __builtin_amdgcn_perm(m5, m1, sel_w1);
+                const uint32_t w2 = __builtin_amdgcn_perm(m3, w1, sel_w2);
+                // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32, not a ds_write_b64)
+                LdsU32 *rec = (LdsU32 *)(uintptr_t)(out_addr + (uint32_t)k * 12u);
+                rec[0] = w2;
+                rec[1] = w1;
                 asm volatile("" ::: "memory");
                 if (!odd)
                     __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,

@@ -25,9 +25,9 @@ constexpr int kBandLanes     = 512;  // lanes per band of BandNodesKernel (frame
 constexpr int kDitherMaxWaves = 16;
 constexpr int kPairRows       = 32;  // rows per wave
 // The diffusion of a frame spread over several workgroups (CUs): hand-over buffer of one boundary between two of
-// them -- the boundary row's (W + 2) x 3 words, then (in a cache line of its own) the producer's progress counter
+// them -- the boundary row's (W + 3) x 3 words, then (in a cache line of its own) the producer's progress counter
 constexpr int kDitherMaxParts = 16;
-__host__ __device__ inline int XwgData(int w) { return ((w + 2) * 3 + 31) & ~31; }
+__host__ __device__ inline int XwgData(int w) { return ((w + 3) * 3 + 31) & ~31; }
 __host__ __device__ inline int XwgStride(int w) { return XwgData(w) + 32; }
 // Two forms of the diffusion's table lookup (DitherKernel<., ., kOneTrip>):
 //  * one trip: the palette COLOUR of every 15-bit cell in LDS -- three byte tables b, r, g of 32 KB each; one LDS
@@ -45,7 +45,7 @@ constexpr int kDitherOverrun = 96;
 constexpr int kDitherLdsHead = 64;  // bytes in front of the tables: the waves' progress counters
 inline size_t DitherLdsBytes(int w, int rows, bool one_trip) {
     return kDitherLdsHead +
-           (DitherTabWords(one_trip) + (size_t)(rows > 1 ? rows + 1 : 1) * 3 * (size_t)(w + 2) + 3 * kDitherOverrun) * sizeof(uint32_t);
+           (DitherTabWords(one_trip) + (size_t)(rows > 1 ? rows + 1 : 1) * 3 * (size_t)(w + 3) + 3 * kDitherOverrun) * sizeof(uint32_t);
 }
 constexpr size_t kDitherStaticLds = 512;  // (kept free of a workgroup's LDS: nothing static is left in the kernel)
 

@@ -93,11 +93,14 @@ def test_built_library_passes():
     assert r.returncode == 0, r.stdout[-2000:]
     # 4 instantiations of the matrix kernel + 18 of the horizontal-first kernel (3 channel sets x 3 tap counts x 2 load widths)
     assert "22 kernels" in r.stdout
-    # the sixel diffusion keeps eight source pixels in flight the same way (two instantiations)
+    # ... and the four matrix instantiations write their A operand by v_writelane, four wait states ahead of the first v_mfma
+    assert "4 kernels with v_writelane -> v_mfma" in r.stdout
+    # the sixel diffusion keeps eight source pixels (and, in its one-trip forms, eight palette indices) in flight the
+    # same way: five instantiations
     sixel = BUILT.replace("scale_stream", "sixel_canvas")
     r = subprocess.run([sys.executable, CHECK, sixel], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "3 kernels" in r.stdout
+    assert "5 kernels" in r.stdout
 
 
 def test_single_register_ring_is_checked_too(tmp_path):
@@ -117,3 +120,64 @@ _Z6kernelv:
     path.write_text(body)
     r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
     assert r.returncode == 1 and "v[7:7]" in r.stdout
+
+
+# ---- v_writelane -> v_mfma wait states (the hand-counted s_nop of the matrix kernel) -----------------------------
+MFMA = """\
+_Z6kernelv:
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[2:5], v[20:21], off
+\t;;#ASMEND
+{pre}\t;;#ASMSTART
+\tv_writelane_b32 v157, s48, 0
+\tv_writelane_b32 v157, s49, 1
+\tv_writelane_b32 v157, s50, 2
+\tv_writelane_b32 v157, s51, 3
+{nop}\t;;#ASMEND
+{mid}\tv_mfma_f32_4x4x1_16b_f32 v[54:57], v157, v58, 0 cbsz:4
+\tv_mfma_f32_4x4x1_16b_f32 v[50:53], v157, v59, 0 cbsz:4
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0) ; ring all
+\t;;#ASMEND
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def run_mfma(tmp_path, pre="", nop="\ts_nop 3\n", mid=""):
+    path = tmp_path / "m.s"
+    path.write_text(MFMA.format(pre=pre, nop=nop, mid=mid))
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    return r.returncode, r.stdout
+
+
+def test_writelane_then_mfma_with_the_nop_passes(tmp_path):
+    rc, out = run_mfma(tmp_path)
+    assert rc == 0 and "all 4 wait states apart" in out, out
+
+
+def test_missing_or_short_nop_is_caught(tmp_path):
+    rc, out = run_mfma(tmp_path, nop="")
+    assert rc == 1 and "reads v157 0 wait state(s)" in out, out
+    rc, out = run_mfma(tmp_path, nop="\ts_nop 1\n", mid="\ts_bitcmp1_b32 s98, 0\n")  # 2 + 1 = 3 < 4
+    assert rc == 1 and "reads v157 3 wait state(s)" in out, out
+    # ... and other instructions count as wait states like the nop does
+    rc, out = run_mfma(tmp_path, nop="\ts_nop 1\n", mid="\ts_bitcmp1_b32 s98, 0\n\ts_cselect_b64 s[4:5], -1, 0\n")
+    assert rc == 0, out
+
+
+def test_short_path_around_the_nop_is_caught(tmp_path):
+    # a branch from right behind the v_writelane to the v_mfma skips the padding: the minimum over the paths counts
+    pre = ""
+    nop = "\ts_nop 3\n"
+    body = MFMA.format(pre=pre, nop="", mid="\ts_cbranch_scc1 .LBB0_7\n\ts_nop 3\n.LBB0_7:\n")
+    path = tmp_path / "m.s"
+    path.write_text(body)
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "reads v157 1 wait state(s)" in r.stdout, r.stdout
+
+
+def test_sgpr_spill_writelanes_do_not_disturb(tmp_path):
+    # the compiler spills scalar registers into lanes of a VGPR with the same instruction: no v_mfma reads those
+    rc, out = run_mfma(tmp_path, mid="\tv_writelane_b32 v214, s12, 0\n")
+    assert rc == 0, out

@@ -12,6 +12,13 @@ set would read data that has not arrived, or be overwritten when it does).
 Method: basic blocks from labels and branches, forward may-analysis of "sets in flight" (union over
 predecessors, to a fixed point), then every instruction is checked against the sets in flight before it.
 
+Second property, same assembly: the matrix kernel writes the A operand of its v_mfma products with inline-asm
+`v_writelane_b32` (four weights into lanes 0-3) and pads the VALU-write -> MFMA-read hazard by hand (`s_nop 3`): the
+compiler does not see that write, so it inserts nothing.  Missing wait states showed as wrong red channels in every
+sixth output row (round 2).  Here: on every path from a `v_writelane_b32 vN` to a `v_mfma*` that reads vN there are at
+least MFMA_WAIT_STATES wait states (an instruction counts one, `s_nop n` counts n + 1) -- a forward analysis of
+"wait states since the last v_writelane" per register, minimum over predecessors.
+
 Exit status 0: every kernel that uses the ring is clean.  1: a violation (printed)."""
 import re
 import sys
@@ -135,6 +142,100 @@ def check_kernel(lines):
     return loads, waits, bad
 
 
+MFMA_WAIT_STATES = 4  # what `s_nop 3` provides between the last v_writelane and the first v_mfma (scale_stream.hip)
+WRITELANE = re.compile(r"v_writelane_b32 v(\d+),")
+NOP = re.compile(r"s_nop (\d+)")
+
+
+def parse_all_blocks(lines):
+    """Like parse_blocks, but every instruction counts -- those inside asm statements too (the v_writelane and its
+    s_nop live there)."""
+    blocks = [Block(None)]
+    for no, line in lines:
+        code = line.strip()
+        m = re.match(r"^([.\w$]+):", code)
+        if m:
+            blocks.append(Block(m.group(1)))
+            continue
+        if not code or code[0] in ";.":
+            continue
+        instr = code.split(";")[0].strip()
+        if not instr:
+            continue
+        op = instr.split()[0]
+        blocks[-1].ops.append((no, "instr", instr))
+        if op == "s_branch":
+            blocks[-1].succ_labels.append(instr.split()[1])
+            blocks[-1].falls = False
+            blocks.append(Block(None))
+        elif op.startswith("s_cbranch"):
+            blocks[-1].succ_labels.append(instr.split()[1])
+            blocks.append(Block(None))
+        elif op == "s_endpgm":
+            blocks[-1].falls = False
+            blocks.append(Block(None))
+    by_label = {b.label: b for b in blocks if b.label}
+    for i, b in enumerate(blocks):
+        b.succ = [by_label[l] for l in b.succ_labels if l in by_label]
+        if b.falls and i + 1 < len(blocks):
+            b.succ.append(blocks[i + 1])
+    return blocks
+
+
+def mfma_step(state, instr, no, report):
+    """state: {vgpr: wait states since a v_writelane wrote it} (only registers below MFMA_WAIT_STATES are kept)."""
+    op = instr.split()[0]
+    if op.startswith("v_mfma") and state:
+        operands = instr[len(op):].split(",")
+        read = regs_of(",".join(operands[1:]))  # (everything but the destination: A, B and the accumulator)
+        for r in read:
+            if r in state and report is not None:
+                report.append((no, instr, "v%d" % r, state[r]))
+    m = NOP.match(instr)
+    states = int(m.group(1)) + 1 if m else 1
+    out = {r: n + states for r, n in state.items() if n + states < MFMA_WAIT_STATES}
+    m = WRITELANE.match(instr)
+    if m:
+        out[int(m.group(1))] = 0
+    return out
+
+
+def check_mfma_waits(lines):
+    if not any("v_mfma" in l for _, l in lines) or not any("v_writelane_b32" in l for _, l in lines):
+        return 0, []
+    blocks = parse_all_blocks(lines)
+    for b in blocks:
+        b.entry = None  # None: not reached yet; else {vgpr: wait states}
+    blocks[0].entry = {}
+    work = [blocks[0]]
+    while work:
+        b = work.pop()
+        state = dict(b.entry)
+        for no, _, instr in b.ops:
+            state = mfma_step(state, instr, no, None)
+        for s in b.succ:
+            if s.entry is None:
+                merged = dict(state)
+            else:  # the minimum over the predecessors: a register is "recent" if it is on any path
+                merged = dict(s.entry)
+                for r, n in state.items():
+                    merged[r] = min(n, merged.get(r, MFMA_WAIT_STATES))
+            if merged != s.entry:
+                s.entry = merged
+                work.append(s)
+    bad = []
+    n_mfma = 0
+    for b in blocks:
+        if b.entry is None:
+            continue
+        state = dict(b.entry)
+        for no, _, instr in b.ops:
+            if instr.startswith("v_mfma"):
+                n_mfma += 1
+            state = mfma_step(state, instr, no, bad)
+    return n_mfma, bad
+
+
 def main(path):
     kernels, cur = [], None
     for no, line in enumerate(open(path), 1):
@@ -146,8 +247,17 @@ def main(path):
             cur = None
         elif cur is not None:
             cur.append((no, line.rstrip("\n")))
-    status, checked = 0, 0
+    status, checked, mfma_kernels = 0, 0, 0
     for name, lines in kernels:
+        n_mfma, late = check_mfma_waits(lines)
+        if n_mfma:
+            mfma_kernels += 1
+        for no, instr, reg, n in late[:20]:
+            print("%s:%d: '%s' reads %s %d wait state(s) after a v_writelane_b32 wrote it (needs %d)"
+                  % (path, no, instr, reg, n, MFMA_WAIT_STATES))
+        if late:
+            print("%s: %d v_mfma reads too close behind a v_writelane" % (name, len(late)))
+            status = 1
         loads, waits, bad = check_kernel(lines)
         if loads == 0:
             continue
@@ -164,7 +274,10 @@ def main(path):
         print("%s: no kernel with a register ring found" % path)
         status = 1
     if status == 0:
-        print("check_ring_isa: %s: %d kernels, no instruction touches a register set in flight" % (path.split("/")[-1], checked))
+        print("check_ring_isa: %s: %d kernels, no instruction touches a register set in flight%s"
+              % (path.split("/")[-1], checked,
+                 "; %d kernels with v_writelane -> v_mfma, all %d wait states apart" % (mfma_kernels, MFMA_WAIT_STATES)
+                 if mfma_kernels else ""))
     return status
 
 

@@ -1170,8 +1170,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // requested one step before it is unpacked.  (The slot is not clamped to the row: past its end the slots of the
         // following row -- or the slack behind the last one, sixel_launch.h -- are read, for lanes that are outside
         // their rows by then.)
-        auto request = [&](int x_rec, uint32_t slot_addr) __attribute__((always_inline)) {
-            wait_for(min(x_rec + 1, n_pub));
+        auto request = [&](int x_rec, uint32_t slot_addr, bool check = true) __attribute__((always_inline)) {
+            if (check) wait_for(min(x_rec + 1, n_pub));
             peek();
             const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = this half's part of slot x_rec + 1
             n_lo = slot[0];
@@ -1228,7 +1228,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             }
             // the record requested a step ago (column t + 2), and the request for column t + 3
             const uint32_t q_lo = n_lo, q_hi = n_hi;
-            request(t + 3, in_addr + (uint32_t)(k + 4) * 12u);
+            // (the counter is looked at every other step, for two records: half the scalar work of the check)
+            request(t + 3 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 4) * 12u, (k & 1) == 0);
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
             if (rl == 0) {
                 up_l = up1_a;

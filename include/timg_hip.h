@@ -232,14 +232,10 @@ void timg_hip_block_canvas_forget(timg_hip_block_canvas *c);
  * within a stated Delta-E of the CPU restatement (libsixel is un-vendored:
  * parity unpinned). */
 #define TIMG_HIP_SIXEL_BROKEN_CURSOR 1 /* SixelOptions::known_broken_cursor_placement */
-/* A CHECKER MODE, not a production path: libsixel's lookup cache exactly as sixel_encode fills it -- a 15-bit cell
- * answers with the palette entry nearest to the FIRST pixel value that lands in it, in raster order, diffused errors
- * included.  That order is inherently serial: one wave walks a frame, ~0.3 s per 800x450 frame (15x slower than one
- * host thread running the same rule).  It exists so that the device's default rule can be compared with libsixel's
- * semantics pixel by pixel on the device (the per-pixel bound in DESIGN.md 2, tests/test_sixel_oracle.py); a
- * maintainer who needs libsixel's exact cache behaviour at speed keeps the CPU SixelCanvas.  Without the flag a cell
- * answers with the entry nearest to its centre and the diffusion is pipelined (1.6 ms per 64 frames). */
-#define TIMG_HIP_SIXEL_FIRST_HIT 2
+/* (One lookup rule: a 15-bit cell answers with the palette entry nearest to its centre, and the diffusion is
+ * pipelined.  libsixel's own first-hit cache -- inherently serial, ~0.3 s per 800x450 frame -- exists as a checker in the
+ * TEST-ONLY libtimg_hip_debug.so (timg_hip_debug_sixel_encode_first_hit, csrc/sixel_canvas.hip), not here; a maintainer
+ * who needs libsixel's exact cache behaviour keeps the CPU SixelCanvas.  Unknown flag bits are TIMG_HIP_ERR_ARG.) */
 
 size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
 

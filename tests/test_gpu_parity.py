@@ -443,12 +443,13 @@ def test_sixel_diffusion_hand_over_under_uneven_load(hip):
 @pytest.mark.parametrize("kind,w,h", [("photo", 320, 203), ("alpha", 200, 100), ("noise", 97, 61), ("photo", 64, 7),
                                       ("noise", 33, 6), ("photo", 2, 13), ("alpha", 1, 1), ("photo", 800, 450)])
 def test_sixel_first_hit_lookup_is_libsixels_cache(hip, oracle, kind, w, h):
-    """TIMG_HIP_SIXEL_FIRST_HIT: the 15-bit lookup cache filled the way sixel_encode fills it (the entry of a cell
-    is the palette colour nearest to the first pixel value that lands in it, raster order, diffused errors
-    included) -- byte-identical to the restatement's lookup_mode 0, pad rows and checkerboard included."""
+    """The checker in libtimg_hip_debug.so (timg_hip_debug_sixel_encode_first_hit): the 15-bit lookup cache filled the
+    way sixel_encode fills it (the entry of a cell is the palette colour nearest to the first pixel value that lands
+    in it, raster order, diffused errors included) -- byte-identical to the restatement's lookup_mode 0, pad rows and
+    checkerboard included.  The product library has one rule (lookup_mode 1) and rejects unknown flags."""
     fb = synth.make(kind, w, h, seed=9)
-    got = hip.sixel_encode(fb, w, h, flags=timg_amd.TimgHip.SIXEL_FIRST_HIT, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 4),
-                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    got = hip.sixel_encode_first_hit(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 4),
+                                     out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
     want = oracle.sixel_encode(fb, BG, PAT, 4, 4, lookup_mode=0)
     assert len(got) == len(want) and got == want, (len(got), len(want))
 
@@ -456,15 +457,16 @@ def test_sixel_first_hit_lookup_is_libsixels_cache(hip, oracle, kind, w, h):
 def test_sixel_first_hit_batch_and_few_colours(hip, oracle):
     n, w, h = 3, 120, 40
     frames = np.stack([synth.photo(w, h, 70 + i) for i in range(n)])
-    outs = hip.sixel_encode(frames, w, h, flags=timg_amd.TimgHip.SIXEL_FIRST_HIT, n_frames=n)
+    outs = hip.sixel_encode_first_hit(frames, w, h, n_frames=n)
     for i in range(n):
         assert outs[i] == oracle.sixel_encode(frames[i], has_getter=False, lookup_mode=0), i
     fb = np.zeros((36, 120, 4), np.uint8)  # <= 256 colours: no diffusion, the palette is the histogram
     fb[..., 3] = 255
     for i in range(20):
         fb[:, 6 * i:6 * i + 6, :3] = (8 * i % 256, 16 * (i % 16), 248 - 8 * (i % 32))
-    assert hip.sixel_encode(fb, 120, 36, flags=timg_amd.TimgHip.SIXEL_FIRST_HIT)[0] == \
-        oracle.sixel_encode(fb, has_getter=False, lookup_mode=0)
+    assert hip.sixel_encode_first_hit(fb, 120, 36)[0] == oracle.sixel_encode(fb, has_getter=False, lookup_mode=0)
+    with pytest.raises(timg_amd.TimgHipError):  # (what used to select the checker through the product entry point)
+        hip.sixel_encode(fb, 120, 36, flags=2)
 
 
 def test_sixel_within_stated_delta_e_of_the_libsixel_like_lookup(hip, oracle):

@@ -1362,6 +1362,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     if (gave_up && lane == 0) atomicExch(b.error, 1);
 }
 
+// (libtimg_hip_debug.so only -- csrc/Makefile compiles this file a second time with TIMG_SIXEL_FIRST_HIT_BUILD: the
+// product library has ONE lookup rule, the pipelined one above)
+#ifdef TIMG_SIXEL_FIRST_HIT_BUILD
 // ---- K4, first-hit variant: libsixel's lookup cache as libsixel fills it -----------------------------
 // sixel_encode looks a pixel up through a 15-bit (5:5:5) cache whose entry is the palette colour nearest to
 // the FIRST pixel value that lands in the cell -- first in raster order, with the diffused errors of all
@@ -1453,6 +1456,7 @@ __global__ void __launch_bounds__(64) DitherFirstHitKernel(SixelGeom g, SixelBat
         __syncthreads();
     }
 }
+#endif  // TIMG_SIXEL_FIRST_HIT_BUILD
 
 // ---- K5: band encode, three kernels --------------------------------------------------------
 // libsixel encodes a 6-row band as "nodes" (a colour's run of columns, gaps of < 10
@@ -2214,9 +2218,11 @@ using namespace timg_amd;
 
 static size_t Round6(int h) { return (size_t)((h + 5) - (h + 5) % 6); }
 
+#ifndef TIMG_SIXEL_FIRST_HIT_BUILD
 extern "C" size_t timg_hip_sixel_max_bytes(int w, int h) {
     return 1024 + (size_t)w * Round6(h) * 5;  // src/sixel-canvas.cc:123
 }
+#endif
 
 // The encoder behind timg_hip_sixel_encode and timg_hip_scale_sixel_encode.  pieces_req > 0: the batch is cut into
 // that many pieces whose kernel chains run on the context's side streams (forked from / joined to `stream` with
@@ -2224,13 +2230,21 @@ extern "C" size_t timg_hip_sixel_max_bytes(int w, int h) {
 // kernel is enqueued -- the fused entry point launches the piece's SCALE there, so that it runs beside the serial
 // stages (median cut, diffusion: one workgroup per frame) of the pieces in front of it.  hook_ms (optional): device
 // time of the hooks' work, summed over the pieces (HIP events on the pieces' own streams).
+// (the second compilation of this file, for libtimg_hip_debug.so, is the same encoder with DitherFirstHitKernel in
+// the place of BuildLut + Dither, under its own names: nothing of it is reachable through libtimg_hip.so)
+#ifdef TIMG_SIXEL_FIRST_HIT_BUILD
+#define TIMG_SIXEL_IMPL SixelEncodeFirstHitImpl
+#else
+#define TIMG_SIXEL_IMPL SixelEncodeImpl
+#endif
 namespace timg_amd {
-int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride, size_t frame_stride,
+int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride, size_t frame_stride,
                     int fb_on_device, int n_frames, int flags, const timg_hip_blend *pad_blend, char *out,
                     size_t out_cap, int out_on_device, size_t *out_len, void *stream, int pieces_req,
                     const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms) {
     if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0)
         return TIMG_HIP_ERR_ARG;
+    if (flags & ~TIMG_HIP_SIXEL_BROKEN_CURSOR) return ctx->Fail(TIMG_HIP_ERR_ARG, "unknown sixel flags 0x%x", flags);
     if (w > kMaxSixelWidth)
         return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "sixel width %d > %d", w, kMaxSixelWidth);
     if (stride == 0) stride = w * 4;
@@ -2396,11 +2410,11 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds));
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)HistKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLdsBytes));
-    const bool first_hit       = (flags & TIMG_HIP_SIXEL_FIRST_HIT) != 0;
+#ifdef TIMG_SIXEL_FIRST_HIT_BUILD
     const size_t first_hit_lds = (16384 + 256) * sizeof(uint32_t) + 2 * (size_t)((3 * w + 3) & ~3);
-    if (first_hit)
-        TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherFirstHitKernel,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)first_hit_lds));
+    TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)DitherFirstHitKernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)first_hit_lds));
+#endif
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)MedianCutKernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kCutLdsBytes));
@@ -2464,9 +2478,11 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         }
         hipLaunchKernelGGL(HistKernel, dim3(nfr), dim3(kHistThreads), kHistLdsBytes, gs, g, gb);
         hipLaunchKernelGGL(MedianCutKernel, dim3(nfr), dim3(kCutWaves * 64), kCutLdsBytes, gs, g, gb);
-        if (first_hit) {
-            hipLaunchKernelGGL(DitherFirstHitKernel, dim3(nfr), dim3(64), first_hit_lds, gs, g, gb);
-        } else {
+#ifdef TIMG_SIXEL_FIRST_HIT_BUILD
+        hipLaunchKernelGGL(DitherFirstHitKernel, dim3(nfr), dim3(64), first_hit_lds, gs, g, gb);
+        (void)dither_fn; (void)dither_block; (void)dither_dyn; (void)dither_parts;
+#else
+        {
             hipLaunchKernelGGL(BuildLutKernel, dim3(64, nfr), dim3(256), 0, gs, g, gb);
             {
                 SixelGeom kg       = g;
@@ -2476,6 +2492,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
                 TIMG_HIP_TRY(ctx, hipLaunchKernel(dither_fn, grid, dither_block, kargs, dither_dyn, gs));
             }
         }
+#endif
         if (wide_bands)
             hipLaunchKernelGGL((BandNodesKernel<true, 256>), dim3(g.bands, nfr), dim3(256), nodes_lds, gs, g, gb);
         else
@@ -2519,6 +2536,7 @@ int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
 }
 }  // namespace timg_amd
 
+#ifndef TIMG_SIXEL_FIRST_HIT_BUILD
 extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h,
                                      int stride, size_t frame_stride, int fb_on_device,
                                      int n_frames, int flags, const timg_hip_blend *pad_blend,
@@ -2527,3 +2545,17 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
     return timg_amd::SixelEncodeImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, pad_blend, out,
                                      out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr);
 }
+#else
+// TEST-ONLY (libtimg_hip_debug.so): timg_hip_sixel_encode with libsixel's own lookup rule -- a 15-bit cell answers with
+// the palette entry nearest to the FIRST pixel value that lands in it, in raster order, diffused errors included (what
+// sixel_encode executes; oracle/sixel.c lookup_mode 0).  That order is serial: one wave walks a frame, ~0.3 s per
+// 800x450 frame.  It exists so that the product's rule can be compared with libsixel's semantics pixel by pixel on
+// the device (the per-pixel bound of DESIGN.md 2); ctx is a context of libtimg_hip.so.
+extern "C" int timg_hip_debug_sixel_encode_first_hit(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                                                     size_t frame_stride, int fb_on_device, int n_frames, int flags,
+                                                     const timg_hip_blend *pad_blend, char *out, size_t out_cap,
+                                                     int out_on_device, size_t *out_len, void *stream) {
+    return timg_amd::SixelEncodeFirstHitImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, pad_blend,
+                                             out, out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr);
+}
+#endif

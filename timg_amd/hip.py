@@ -187,7 +187,7 @@ class TimgHip:
     """One timg_hip_ctx."""
 
     QUARTER, UPPER, COLOR256 = 1, 2, 4
-    SIXEL_BROKEN_CURSOR, SIXEL_FIRST_HIT = 1, 2  # timg_hip_sixel_encode flags
+    SIXEL_BROKEN_CURSOR = 1  # timg_hip_sixel_encode flag
 
     def __init__(self, device: int = 0):
         self.L = load_library()
@@ -372,6 +372,23 @@ class TimgHip:
 
     def sixel_max_bytes(self, w, h) -> int:
         return int(self.L.timg_hip_sixel_max_bytes(w, h))
+
+    def sixel_encode_first_hit(self, fb, w, h, flags=0, pad_blend: Blend | None = None, n_frames=1, out_cap=None):
+        """TEST-ONLY: the encoder under libsixel's own first-hit lookup rule, from libtimg_hip_debug.so
+        (timg_hip_debug_sixel_encode_first_hit: serial, ~0.3 s per 800x450 frame); host output."""
+        if not hasattr(self, "_debug_lib"):
+            self._debug_lib = ctypes.CDLL(os.path.join(_HERE, "libtimg_hip_debug.so"))
+            self._debug_lib.timg_hip_debug_sixel_encode_first_hit.restype = ctypes.c_int
+        p, dev = _ptr(fb)
+        if out_cap is None:
+            out_cap = self.sixel_max_bytes(w, h)
+        out = np.empty(out_cap * n_frames, np.uint8)
+        lens = (c_size_t * n_frames)()
+        self._check(self._debug_lib.timg_hip_debug_sixel_encode_first_hit(
+            self.ctx, p, c_int(w), c_int(h), c_int(0), c_size_t(0), c_int(int(dev)), c_int(n_frames), c_int(flags),
+            byref(pad_blend) if pad_blend is not None else None, c_void_p(out.ctypes.data), c_size_t(out_cap), c_int(0),
+            lens, None))
+        return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
 
     def sixel_encode(self, fb, w, h, flags=0, pad_blend: Blend | None = None, n_frames=1,
                      out=None, out_cap=None, stride=0, frame_stride=0, stream=None):

@@ -22,27 +22,18 @@ static inline int round_to_sixel(int pixels) {  // src/sixel-canvas.cc:91-94
     return pixels - pixels % 6;
 }
 
-static bool FirstHitRequested() {
-    const char *e = getenv("TIMG_HIP_SIXEL_FIRST_HIT");
-    return e && *e && *e != '0';
-}
-
 HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_pool,
                                const SixelOptions &sixel_options,
                                const DisplayOptions &display_opts)
     : TerminalCanvas(ws), options_(display_opts), full_cell_jump_(sixel_options.full_cell_jump),
-      broken_cursor_(sixel_options.known_broken_cursor_placement), first_hit_(FirstHitRequested()),
+      broken_cursor_(sixel_options.known_broken_cursor_placement),
       executor_(thread_pool),
       ctx_(SharedHipContext()) {
     if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
     DeviceFrameConsumerCreated();
 }
 
-// TIMG_HIP_SIXEL_FIRST_HIT=1 in the environment: libsixel's lookup cache exactly as sixel_encode fills it (serial,
-// ~0.3 s per 800x450 frame) instead of the pipelined nearest-to-the-cell's-centre rule
-int HipSixelCanvas::EncodeFlags() const {
-    return (broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0) | (first_hit_ ? TIMG_HIP_SIXEL_FIRST_HIT : 0);
-}
+int HipSixelCanvas::EncodeFlags() const { return broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0; }
 
 int HipSixelCanvas::cell_height_for_pixels(int pixels) const {  // src/sixel-canvas.cc:157-172
     assert(pixels <= 0);

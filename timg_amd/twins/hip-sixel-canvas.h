@@ -60,7 +60,6 @@ private:
     const DisplayOptions &options_;
     const bool full_cell_jump_;
     const bool broken_cursor_;
-    const bool first_hit_;  // TIMG_HIP_SIXEL_FIRST_HIT=1 when the canvas was created
     int EncodeFlags() const;  // timg_hip_sixel_encode flags of this canvas
     ThreadPool *const executor_;
     timg_hip_ctx *const ctx_;

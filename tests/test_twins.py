@@ -55,6 +55,8 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     assert "RCCL gather to the root + ordered hand-over to the write sequencer (world 1): checked" in r.stdout
     # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
     assert "kitty / iTerm2 canvas twins at --compress=0: checked" in r.stdout
+    # what the twins cache on the device: idle scalers bounded over all geometries (LRU), everything given back by a trim
+    assert "scaler / block pools: bounded over 40 geometries, trimmed, still scaling" in r.stdout
     # the sixel twin's stream (variant 0): five frames, the first decodable to a 200x114 raster
     data = dump.read_bytes()
     frames = [b"\x1bP" + part.split(b"\x1b\\")[0] + b"\x1b\\" for part in data.split(b"\x1bP")[1:]]
@@ -62,6 +64,21 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     img, ncolors = oracle.sixel_decode(frames[0])
     assert img.shape[:2] == (114, 200) and 2 <= ncolors <= 256
     assert (img[..., 3] == 255).all()  # every pixel drawn (pad rows blended, not transparent)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,fail_at", [("source", k) for k in (1, 2, 3, 5, 8, 13, 21)] + [("timggrid", 2), ("timggrid", 7),
+                                                                                           ("graphics", 1), ("scaler", 1)])
+def test_a_device_allocation_that_fails_mid_stream_is_survived(mode, fail_at):
+    """TIMG_HIP_FAIL_MALLOC=k: the k-th device allocation after the context exists fails once with out-of-memory -- a pool
+    block, a scaler's tables, the growth of a scratch buffer inside an encode call, wherever k lands.  The twins give
+    back what they cache (HipPoolTrim) and make the call once more (HipCall, hip-context.h): the run completes and
+    every stream still equals the reference classes' byte for byte (it used to end in HipFatal's abort())."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/twins/build/twin_check not built (needs /root/reference at build time)")
+    r = subprocess.run([BIN, mode], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TIMG_HIP_FAIL_MALLOC=str(fail_at)))
+    assert r.returncode == 0 and "all twins match" in r.stdout, (mode, fail_at, r.stdout[-1500:] + r.stderr[-1500:])
 
 
 @pytest.mark.gpu

@@ -61,7 +61,9 @@ public:
     void SendFrames(const Duration &duration, int loops, const volatile sig_atomic_t &interrupt_received,
                     const Renderer::WriteFramebufferFun &sink) final {
         int last_height         = -1;
-        const bool is_animation = frames_.size() > 1;
+        // (by the frames of the SOURCE, as src/stb-image-source.cc:175 decides -- its frames_ holds the whole file, the
+        // frame limit only bounds the inner loop: --frames=1 of an animation is an animation of one frame, looped)
+        const bool is_animation = n_src_ > 1;
         if (!is_animation) loops = 1;
         const bool loop_forever = loops < 0;
         const timg::Duration time_from_first_frame;

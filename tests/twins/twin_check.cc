@@ -815,8 +815,44 @@ static void CheckGatherWriter() {
     fflush(stdout);
 }
 
+// What the twins cache on the device is bounded and can be given back (hip-context.h): idle scalers over ALL
+// geometries (a slide show of differently sized images), pool blocks; after HipPoolTrim a scaler still scales.
+static void CheckPools() {
+    timg_hip_ctx *ctx = SharedHipContext();
+    std::vector<timg_hip_scaler *> held;
+    for (int i = 0; i < 40; ++i) {  // 40 geometries, each used once
+        timg_hip_scaler *s = HipScalerAcquire(ctx, 64 + i, 48 + i, TIMG_HIP_FMT_RGBA, 20 + i % 7, 15 + i % 5, HipScalerFilter());
+        CHECK(s != nullptr, "scaler %d", i);
+        HipScalerRelease(s);
+    }
+    CHECK(HipIdleScalers() <= 24 && HipIdleScalers() >= 1, "idle scalers after 40 geometries: %zu", HipIdleScalers());
+    // the most recently released geometry is still cached, the first one is not
+    const size_t before = HipIdleScalers();
+    timg_hip_scaler *recent = HipScalerAcquire(ctx, 64 + 39, 48 + 39, TIMG_HIP_FMT_RGBA, 20 + 39 % 7, 15 + 39 % 5, HipScalerFilter());
+    CHECK(HipIdleScalers() == before - 1, "the last geometry came from the cache: %zu -> %zu", before, HipIdleScalers());
+    HipScalerRelease(recent);
+    void *blocks[4];
+    for (int i = 0; i < 4; ++i) blocks[i] = HipPoolMalloc(ctx, 1000 + 4 * i);
+    for (int i = 0; i < 4; ++i) HipPoolFree(ctx, blocks[i]);
+    const size_t dropped = HipPoolTrim(ctx);
+    CHECK(dropped >= 4 + 1 && HipIdleScalers() == 0, "trim dropped %zu objects, %zu scalers left", dropped, HipIdleScalers());
+    CHECK(HipPoolTrim(ctx) == 0, "a second trim finds nothing");
+    Framebuffer in(103, 87), out_ref(24, 19), out_hip(24, 19);
+    Fill(&in, 0);
+    std::unique_ptr<ImageScaler> ref = ImageScaler::Create(103, 87, ImageScaler::ColorFmt::kRGB32, 24, 19);
+    std::unique_ptr<ImageScaler> hip = HipImageScaler::Create(103, 87, ImageScaler::ColorFmt::kRGB32, 24, 19);
+    CHECK(ref && hip, "scalers after the trim");
+    if (ref && hip) {
+        ref->Scale(in, &out_ref);
+        hip->Scale(in, &out_hip);
+        CHECK(memcmp(out_ref.begin(), out_hip.begin(), 24 * 19 * 4) == 0, "a scaler created after the trim scales");
+    }
+    printf("scaler / block pools: bounded over 40 geometries, trimmed, still scaling\n");
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|bilinear] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|pools|bilinear] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -837,6 +873,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "source" || what == "animation") CheckAnimationSource();
     if (what == "all" || what == "source" || what == "autocrop") CheckAutoCropSource();
     if (what == "all" || what == "gather") CheckGatherWriter();
+    if (what == "all" || what == "pools") CheckPools();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);
         return 1;

@@ -139,6 +139,7 @@ int timg_hip_init(int device, timg_hip_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         ctx->cu_count = prop.multiProcessorCount;
     *out = ctx;
+    timg_amd::ArmMallocInjection();
     return TIMG_HIP_OK;
 }
 

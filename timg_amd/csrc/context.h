@@ -105,9 +105,12 @@ struct timg_hip_ctx {
     // A device call failed, possibly after copies and kernels on this context's scratch memory
     // were enqueued: nothing may still be in flight when the caller's lock on `mu` is released
     // and the next caller reuses (or re-allocates) that scratch.
+    // (Out of device memory is its own code: the one failure a caller can do something about -- give back what it
+    // caches and call again, timg_amd/twins/hip-context.h HipCall.)
     int FailHip(hipError_t e, const char *what) {
         (void)hipDeviceSynchronize();
-        return Fail(TIMG_HIP_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+        if (e == hipErrorOutOfMemory) (void)hipGetLastError();  // (not sticky: the next call starts clean)
+        return Fail(e == hipErrorOutOfMemory ? TIMG_HIP_ERR_NOMEM : TIMG_HIP_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
     }
     hipStream_t Stream(void *s) { return s ? (hipStream_t)s : stream; }
 };

@@ -22,6 +22,9 @@ hipError_t DevMalloc(void **ptr, size_t bytes);
 hipError_t DevFree(void *ptr);
 // 0 = off, 1 = start, 2 = end16, 3 = end4
 int GuardMode();
+// TIMG_HIP_FAIL_MALLOC=<k> (a TEST aid): the k-th DevMalloc after the first call of this function fails once with
+// hipErrorOutOfMemory.  timg_hip_init calls it when a context exists.
+void ArmMallocInjection();
 
 }  // namespace timg_amd
 

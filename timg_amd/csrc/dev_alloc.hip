@@ -133,7 +133,27 @@ int GuardMode() {
     return mode;
 }
 
+// Fault injection for the callers' out-of-memory paths (tests/test_twins.py, twin_check under TIMG_HIP_FAIL_MALLOC):
+// TIMG_HIP_FAIL_MALLOC=<k> makes the k-th device allocation AFTER the process's first timg_hip_init has returned,
+// counted from 1, fail ONCE with hipErrorOutOfMemory -- what a device that is full at that moment answers; the
+// allocation after it goes through.  Read once; unset or 0: never.
+static std::mutex g_inject_mu;
+static long g_inject_at = 0, g_inject_count = 0;
+static bool g_inject_armed = false;
+void ArmMallocInjection() {
+    std::lock_guard<std::mutex> l(g_inject_mu);
+    if (g_inject_armed) return;
+    g_inject_armed = true;
+    const char *e = getenv("TIMG_HIP_FAIL_MALLOC");
+    g_inject_at   = e && *e ? atol(e) : 0L;
+}
+static bool InjectedFailure() {
+    std::lock_guard<std::mutex> l(g_inject_mu);
+    return g_inject_armed && g_inject_at > 0 && ++g_inject_count == g_inject_at;
+}
+
 hipError_t DevMalloc(void **ptr, size_t bytes) {
+    if (InjectedFailure()) return hipErrorOutOfMemory;
     const int mode = GuardMode();
     if (mode == 0) return hipMalloc(ptr, bytes ? bytes : 1);
     return GuardMalloc(ptr, bytes, mode);

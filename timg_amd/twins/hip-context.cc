@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -45,7 +46,7 @@ int HipScalerFilter() {
         const char *v = getenv("TIMG_HIP_FILTER");
         if (v && !strcmp(v, "bilinear")) return TIMG_HIP_FILTER_TRIANGLE;
         if (v && !strcmp(v, "stb")) return TIMG_HIP_FILTER_STB_DEFAULT;
-#if defined(WITH_TIMG_SWS_RESIZE) && !defined(WITH_TIMG_STB_RESIZE)
+#if defined(WITH_TIMG_SWS_RESIZE)  // (first, as ImageScaler::Create prefers it when a build defines both: src/image-scaler.cc:24-35)
         return TIMG_HIP_FILTER_TRIANGLE;
 #else
         return TIMG_HIP_FILTER_STB_DEFAULT;
@@ -55,18 +56,50 @@ int HipScalerFilter() {
 }
 
 namespace {
-constexpr size_t kPoolBytes = (size_t)8 << 30;
+// (all contexts of the twins live on ONE device -- TIMG_HIP_DEVICE -- so blocks need no device in their key)
+constexpr size_t kPoolBytes = (size_t)4 << 30;
 std::mutex g_pool_mu;
 std::map<size_t, std::vector<void *>> g_pool_idle;  // size -> blocks
 std::map<void *, size_t> g_pool_size;               // every block handed out or idle
 size_t g_pool_cached = 0;
 
+// Idle scalers, most recently released first.  A scaler owns device tables (resample plan, two schedule variants with
+// their alpha tables: up to tens of megabytes for large geometries), so what stays cached is bounded in TOTAL, not per
+// geometry: a slide show or a directory of differently sized images keeps the kMaxIdleScalers it used last and
+// destroys the oldest (round 3's pool kept 16 per geometry for the life of the process: the advisor's finding).
 typedef std::tuple<int, int, int, int, int, int> ScalerKey;
 std::mutex g_scaler_mu;
-std::map<ScalerKey, std::vector<timg_hip_scaler *>> g_scaler_idle;
-std::map<timg_hip_scaler *, ScalerKey> g_scaler_key;
-constexpr size_t kScalersPerGeometry = 16;
+std::list<std::pair<ScalerKey, timg_hip_scaler *>> g_scaler_idle;
+std::map<timg_hip_scaler *, ScalerKey> g_scaler_key;  // every scaler handed out or idle
+constexpr size_t kMaxIdleScalers = 24;
 }  // namespace
+
+size_t HipPoolTrim(timg_hip_ctx *ctx) {
+    std::vector<void *> drop;
+    std::vector<timg_hip_scaler *> scalers;
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        for (auto &kv : g_pool_idle) {
+            for (void *q : kv.second) {
+                drop.push_back(q);
+                g_pool_size.erase(q);
+            }
+            kv.second.clear();
+        }
+        g_pool_cached = 0;
+    }
+    {
+        std::lock_guard<std::mutex> l(g_scaler_mu);
+        for (auto &e : g_scaler_idle) {
+            scalers.push_back(e.second);
+            g_scaler_key.erase(e.second);
+        }
+        g_scaler_idle.clear();
+    }
+    for (void *q : drop) (void)timg_hip_free(ctx, q);
+    for (timg_hip_scaler *s : scalers) timg_hip_scaler_destroy(s);
+    return drop.size() + scalers.size();
+}
 
 void *HipPoolMalloc(timg_hip_ctx *ctx, size_t bytes) {
     if (bytes == 0) bytes = 4;
@@ -82,20 +115,8 @@ void *HipPoolMalloc(timg_hip_ctx *ctx, size_t bytes) {
     }
     void *p = nullptr;
     if (timg_hip_malloc(ctx, bytes, &p) != TIMG_HIP_OK) {
-        // out of memory with blocks cached: give them back and try once more
-        std::vector<void *> drop;
-        {
-            std::lock_guard<std::mutex> l(g_pool_mu);
-            for (auto &kv : g_pool_idle) {
-                for (void *q : kv.second) {
-                    drop.push_back(q);
-                    g_pool_size.erase(q);
-                }
-                kv.second.clear();
-            }
-            g_pool_cached = 0;
-        }
-        for (void *q : drop) (void)timg_hip_free(ctx, q);
+        // out of memory: everything cached (blocks whose sizes may never recur, idle scalers) goes back, one more try
+        HipPoolTrim(ctx);
         if (timg_hip_malloc(ctx, bytes, &p) != TIMG_HIP_OK) return nullptr;
     }
     std::lock_guard<std::mutex> l(g_pool_mu);
@@ -123,15 +144,20 @@ timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_
     const ScalerKey key(in_w, in_h, in_fmt, out_w, out_h, filter);
     {
         std::lock_guard<std::mutex> l(g_scaler_mu);
-        auto it = g_scaler_idle.find(key);
-        if (it != g_scaler_idle.end() && !it->second.empty()) {
-            timg_hip_scaler *s = it->second.back();
-            it->second.pop_back();
-            return s;
-        }
+        for (auto it = g_scaler_idle.begin(); it != g_scaler_idle.end(); ++it)
+            if (it->first == key) {
+                timg_hip_scaler *s = it->second;
+                g_scaler_idle.erase(it);
+                return s;
+            }
     }
     timg_hip_scaler *s = nullptr;
-    if (timg_hip_scaler_create(ctx, in_w, in_h, in_fmt, out_w, out_h, filter, &s) != TIMG_HIP_OK) return nullptr;
+    int rc = timg_hip_scaler_create(ctx, in_w, in_h, in_fmt, out_w, out_h, filter, &s);
+    if (rc == TIMG_HIP_ERR_NOMEM) {  // (its tables did not fit: give back what is cached, once)
+        HipPoolTrim(ctx);
+        rc = timg_hip_scaler_create(ctx, in_w, in_h, in_fmt, out_w, out_h, filter, &s);
+    }
+    if (rc != TIMG_HIP_OK) return nullptr;
     std::lock_guard<std::mutex> l(g_scaler_mu);
     g_scaler_key[s] = key;
     return s;
@@ -139,19 +165,27 @@ timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_
 
 void HipScalerRelease(timg_hip_scaler *s) {
     if (!s) return;
+    timg_hip_scaler *victim = nullptr;
     {
         std::lock_guard<std::mutex> l(g_scaler_mu);
         auto it = g_scaler_key.find(s);
-        if (it != g_scaler_key.end()) {
-            auto &idle = g_scaler_idle[it->second];
-            if (idle.size() < kScalersPerGeometry) {
-                idle.push_back(s);
-                return;
+        if (it == g_scaler_key.end()) {
+            victim = s;  // (not one of the pool's)
+        } else {
+            g_scaler_idle.emplace_front(it->second, s);
+            if (g_scaler_idle.size() > kMaxIdleScalers) {  // the one released longest ago goes
+                victim = g_scaler_idle.back().second;
+                g_scaler_idle.pop_back();
+                g_scaler_key.erase(victim);
             }
-            g_scaler_key.erase(it);
         }
     }
-    timg_hip_scaler_destroy(s);
+    if (victim) timg_hip_scaler_destroy(victim);
+}
+
+size_t HipIdleScalers() {
+    std::lock_guard<std::mutex> l(g_scaler_mu);
+    return g_scaler_idle.size();
 }
 
 void HipFatal(timg_hip_ctx *ctx, const char *what) {

@@ -32,17 +32,37 @@ int HipScalerFilter();
 
 // Device memory for frames, recycled: hipMalloc / hipFree cost far more than the kernels that use a frame
 // (a 4K frame is scaled in ~20 us), and every image source and every held grid row needs a buffer.
-// Blocks are handed out again by exact size; at most kPoolBytes stay cached, the rest is really freed.
+// Blocks are handed out again by exact size; at most kPoolBytes (4 GiB) stay cached, the rest is really freed, and
+// everything cached is given back when an allocation fails (HipPoolTrim).
 // Thread-safe.  nullptr on failure.
 void *HipPoolMalloc(timg_hip_ctx *ctx, size_t bytes);
 void HipPoolFree(timg_hip_ctx *ctx, void *ptr);
+// Everything the twins cache on the device and nobody is using -- idle blocks, idle scalers -- goes back to the
+// driver; returns how many objects that were.  Called when an allocation fails, here and (HipCall) in the library.
+size_t HipPoolTrim(timg_hip_ctx *ctx);
+
+// A device call that fails for lack of device memory (TIMG_HIP_ERR_NOMEM: a scratch buffer of the library could not
+// grow, a staging copy could not be allocated) is made ONCE more after HipPoolTrim: a transient shortage in the
+// middle of a 600-frame stream must not end the process while gigabytes sit in the pool.  Any other failure, and a
+// second one, is the caller's (HipFatal).
+template <class Call>
+int HipCall(timg_hip_ctx *ctx, Call &&call) {
+    int rc = call();
+    if (rc == TIMG_HIP_ERR_NOMEM) {
+        HipPoolTrim(ctx);
+        rc = call();
+    }
+    return rc;
+}
 
 // Scalers, recycled by geometry: creating one builds the resampling plan on the host and uploads its tables
 // (O(W + H), but hundreds of microseconds) -- a grid of equally sized images needs it once, not per image.
 // A scaler is used by one caller at a time (its tile bookkeeping is per scaler): Acquire hands out an idle
 // one or creates one, Release returns it.  Thread-safe.  nullptr on failure.
+// At most kMaxIdleScalers (24) idle scalers stay cached over ALL geometries, the most recently released ones.
 timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, int out_w, int out_h, int filter);
 void HipScalerRelease(timg_hip_scaler *s);
+size_t HipIdleScalers();  // (for the tests)
 
 // A device call failed after the GPU back-end had been selected: print
 // timg_hip_last_error() and terminate.  The twins never substitute CPU results

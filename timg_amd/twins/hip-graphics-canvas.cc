@@ -41,7 +41,8 @@ void SendAsync(timg_hip_ctx *ctx, ThreadPool *pool, BufferedWriteSequencer *ws, 
     memcpy(pixels->data(), fb.begin(), pixels->size());
     const std::function<OutBuffer()> encode_fun = [=]() {
         size_t len = 0;
-        if (encode(pixels->data(), w, h, offset, cap - (size_t)(offset - buffer), &len) != TIMG_HIP_OK)
+        if (HipCall(ctx, [&]() { return encode(pixels->data(), w, h, offset, cap - (size_t)(offset - buffer), &len); }) !=
+            TIMG_HIP_OK)
             HipFatal(ctx, what);
         return OutBuffer(buffer, (size_t)(offset - buffer) + len);
     };

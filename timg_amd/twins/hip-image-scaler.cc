@@ -30,9 +30,10 @@ HipImageScaler::~HipImageScaler() { HipScalerRelease(scaler_); }
 void HipImageScaler::Scale(Framebuffer &in, Framebuffer *out) {
     if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ ||
         out->height() != out_h_ ||
-        timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0,
-                             (uint8_t *)out->begin(), 0, 0, 0, 1, nullptr, nullptr,
-                             nullptr) != TIMG_HIP_OK)
+        HipCall(ctx_, [&]() {
+            return timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0, (uint8_t *)out->begin(), 0, 0, 0,
+                                        1, nullptr, nullptr, nullptr);
+        }) != TIMG_HIP_OK)
         HipFatal(ctx_, "HipImageScaler::Scale");
 }
 
@@ -40,9 +41,10 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
                                      const Framebuffer::bgcolor_query &get_bg,
                                      rgba_t pattern, int pattern_width, int pattern_height) {
     int transparent = 0;
-    if (timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0,
-                             (uint8_t *)out->begin(), 0, 0, 0, 1, nullptr, &transparent,
-                             nullptr) != TIMG_HIP_OK)
+    if (HipCall(ctx_, [&]() {
+            return timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0, (uint8_t *)out->begin(), 0, 0, 0,
+                                        1, nullptr, &transparent, nullptr);
+        }) != TIMG_HIP_OK)
         HipFatal(ctx_, "HipImageScaler::ScaleAndCompose");
     if (!get_bg || !transparent) return;  // src/framebuffer.cc:111,117: getter not consulted
     timg_hip_blend b;
@@ -52,8 +54,9 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
     b.pattern_w = pattern_width;
     b.pattern_h = pattern_height;
     b.start_row = 0;
-    if (timg_hip_alpha_compose(ctx_, (uint8_t *)out->begin(), out_w_, out_h_, 0, 0, 0, 1, &b,
-                               nullptr, nullptr) != TIMG_HIP_OK)
+    if (HipCall(ctx_, [&]() {
+            return timg_hip_alpha_compose(ctx_, (uint8_t *)out->begin(), out_w_, out_h_, 0, 0, 0, 1, &b, nullptr, nullptr);
+        }) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_alpha_compose");
 }
 

@@ -122,8 +122,10 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
         if (ok && done == 0) {
             if (!is_animation && (opts.crop_border > 0 || opts.auto_crop)) {
                 if (opts.auto_crop) {
-                    ok = timg_hip_autocrop_bbox(ctx_, src, feed.w, feed.h, 0, 0, 1, 1, std::max(0, opts.crop_border), box,
-                                                nullptr) == TIMG_HIP_OK;
+                    ok = HipCall(ctx_, [&]() {
+                             return timg_hip_autocrop_bbox(ctx_, src, feed.w, feed.h, 0, 0, 1, 1, std::max(0, opts.crop_border),
+                                                           box, nullptr);
+                         }) == TIMG_HIP_OK;
                     if (ok && (box[2] <= 0 || box[3] <= 0)) {  // nothing but border: GraphicsMagick's trim() keeps a pixel
                         box[0] = box[1] = 0;
                         box[2] = box[3] = 1;
@@ -147,8 +149,11 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
         }
         // -- scale on the device, as src/qoi-image-source.cc:63-68 does on the host: one launch per chunk
         const uint8_t *window = src + (size_t)box[1] * feed.w * 4 + (size_t)box[0] * 4;
-        ok = ok && timg_hip_scale_blend(ctx_, scaler, window, feed.w * 4, src_frame, 1, device_frames_ + frame_bytes_ * done,
-                                        0, 0, 1, m, nullptr, transparent.data(), nullptr) == TIMG_HIP_OK;
+        ok = ok && HipCall(ctx_, [&]() {
+                       return timg_hip_scale_blend(ctx_, scaler, window, feed.w * 4, src_frame, 1,
+                                                   device_frames_ + frame_bytes_ * done, 0, 0, 1, m, nullptr, transparent.data(),
+                                                   nullptr);
+                   }) == TIMG_HIP_OK;
         for (int i = 0; ok && i < m; ++i) any_transparent = any_transparent || transparent[i] != 0;
     }
     // the background getter is only consulted when a pixel needs it (src/framebuffer.cc:113-121); frames
@@ -161,8 +166,9 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
         b.pattern_w = opts.pattern_size * opts.cell_x_px;
         b.pattern_h = opts.pattern_size * opts.cell_y_px / 2;
         b.start_row = 0;
-        ok = timg_hip_alpha_compose(ctx_, device_frames_, target_width, target_height, 0, 0, 1, n, &b, nullptr,
-                                    nullptr) == TIMG_HIP_OK;
+        ok = HipCall(ctx_, [&]() {
+                 return timg_hip_alpha_compose(ctx_, device_frames_, target_width, target_height, 0, 0, 1, n, &b, nullptr, nullptr);
+             }) == TIMG_HIP_OK;
     }
     if (ok) ok = timg_hip_sync(ctx_, nullptr) == TIMG_HIP_OK;
     HipScalerRelease(scaler);
@@ -177,7 +183,9 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
 void HipRawRGBASource::SendFrames(const Duration &duration, int loops, const volatile sig_atomic_t &interrupt_received,
                                   const Renderer::WriteFramebufferFun &sink) {
     // the loop of src/stb-image-source.cc:172-205 (frames of this source carry no delay)
-    const bool is_animation = n_frames_ > 1;
+    // (by the SOURCE's frame count, like LoadAndScale above and src/stb-image-source.cc:175 `frames_.size() > 1`:
+    // --frames=1 of a multi-frame source is still presented as an animation of one frame)
+    const bool is_animation = frames_in_source_ > 1;
     if (!is_animation) loops = 1;
     const bool loop_forever = loops < 0;  // (kNotInitialized is negative too)
     const int indent        = options_.center_horizontally ? (options_.width - image_->width()) / 2 : 0;

@@ -78,8 +78,12 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     const int flags = EncodeFlags();
     static const bool trace = getenv("TIMG_HIP_TWIN_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    if (timg_hip_sixel_encode(ctx, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
-                              bytes.get(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
+    // (HipCall: out of device memory -- the encoder's scratch grows with the batch -- is retried once after the twins'
+    // caches have been given back)
+    if (HipCall(ctx, [&]() {
+            return timg_hip_sixel_encode(ctx, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
+                                         bytes.get(), slot, 0, lens.data(), nullptr);
+        }) != TIMG_HIP_OK)
         HipFatal(ctx, "timg_hip_sixel_encode");
     const auto t1 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; ++i) {
@@ -155,8 +159,10 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     const std::function<OutBuffer()> encode_fun = [=]() {
         OutBuffer out(buffer, offset - buffer);
         size_t len = 0;
-        if (timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr, 1,
-                                  flags, &pad, offset, cap - (size_t)(offset - buffer), 0, &len, nullptr) != TIMG_HIP_OK)
+        if (HipCall(ctx, [&]() {
+                return timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr,
+                                             1, flags, &pad, offset, cap - (size_t)(offset - buffer), 0, &len, nullptr);
+            }) != TIMG_HIP_OK)
             HipFatal(ctx, "timg_hip_sixel_encode");
         if (device_copy) HipPoolFree(ctx, device_copy);
         out.size += len;

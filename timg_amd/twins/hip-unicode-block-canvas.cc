@@ -45,8 +45,10 @@ void HipUnicodeBlockCanvas::Flush() {
 void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height,
                                     SeqType seq_type, Duration end_of_frame) {
     size_t len = 0;
-    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, on_device, p.buffer + p.prefix,
-                                   p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
+    if (HipCall(ctx_, [&]() {
+            return timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, on_device, p.buffer + p.prefix,
+                                              p.cap - p.prefix, &len, nullptr);
+        }) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_block_canvas_send");
     // nothing emitted: the reference keeps the buffer size zero, dropping the
     // cursor jump as well (:390-395)
@@ -65,8 +67,10 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
         std::vector<size_t> lens(n - 1);
         std::vector<int> xs(n - 1);
         for (size_t i = 0; i + 1 < n; ++i) xs[i] = batch.frames[i].x;
-        if (timg_hip_block_encode_grid(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)(n - 1), flags_,
-                                       xs.data(), bytes.get(), slot, 0, lens.data(), nullptr) != TIMG_HIP_OK)
+        if (HipCall(ctx_, [&]() {
+                return timg_hip_block_encode_grid(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)(n - 1),
+                                                  flags_, xs.data(), bytes.get(), slot, 0, lens.data(), nullptr);
+            }) != TIMG_HIP_OK)
             HipFatal(ctx_, "timg_hip_block_encode_grid");
         for (size_t i = 0; i + 1 < n; ++i) {
             HeldFrame &p = batch.frames[i];
@@ -80,8 +84,10 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
     timg_hip_block_canvas_forget(canvas_);
     HeldFrame &p = batch.frames[n - 1];
     size_t len   = 0;
-    if (timg_hip_block_canvas_send(canvas_, p.x, p.dy, batch.data() + (n - 1) * frame_bytes, batch.w, batch.h, 0,
-                                   batch.on_device, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr) != TIMG_HIP_OK)
+    if (HipCall(ctx_, [&]() {
+            return timg_hip_block_canvas_send(canvas_, p.x, p.dy, batch.data() + (n - 1) * frame_bytes, batch.w, batch.h, 0,
+                                              batch.on_device, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr);
+        }) != TIMG_HIP_OK)
         HipFatal(ctx_, "timg_hip_block_canvas_send");
     p.promise.set_value(OutBuffer(p.buffer, len ? p.prefix + len : 0));
 }

@@ -121,7 +121,13 @@ typedef struct {
  * any_transparent (optional, host int[n_frames]) receives whether the scaled
  * frame held a pixel with alpha<255 at/after blend.start_row before blending
  * -- the laziness condition of AlphaComposeBackground (framebuffer.cc:113-117);
- * asking for it synchronises. */
+ * asking for it synchronises.
+ *
+ * Concurrency: calls on ONE scaler from several host threads are serialised while they are being launched (the
+ * scaler's tile bookkeeping), and their kernels may then run side by side on different streams with correct results;
+ * they share one table of finished tiles per slot, though, so each may redo tiles of the other -- a caller that
+ * wants several calls of one geometry in flight at full speed uses one scaler per caller (the twins' pool does:
+ * timg_amd/twins/hip-context.h HipScalerAcquire). */
 int timg_hip_scale_blend(timg_hip_ctx *ctx, timg_hip_scaler *s,
                          const uint8_t *src, int src_stride,
                          size_t src_frame_stride, int src_on_device,

@@ -1450,6 +1450,9 @@ struct StreamSchedule {
     int gen[kTileSlots]         = {0, 0, 0, 0};  // generation of the slot's current call (tile_state holds generations)
     size_t tile_cap[kTileSlots] = {0, 0, 0, 0};
     int slot                    = 0;             // the slot of the call being launched (host-side plumbing)
+    // slot, gen and the tile tables are written while a call is being LAUNCHED: two host threads that launch on the
+    // same scaler take turns here (include/timg_hip.h: what concurrent use of one scaler means)
+    std::mutex launch_mu;
 };
 
 static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &strips,
@@ -1898,6 +1901,7 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
                              const FrameBatch &batch, hipStream_t stream, int slot) {
     StreamSchedule *ss = (StreamSchedule *)s->stream_tables;
     if (!ss || slot < 0 || slot >= StreamSchedule::kTileSlots) return hipErrorNotSupported;
+    std::lock_guard<std::mutex> launching(ss->launch_mu);
     ss->slot = slot;
     // rows of whole pixels (the 16-byte loads only need 4-byte alignment); otherwise the
     // generic kernel runs

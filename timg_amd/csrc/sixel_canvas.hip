@@ -239,7 +239,7 @@ __device__ __forceinline__ uint32_t PlaneKey(uint32_t entry, int plane) {
     return (entry >> (10 - 5 * plane)) & 0x1fu;  // plane 0=r 1=g 2=b
 }
 
-struct CutBox {
+struct alignas(16) CutBox {  // (32 bytes: the bookkeeping wave fetches a record as two 16-byte LDS reads)
     uint32_t ind, colors, sum, buf;  // buf: which half of the ping-pong table holds it
     uint32_t median, lowersum;       // prepared split (valid when ready != 0)
     uint32_t ready, pad;

@@ -327,6 +327,7 @@ def main():
         return None
 
     cfg = dict(CONFIGS[args.config])
+    base_kind = cfg["kind"]
     if args.frames:
         cfg["frames"] = args.frames
     if args.kind:
@@ -540,7 +541,7 @@ def main():
             "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(scale_avg_ms, 4),
-            "limiter": "instruction issue (profiles/r2: SQ counters), not HBM",
+            "limiter": "no counters collected for this configuration (profiles/collect_pmc.sh)",
             "launches_per_step": launches_per_batch * (launches_per_step if strong else 1),
             "measured": ("HIP events of libtimg_hip.so around every piece's scale launches on the piece's own stream "
                          "(timg_hip_scale_sixel_encode: the kernels run beside the serial sixel stages of the pieces in front "
@@ -554,17 +555,28 @@ def main():
     }
     if parity is not None:
         result["parity_check"] = parity
-    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file):
+    # HBM traffic and what limits the kernel: PMC counters of THIS command line, collected by profiles/collect_pmc.sh
+    # (rocprofv3 cannot wrap a run from inside it) into profiles/hbm_traffic_<config>[_<kind>].json -- one file per
+    # configuration, from the round named in it; profiles/hbm_traffic.json (metric, S-photo) is the older single file
+    tname = args.config + ("_" + args.kind if args.kind and args.kind != base_kind else "")
+    for traffic_file in (os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % tname),
+                         os.path.join(ROOT, "profiles", "hbm_traffic.json")):
+        if not os.path.exists(traffic_file):
+            continue
         try:
             t = json.load(open(traffic_file))
             if (t.get("workload_frames") == chunk and t.get("kernel") == result["config"]["scale_kernel"]
-                    and t.get("config", "metric") == args.config):
+                    and t.get("config", "metric") == args.config and (t.get("kind") or "") == (tname.split("_", 1) + [""])[1]
+                    and t.get("hbm_bytes_per_launch")):
                 result["roofline"]["traffic"] = t["hbm_bytes_per_launch"] // launches_per_batch
+                result["roofline"]["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / launches_per_batch / alg_bytes, 3)
                 result["roofline"]["traffic_measured_in_this_run"] = False
-                result["roofline"]["traffic_source"] = ("NOT measured in this run: profiles/hbm_traffic.json, rocprofv3 "
-                                                        "--pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
-                                                        "(profiles/collect.sh)")
+                result["roofline"]["traffic_source"] = ("NOT measured in this run: profiles/%s, rocprofv3 --pmc FETCH_SIZE / "
+                                                        "WRITE_SIZE passes of this same command (profiles/collect_pmc.sh)"
+                                                        % os.path.basename(traffic_file))
+                if t.get("limiter"):
+                    result["roofline"]["limiter"] = t["limiter"]
+                break
         except Exception:
             pass
 

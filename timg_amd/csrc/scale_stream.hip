@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -1450,6 +1451,13 @@ struct StreamSchedule {
     int gen[kTileSlots]         = {0, 0, 0, 0};  // generation of the slot's current call (tile_state holds generations)
     size_t tile_cap[kTileSlots] = {0, 0, 0, 0};
     int slot                    = 0;             // the slot of the call being launched (host-side plumbing)
+    // Further band heights, built when a batch size asks for one (LaunchScaleStream): a batch should fill the chip's
+    // workgroup slots ONCE with equally tall bands -- 64 frames of 3840x2160 -> 200x56 as two bands of 45 + 11 rows a
+    // frame were 512 tiles of which the 256 tall ones set the time, on 1024 slots (BASELINE config 3: 0.83 ms).
+    std::vector<StripInfo> strips_host;
+    std::vector<int> first_host, last_host;
+    std::map<int, StreamVariant> more;           // by band_rows
+    static constexpr size_t kMoreVariants = 6;
     // slot, gen and the tile tables are written while a call is being LAUNCHED: two host threads that launch on the
     // same scaler take turns here (include/timg_hip.h: what concurrent use of one scaler means)
     std::mutex launch_mu;
@@ -1764,6 +1772,10 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     int tall = 45;
     if (const char *e = getenv("TIMG_HIP_BAND_ROWS")) tall = atoi(e) > 0 ? atoi(e) : tall;  // tuning
     tall = std::max(1, std::min(p.out_h, tall));
+    tall = (p.out_h + (p.out_h + tall - 1) / tall - 1) / ((p.out_h + tall - 1) / tall);  // (equally tall bands)
+    ss->strips_host = strips;
+    ss->first_host  = first;
+    ss->last_host   = last;
     int fine           = tall;
     while (fine > 6 && (size_t)strips.size() * ((p.out_h + fine - 1) / fine) < 512)
         fine = std::max(6, fine / 2);
@@ -1794,6 +1806,8 @@ void ReleaseStreamSchedule(timg_hip_scaler *s) {
     if (!ss) return;
     for (auto &v : ss->v)
         if (v.device) (void)DevFree(v.device);
+    for (auto &kv : ss->more)
+        if (kv.second.device) (void)DevFree(kv.second.device);
     for (int *t : ss->tile_state)
         if (t) (void)DevFree(t);
     delete ss;
@@ -1907,9 +1921,36 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
     // generic kernel runs
     if (((uintptr_t)batch.src & 3) || (batch.src_stride & 3) || (batch.src_frame_stride & 3))
         return LaunchScaleGeneric(s->dev, blend, batch, stream);
+    // Band height: the tallest whose tiles fill the workgroup slots of the chip (four a CU), between the tall variant
+    // (little halo: batches that fill the chip anyway) and 6-row bands (a single frame); equally tall bands
     const StreamVariant &tall = ss->v[0];
-    const bool enough = (size_t)tall.t.n_strips * tall.t.n_bands * batch.n_frames >= 512;
-    const StreamVariant &v = enough ? tall : ss->v[1];
+    const StreamVariant *pick = &tall;
+    {
+        const int out_h   = s->plan.out_h;
+        const long slots  = 4L * std::max(1, s->ctx ? s->ctx->cu_count : 256);
+        const long per_b  = (long)tall.t.n_strips * std::max(1, batch.n_frames);
+        const long b_max  = std::max<long>(tall.t.n_bands, (out_h + 5) / 6);
+        const long bands  = std::min(b_max, std::max<long>(tall.t.n_bands, (slots + per_b - 1) / per_b));
+        const int rows    = (int)((out_h + bands - 1) / bands);
+        if (rows >= tall.band_rows) {
+            pick = &tall;
+        } else if (rows <= ss->v[1].band_rows) {
+            pick = &ss->v[1];
+        } else {
+            auto it = ss->more.find(rows);
+            if (it == ss->more.end() && ss->more.size() < StreamSchedule::kMoreVariants) {
+                StreamVariant nv;
+                if (BuildVariant(s->plan, ss->strips_host, ss->first_host, ss->last_host, rows, &nv))
+                    it = ss->more.emplace(rows, nv).first;
+            }
+            if (it != ss->more.end()) {
+                pick = &it->second;
+            } else {  // (the cache is full or the tables did not fit: the nearest of the two that always exist)
+                pick = (size_t)tall.t.n_strips * tall.t.n_bands * batch.n_frames >= 512 ? &tall : &ss->v[1];
+            }
+        }
+    }
+    const StreamVariant &v = *pick;
     const size_t tiles = (size_t)v.t.n_strips * v.t.n_bands * batch.n_frames;
     if (tiles > ss->tile_cap[slot]) {
         // (a slot's previous call may still be running on ANOTHER stream: the device is idle before its table goes)

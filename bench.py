@@ -326,6 +326,14 @@ def main():
             exchange["bytes_at_root"] = got
         return None
 
+    gather_log = []  # (ms, bytes at the root) of every exchange of the timed region, rank 0's clock
+
+    def timed_gather(payload, lens):
+        t0 = time.perf_counter()
+        gather(payload, lens)
+        if rank == 0:
+            gather_log.append(((time.perf_counter() - t0) * 1e3, int(exchange.get("bytes_at_root", 0))))
+
     cfg = dict(CONFIGS[args.config])
     base_kind = cfg["kind"]
     if args.frames:
@@ -394,7 +402,7 @@ def main():
         """n_steps passes of the hot path; with several ranks the outputs are gathered to rank 0
         in step order by this (the main) thread."""
         if not strong:
-            run_batched_streams(pipes, src, n_steps, n_pipes, 2 if force_gather else world, gather, timed_events, record)
+            run_batched_streams(pipes, src, n_steps, n_pipes, 2 if force_gather else world, timed_gather, timed_events, record)
             return
         for _ in range(n_steps):  # a step = the whole sharded stream, chunk by chunk
             for k in range(n_launches_max):
@@ -423,7 +431,7 @@ def main():
                     want = max(min(chunk, max(0, n_r - k * chunk)) for n_r in counts)
                     if lens.numel() < want:
                         lens = torch.cat([lens, torch.zeros(want - lens.numel(), dtype=torch.int64, device="cuda")])
-                    gather(payload, lens)
+                    timed_gather(payload, lens)
 
     def timed(n_steps, n_pipes, timed_events=None):
         torch.cuda.synchronize()
@@ -460,7 +468,18 @@ def main():
         torch.cuda.synchronize()
     run_steps(args.warmup)
     events = []
+    del gather_log[:]
     elapsed = timed(args.steps, n_pipes, events)  # THE timed region: exactly K steps
+    if rank == 0 and gather_log:
+        # the exchange of the timed region, per step (a step of a strong-scaling configuration is several exchanges):
+        # rank 0's wall clock around the two C-ABI calls (they end synchronised), the bytes that arrived at the root
+        per_step = max(1, len(gather_log) // max(1, args.steps))
+        steps_ms = [round(sum(ms for ms, _ in gather_log[i:i + per_step]), 3) for i in range(0, len(gather_log), per_step)]
+        steps_by = [sum(b for _, b in gather_log[i:i + per_step]) for i in range(0, len(gather_log), per_step)]
+        exchange["exchanges_per_step"] = per_step
+        exchange["gather_ms_per_step"] = steps_ms[:16]
+        exchange["bytes_at_root_per_step"] = steps_by[:16]
+        exchange["gather_ms_mean"] = round(sum(steps_ms) / len(steps_ms), 3)
     parity = None
     if rank == 0 and not args.no_parity and n_mine > 0:
         # what the last timed step left behind (pipeline (K-1) % n_pipes holds it; strong configs: the last chunk)

@@ -69,7 +69,9 @@ int timg_hip_gather_lengths(timg_hip_comm *comm, const uint64_t *lengths, int n_
  * bytes) holds the payloads of ranks 0 .. world-1 back to back in rank order and *recv_bytes their
  * total.  Other ranks pass recv = NULL, recv_cap = 0.  The root's recv_cap travels with a one-word
  * all-gather first: when it is too small EVERY rank returns TIMG_HIP_COMM_ERR_CAP and no payload
- * moves. */
+ * moves.  `stream`: the hipStream_t the payload was produced on -- the exchange is enqueued behind it;
+ * NULL: the communicator's own stream, after the whole device has gone idle (the payload is complete
+ * whatever stream produced it). */
 int timg_hip_gather_payload(timg_hip_comm *comm, int root, const uint8_t *payload, const uint64_t *all_lengths,
                             int n_frames_max, uint8_t *recv, size_t recv_cap, size_t *recv_bytes, void *stream);
 

@@ -121,4 +121,41 @@ def test_bench_exchanges_through_the_c_abi_gather(extra):
     x = out["rccl"]
     assert "C-ABI" in x["via"] and x["rccl_version"] > 0 and "librccl" in x["lib"], x
     assert x["gathers"] >= 2 and x["bytes_at_root"] > 0, x
+    # per step of the timed region: how long the exchange took on rank 0's clock and what arrived at the root
+    assert len(x["gather_ms_per_step"]) == 2 and all(ms > 0 for ms in x["gather_ms_per_step"]), x
+    if "--config" not in extra:  # (one exchange a step: exactly the step's bytes; c4's ragged last launch carries fewer)
+        assert x["exchanges_per_step"] == 1 and x["bytes_at_root_per_step"] == [out["output_bytes_per_step"]] * 2, x
+    else:
+        assert x["exchanges_per_step"] == 3 and all(0 < b <= out["output_bytes_per_step"] for b in x["bytes_at_root_per_step"]), x
     assert out["parity_check"]["ok"], out["parity_check"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,extra", [
+    (2, []),                                                   # the metric configuration: 64 frames per rank, weak scaling
+    (2, ["--config", "c5", "--frames", "9", "--no-parity"]),   # strong scaling, contiguous blocks of 5 + 4 8K frames
+    (4, ["--config", "c5", "--frames", "3", "--no-parity"]),   # ... of 1 + 1 + 1 + 0: a rank with an empty shard
+    (4, ["--config", "c4", "--frames", "10", "--chunk", "2"]), # round-robin video frames, ragged: 3 + 3 + 2 + 2
+])
+def test_multi_rank_control_flow_on_one_gpu(ranks, extra):
+    """bench.py --gpus N as the driver launches it (torch.distributed.run, one process per rank), with the ranks
+    SHARING the one reachable GPU and the collectives over gloo (TIMG_DIST_BACKEND=gloo): the multi-rank control flow --
+    pre-warm decided by rank 0, barrier + max-over-ranks timing, per-step exchange beside the next step's kernels,
+    strong-scaling shards incl. ragged and empty ones -- runs before the first real 8-GPU run does.  The numbers of
+    such a run mean nothing; it must complete on every rank and report the whole job's frames."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, TIMG_DIST_BACKEND="gloo", TIMG_SKIP_CANARY="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2",
+           "--warmup", "1", "--prewarm", "0.05", "--no-cpu-baseline", "--no-extras", "--no-dropin"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    line = ([ln for ln in r.stdout.splitlines() if ln.startswith("{")] or [""])[-1]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-600:], r.stderr[-2000:])
+    out = json.loads(line)
+    assert out["n_gpus"] == ranks and out["value"] > 0 and out["rccl"]["ranks"] == ranks, out
+    assert "torch.distributed over gloo" in out["rccl"]["via"], out["rccl"]
+    if "--no-parity" not in extra:
+        assert out["parity_check"]["ok"], out["parity_check"]

@@ -266,6 +266,11 @@ int timg_hip_gather_payload(timg_hip_comm *c, int root, const uint8_t *payload, 
     if (my_bytes && !payload) return c->Fail(TIMG_HIP_COMM_ERR, "payload is NULL");
     COMM_HIP(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    // stream == NULL: the exchange runs on the communicator's own stream, which knows nothing of the stream(s) the
+    // caller produced `payload` on -- the device is made idle first, so that the payload is complete whatever the
+    // caller did or did not synchronise (the call ends with a synchronisation anyway).  A caller that passes its
+    // producing stream gets stream order instead and pays no device-wide wait.
+    if (!stream) COMM_HIP(c, hipDeviceSynchronize());
     // every rank learns the root's capacity: a short buffer fails everywhere, nobody waits in a send
     const uint64_t my_cap = (c->rank == root && recv) ? (uint64_t)recv_cap : 0;
     std::vector<uint64_t> caps((size_t)c->world, 0);

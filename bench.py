@@ -207,7 +207,9 @@ def cpp_dropin():
         return {"error": (r.stderr or r.stdout)[-400:]}
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     out = {"unit": "Mpixels/s", "what": "timg's own loop (loader pool, Renderer, one Send per image, BufferedWriteSequencer on "
-                                        "/dev/null); gpu = C++ twins, cpu = the reference's classes on the host cores"}
+                                        "/dev/null); gpu = C++ twins on frames that are born in HBM, host = C++ twins on frames in HOST memory "
+                                        "(what real files take: HipImageScaler uploads, scales, composes, downloads; PCIe Gen5 x16 "
+                                        "bounds it at ~15 Gpx/s of 4K sources), cpu = the reference's classes on the host cores"}
     for x in rows:
         out.setdefault(x["config"], {}).setdefault(x["path"], {})["queue_%d" % x["queue_len"]] = {
             "mpx_per_s": x["mpx_per_s"], "ms_per_frame": x["ms_per_frame"], "frames": x["frames"],

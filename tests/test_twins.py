@@ -55,6 +55,8 @@ def test_twins_match_reference_classes(oracle, tmp_path):
     assert "RCCL gather to the root + ordered hand-over to the write sequencer (world 1): checked" in r.stdout
     # kitty / iTerm2 at --compress=0: the reference canvases (real png::Encode + libdeflate) beside the twins
     assert "kitty / iTerm2 canvas twins at --compress=0: checked" in r.stdout
+    # decoded frames in HOST memory through HipImageScaler on loader threads (a context each) and the Hip canvases
+    assert "host frames -> HipImageScaler on loader threads -> Hip canvas: 2 grids identical" in r.stdout
     # what the twins cache on the device: idle scalers bounded over all geometries (LRU), everything given back by a trim
     assert "scaler / block pools: bounded over 40 geometries, trimmed, still scaling" in r.stdout
     # the sixel twin's stream (variant 0): five frames, the first decodable to a 200x114 raster
@@ -104,5 +106,7 @@ def test_twin_bench_runs_the_drop_in_path_like_timg_cc():
     assert r.returncode == 0, r.stdout + r.stderr
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     seen = {(x["config"], x["path"]) for x in rows}
-    assert seen == {(c, p) for c in ("c2", "c3", "c4", "metric") for p in ("gpu", "cpu")}, seen
+    # gpu: frames born in HBM (HipRawRGBASource); host: frames in host memory through HipImageScaler (the path real
+    # files take); cpu: the reference's own classes
+    assert seen == {(c, p) for c in ("c2", "c3", "c4", "metric") for p in ("gpu", "host", "cpu")}, seen
     assert all(x["mpx_per_s"] > 0 and x["bytes_written"] > 1000 for x in rows), rows

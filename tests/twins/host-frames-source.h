@@ -17,6 +17,7 @@
 #include "display-options.h"
 #include "framebuffer.h"
 #include "image-scaler.h"
+#include "hip-image-scaler.h"
 #include "image-source.h"
 
 namespace timg {
@@ -24,8 +25,13 @@ namespace timg {
 class HostFramesSource final : public ImageSource {
 public:
     // frames: `n` RGBA8 frames of w x h back to back (not owned; must outlive LoadAndScale)
-    HostFramesSource(const std::string &name, const uint8_t *frames, int n, int w, int h)
-        : ImageSource(name), src_(frames), n_src_(n), w_(w), h_(h) {}
+    HostFramesSource(const std::string &name, const uint8_t *frames, int n, int w, int h, bool hip_scaler = false)
+        : ImageSource(name), src_(frames), n_src_(n), w_(w), h_(h), hip_scaler_(hip_scaler) {}
+
+    // Frames that already ARE Framebuffers (not owned; one per source frame, uncropped): what a decoder leaves behind.
+    // Without them LoadAndScale copies every frame out of `frames` first -- fine for the parity drivers, but in a
+    // timed run that copy (33 MB per 4K frame, sixteen loaders at once) is host memory traffic a decoder does not add.
+    void UseDecodedFrames(const std::vector<timg::Framebuffer *> *decoded) { decoded_ = decoded; }
 
     // crop window (x, y, w, h) applied before scaling (what GraphicsMagick's crop()/trim() would leave);
     // default: the whole frame
@@ -42,17 +48,36 @@ public:
         int tw, th;
         CalcScaleToFitDisplay(sw, sh, opts, false, &tw, &th);
         for (int i = 0; i < n; ++i) {
-            timg::Framebuffer in(sw, sh);  // (the copy the reference's loaders make)
-            const uint8_t *frame = src_ + (size_t)(f0 + i) * w_ * h_ * 4;
-            for (int y = 0; y < sh; ++y)
-                memcpy((uint8_t *)in.begin() + (size_t)y * sw * 4, frame + ((size_t)(cy_ + y) * w_ + cx_) * 4, (size_t)sw * 4);
-            auto scaler = ImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
-            if (!scaler) return false;
+            std::unique_ptr<timg::Framebuffer> copy;
+            timg::Framebuffer *in_p = nullptr;
+            if (decoded_ && cw_ <= 0 && ch_ <= 0) {
+                in_p = (*decoded_)[f0 + i];
+            } else {
+                copy.reset(new timg::Framebuffer(sw, sh));  // (the copy the reference's loaders make)
+                const uint8_t *frame = src_ + (size_t)(f0 + i) * w_ * h_ * 4;
+                for (int y = 0; y < sh; ++y)
+                    memcpy((uint8_t *)copy->begin() + (size_t)y * sw * 4, frame + ((size_t)(cy_ + y) * w_ + cx_) * 4, (size_t)sw * 4);
+                in_p = copy.get();
+            }
+            timg::Framebuffer &in = *in_p;
+            // hip_scaler_: what a timg built with the twin factory does with a decoded file -- the frame is in HOST
+            // memory, HipImageScaler::Create stands where ImageScaler::Create stood (src/stb-image-source.cc:44-61,
+            // src/qoi-image-source.cc:42-77): upload, scale and compose on the device, the result back in a Framebuffer
             std::unique_ptr<timg::Framebuffer> out(new timg::Framebuffer(tw, th));
-            scaler->Scale(in, out.get());
-            out->AlphaComposeBackground(options_.bgcolor_getter, options_.bg_pattern_color,
-                                        options_.pattern_size * options_.cell_x_px,
-                                        options_.pattern_size * options_.cell_y_px / 2);
+            if (hip_scaler_) {
+                auto scaler = HipImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
+                if (!scaler) return false;
+                static_cast<HipImageScaler *>(scaler.get())->ScaleAndCompose(
+                    in, out.get(), options_.bgcolor_getter, options_.bg_pattern_color,
+                    options_.pattern_size * options_.cell_x_px, options_.pattern_size * options_.cell_y_px / 2);
+            } else {
+                auto scaler = ImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
+                if (!scaler) return false;
+                scaler->Scale(in, out.get());
+                out->AlphaComposeBackground(options_.bgcolor_getter, options_.bg_pattern_color,
+                                            options_.pattern_size * options_.cell_x_px,
+                                            options_.pattern_size * options_.cell_y_px / 2);
+            }
             frames_.push_back(std::move(out));
         }
         return !frames_.empty();
@@ -88,6 +113,8 @@ public:
 private:
     const uint8_t *const src_;
     const int n_src_, w_, h_;
+    const bool hip_scaler_;
+    const std::vector<timg::Framebuffer *> *decoded_ = nullptr;
     int cx_ = 0, cy_ = 0, cw_ = 0, ch_ = 0;
     DisplayOptions options_;
     std::vector<std::unique_ptr<timg::Framebuffer>> frames_;

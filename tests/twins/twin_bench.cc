@@ -153,7 +153,7 @@ static RunResult RunLikeTimg(const Config &c, bool gpu, size_t queue_len, int lo
 }
 
 int main(int argc, char **argv) {
-    std::string which = "c2,c3,c4,metric", paths = "gpu,cpu";
+    std::string which = "c2,c3,c4,metric", paths = "gpu,host,cpu";
     int frames_override = 0, cpu_frames_cap = 128, repeat = 3, loader_threads = 0;
     std::vector<size_t> queues;
     for (int i = 1; i < argc; ++i) {
@@ -194,13 +194,16 @@ int main(int argc, char **argv) {
             if (c.frames_each > 1) qs.push_back(64);  // a stream: frames held per device call = the queue
         }
         const size_t frame_bytes = (size_t)c.in_w * c.in_h * 4;
-        for (const char *path : {"gpu", "cpu"}) {
+        for (const char *path : {"gpu", "host", "cpu"}) {
             if ((',' + paths + ',').find(std::string(",") + path + ",") == std::string::npos) continue;
-            const bool gpu = !strcmp(path, "gpu");
+            // "host": what real FILES take through a timg built with the twins -- the decoded frame is in host memory,
+            // HipImageScaler uploads, scales and composes it, the Hip canvas encodes the (host) result
+            const bool host = !strcmp(path, "host");
+            const bool gpu  = !strcmp(path, "gpu") || host;
             Config rc = c;
             std::vector<uint8_t> host_frames;
-            if (!gpu) {  // a bounded sample of the same workload; the frames exist before the clock starts
-                const int total = std::min(c.sources * c.frames_each, cpu_frames_cap);
+            if (!gpu || host) {  // a bounded sample of the same workload; the frames exist before the clock starts
+                const int total = std::min(c.sources * c.frames_each, host ? std::max(cpu_frames_cap, 64) : cpu_frames_cap);
                 if (c.frames_each > 1) rc.frames_each = total;
                 else rc.sources = total;
                 if (rc.frames_each == 1) rc.rows = std::max(1, (rc.sources + rc.cols - 1) / rc.cols);
@@ -211,16 +214,29 @@ int main(int argc, char **argv) {
                     return 1;
                 }
             }
-            const int threads = gpu ? std::min(ref_loaders, std::max(1, std::min(rc.sources, 8))) : std::min(ref_loaders, std::max(1, rc.sources));
+            // the frames as a decoder leaves them: Framebuffers in host memory, before the clock starts (both host-memory
+            // paths alike)
+            std::vector<std::unique_ptr<Framebuffer>> decoded_own;
+            std::vector<Framebuffer *> decoded;
+            for (size_t f = 0; f * frame_bytes < host_frames.size(); ++f) {
+                decoded_own.emplace_back(new Framebuffer(c.in_w, c.in_h));
+                memcpy((void *)decoded_own.back()->begin(), host_frames.data() + f * frame_bytes, frame_bytes);
+                decoded.push_back(decoded_own.back().get());
+            }
+            const int threads = (gpu && !host) ? std::min(ref_loaders, std::max(1, std::min(rc.sources, 8)))
+                                               : std::min(host ? std::min(ref_loaders, 16) : ref_loaders, std::max(1, rc.sources));
             auto make = [&](int i, const DisplayOptions &opts) -> ImageSource * {
-                if (gpu) {
+                if (gpu && !host) {
                     char name[96];
                     if (rc.frames_each > 1) snprintf(name, sizeof(name), "synth:photo:%dx%d:0:0:%d", rc.in_w, rc.in_h, rc.frames_each);
                     else snprintf(name, sizeof(name), "synth:photo:%dx%d:0:%d", rc.in_w, rc.in_h, i);
                     return HipRawRGBASource::TryCreate(name, opts, 0, -1);
                 }
                 auto *s = new HostFramesSource("host", host_frames.data() + (rc.frames_each > 1 ? 0 : frame_bytes * i),
-                                               rc.frames_each, rc.in_w, rc.in_h);
+                                               rc.frames_each, rc.in_w, rc.in_h, host);
+                std::vector<Framebuffer *> *mine = new std::vector<Framebuffer *>(  // (leaked: a handful of pointers per source)
+                    decoded.begin() + (rc.frames_each > 1 ? 0 : i), decoded.begin() + (rc.frames_each > 1 ? rc.frames_each : i + 1));
+                s->UseDecodedFrames(mine);
                 if (!s->LoadAndScale(opts, 0, -1)) {
                     delete s;
                     return nullptr;
@@ -241,7 +257,9 @@ int main(int argc, char **argv) {
                        "\"mpx_per_s\": %.1f, \"bytes_written\": %zu, \"classes\": \"%s\"}\n",
                        c.name, path, frames, c.in_w, c.in_h, c.sixel ? "sixel" : "quarter", rc.cols, rc.rows, q, threads, cores,
                        best.seconds, best.seconds * 1e3 / frames, mpx, best.bytes,
-                       gpu ? "HipRawRGBASource + reference Renderer + Hip canvas + reference BufferedWriteSequencer"
+                       host ? "host frames -> HipImageScaler::ScaleAndCompose (upload, scale, compose, download) + reference Renderer "
+                              "+ Hip canvas + reference BufferedWriteSequencer"
+                       : gpu ? "HipRawRGBASource + reference Renderer + Hip canvas + reference BufferedWriteSequencer"
                            : (c.sixel ? "reference ImageScaler/Framebuffer/Renderer/SixelCanvas (libsixel = oracle restatement, "
                                         "first-hit rule)/BufferedWriteSequencer"
                                       : "reference ImageScaler/Framebuffer/Renderer/UnicodeBlockCanvas/BufferedWriteSequencer"));

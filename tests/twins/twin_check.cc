@@ -815,6 +815,83 @@ static void CheckGatherWriter() {
     fflush(stdout);
 }
 
+// The path real FILES take through a timg built with the twins: decoded frames in HOST memory, scaled by
+// HipImageScaler where ImageScaler::Create stood (src/stb-image-source.cc:44-61, src/qoi-image-source.cc:42-77) -- on
+// LOADER THREADS, each on its own context (LoaderHipContext), several at a time -- then the Hip canvas.  Against the
+// reference's scaler + compose + canvases on the same frames: byte-identical streams.
+static void CheckHostFramesPath() {
+    timg_stub_sixel_set_lookup_mode(1);
+    const int sw = 640, sh = 360, nsrc = 12;
+    std::vector<uint8_t> frames((size_t)nsrc * sw * sh * 4);
+    for (int i = 0; i < nsrc; ++i) {
+        Framebuffer fb(sw, sh);
+        rng_state = 500 + i;
+        Fill(&fb, i % 3);  // opaque noise, random alpha, flat areas
+        memcpy(frames.data() + (size_t)i * sw * sh * 4, fb.begin(), (size_t)sw * sh * 4);
+    }
+    int n = 0;
+    for (int canvas_kind = 0; canvas_kind < 2; ++canvas_kind) {  // 0: quarter blocks, 1: sixel
+        std::string streams[2];
+        for (int hip = 0; hip < 2; ++hip) {
+            volatile sig_atomic_t intr = 0;
+            const int fd = memfd_create("host", 0);
+            {
+                DisplayOptions opts;
+                opts.cell_x_px        = canvas_kind ? 9 : 2;
+                opts.cell_y_px        = canvas_kind ? 18 : 2;
+                opts.width            = canvas_kind ? 133 : 120;
+                opts.height           = canvas_kind ? 90 : 68;
+                opts.width_stretch    = canvas_kind ? 1.0f : 2.0f;
+                opts.pattern_size     = 2;
+                opts.bg_pattern_color.r = 200; opts.bg_pattern_color.g = 190; opts.bg_pattern_color.b = 180;
+                opts.bg_pattern_color.a = 255;
+                opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+                ThreadPool loaders(6);  // (more loaders than loader contexts are not needed to see them overlap)
+                std::vector<std::future<ImageSource *>> loaded;
+                for (int i = 0; i < nsrc; ++i) {
+                    const std::function<ImageSource *()> f = [&, i]() -> ImageSource * {
+                        auto *s = new HostFramesSource("host", frames.data() + (size_t)i * sw * sh * 4, 1, sw, sh, hip != 0);
+                        if (!s->LoadAndScale(opts, 0, -1)) {
+                            delete s;
+                            return nullptr;
+                        }
+                        return s;
+                    };
+                    loaded.push_back(loaders.ExecAsync(f));
+                }
+                BufferedWriteSequencer seq(fd, false, 4, true, intr);
+                ThreadPool pool(5);
+                static SixelOptions so;
+                std::unique_ptr<TerminalCanvas> canvas;
+                if (canvas_kind == 0 && hip) canvas.reset(new HipUnicodeBlockCanvas(&seq, true, false, false));
+                if (canvas_kind == 0 && !hip) canvas.reset(new UnicodeBlockCanvas(&seq, true, false, false));
+                if (canvas_kind == 1 && hip) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
+                if (canvas_kind == 1 && !hip) canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
+                {
+                    auto renderer = Renderer::Create(canvas.get(), opts, 4, 3, Duration(), Duration());
+                    for (auto &fut : loaded) {
+                        std::unique_ptr<ImageSource> source(fut.get());
+                        CHECK(source != nullptr, "host-frames source (hip %d)", hip);
+                        if (!source) continue;
+                        canvas->CursorOff();
+                        source->SendFrames(Duration::InfiniteFuture(), 1, intr, renderer->render_cb(""));
+                        canvas->CursorOn();
+                    }
+                    seq.Flush();
+                }
+                canvas.reset();
+            }
+            streams[hip] = Slurp(fd);
+            close(fd);
+        }
+        CHECK(streams[0] == streams[1] && streams[0].size() > 1000, "host frames through the twins, canvas %d: %zu (reference) vs %zu bytes",
+              canvas_kind, streams[0].size(), streams[1].size());
+        ++n;
+    }
+    printf("host frames -> HipImageScaler on loader threads -> Hip canvas: %d grids identical to the reference classes\n", n);
+    fflush(stdout);
+}
+
 // What the twins cache on the device is bounded and can be given back (hip-context.h): idle scalers over ALL
 // geometries (a slide show of differently sized images), pool blocks; after HipPoolTrim a scaler still scales.
 static void CheckPools() {
@@ -852,7 +929,7 @@ static void CheckPools() {
 }
 
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|pools|bilinear] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|hostpath|pools|bilinear] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -873,6 +950,7 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "source" || what == "animation") CheckAnimationSource();
     if (what == "all" || what == "source" || what == "autocrop") CheckAutoCropSource();
     if (what == "all" || what == "gather") CheckGatherWriter();
+    if (what == "all" || what == "hostpath") CheckHostFramesPath();
     if (what == "all" || what == "pools") CheckPools();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);

@@ -2,6 +2,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <list>
 #include <map>
@@ -41,6 +42,19 @@ timg_hip_ctx *ExtraHipContext(int k) {
     return extra[k - 1];
 }
 
+timg_hip_ctx *LoaderHipContext() {
+    // Loader threads (src/timg.cc:948-968 runs 3/4 of the cores as loaders) scale frames that live in HOST memory: a
+    // call uploads the frame, scales and downloads the result under its context's lock -- on ONE context every loader
+    // waits for the others' uploads (64 frames of 4K: 1.02 ms a frame, 8.1 Gpx/s at sixteen loaders).  Each thread is
+    // given one of kLoaderContexts contexts of its own stream and staging memory instead, so that one image's upload
+    // runs beside another's kernels; contexts kLoaderFirst.. leave the first ones to the canvases' encoders.
+    constexpr int kLoaderContexts = 8, kLoaderFirst = 5;
+    static std::atomic<int> next{0};
+    thread_local int mine = next.fetch_add(1);
+    timg_hip_ctx *c = ExtraHipContext(kLoaderFirst + mine % kLoaderContexts);
+    return c ? c : SharedHipContext();
+}
+
 int HipScalerFilter() {
     static const int filter = []() {
         const char *v = getenv("TIMG_HIP_FILTER");
@@ -67,7 +81,7 @@ size_t g_pool_cached = 0;
 // their alpha tables: up to tens of megabytes for large geometries), so what stays cached is bounded in TOTAL, not per
 // geometry: a slide show or a directory of differently sized images keeps the kMaxIdleScalers it used last and
 // destroys the oldest (round 3's pool kept 16 per geometry for the life of the process: the advisor's finding).
-typedef std::tuple<int, int, int, int, int, int> ScalerKey;
+typedef std::tuple<timg_hip_ctx *, int, int, int, int, int, int> ScalerKey;  // (a scaler belongs to its context)
 std::mutex g_scaler_mu;
 std::list<std::pair<ScalerKey, timg_hip_scaler *>> g_scaler_idle;
 std::map<timg_hip_scaler *, ScalerKey> g_scaler_key;  // every scaler handed out or idle
@@ -141,7 +155,7 @@ void HipPoolFree(timg_hip_ctx *ctx, void *ptr) {
 }
 
 timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_fmt, int out_w, int out_h, int filter) {
-    const ScalerKey key(in_w, in_h, in_fmt, out_w, out_h, filter);
+    const ScalerKey key(ctx, in_w, in_h, in_fmt, out_w, out_h, filter);
     {
         std::lock_guard<std::mutex> l(g_scaler_mu);
         for (auto it = g_scaler_idle.begin(); it != g_scaler_idle.end(); ++it)

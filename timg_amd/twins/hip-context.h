@@ -20,6 +20,11 @@ timg_hip_ctx *SharedHipContext();
 // nullptr when it cannot be created (callers then make do with fewer).
 timg_hip_ctx *ExtraHipContext(int k);
 
+// The context a LOADER thread scales host frames on (HipImageScaler): one of a few contexts with their own streams and
+// staging buffers, fixed per thread, so that the uploads of several loaders overlap instead of queueing on the shared
+// context's lock.  Falls back to the shared context.
+timg_hip_ctx *LoaderHipContext();
+
 // GPU selection: TIMG_HIP_DEVICE=<n> (default 0), TIMG_HIP=0 disables.
 bool HipTwinsEnabled();
 

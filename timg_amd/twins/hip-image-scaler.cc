@@ -15,8 +15,9 @@ static uint32_t PackColor(rgba_t c) {
 std::unique_ptr<ImageScaler> HipImageScaler::Create(int in_width, int in_height,
                                                     ColorFmt in_color_format,
                                                     int out_width, int out_height) {
-    timg_hip_ctx *ctx = SharedHipContext();
-    if (!ctx) return nullptr;
+    if (!SharedHipContext()) return nullptr;
+    // (a context per loader thread: the upload of this image runs beside the kernels and uploads of the others)
+    timg_hip_ctx *ctx = LoaderHipContext();
     const int fmt = in_color_format == ColorFmt::kRGBA ? TIMG_HIP_FMT_RGBA : TIMG_HIP_FMT_BGRA;
     // (recycled by geometry: the images of a grid share their plan, hip-context.h)
     timg_hip_scaler *s = HipScalerAcquire(ctx, in_width, in_height, fmt, out_width, out_height, HipScalerFilter());

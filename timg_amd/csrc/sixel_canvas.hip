@@ -1887,12 +1887,9 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
 // the number of colours.
 // v[lane idx] = val for wave-uniform val and idx
 __device__ __forceinline__ void WriteLane(uint32_t &v, uint32_t val, int idx) {
-    // (gfx9: one SGPR operand per VALU instruction, so the lane select travels in M0,
-    // which is saved and restored around the write)
-    uint32_t saved_m0;
-    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                 : "+v"(v), "=&s"(saved_m0)
-                 : "s"(val), "s"(idx));
+    // (gfx9: one SGPR operand per VALU instruction, so the lane select travels in M0 -- which nothing else of these
+    // kernels uses: clobbered, not saved and restored, two instructions instead of four in a loop priced per instruction)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(idx) : "m0");
 }
 
 __global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b, int n_frames) {
@@ -1905,59 +1902,63 @@ __global__ void __launch_bounds__(256) BandPackKernel(SixelGeom g, SixelBatch b,
     const uint32_t *nkey      = s.band_nkey + slot;
     uint32_t *pi              = s.band_pi + slot;
     uint16_t *xs              = s.band_xs + slot;
-    const int n_nodes         = s.band_cnt[band * 4 + 1];
+    const int n_nodes         = __builtin_amdgcn_readfirstlane(s.band_cnt[band * 4 + 1]);  // (wave-uniform: in a scalar register)
 
-    uint32_t pen0 = 0, pen1 = 0, pen2 = 0, pen3 = 0;
-    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    // Pass p lives in lane p % 64 of register p / 64 as ONE word, pen position << 16 | nodes put so far (a pass holds
+    // non-overlapping nodes: fewer than 4096): "does the node fit" is one compare against start << 16 | 0xffff, and a
+    // node costs one v_readlane and one v_writelane of state.  (A wave alone prices its instructions at ~4 clocks
+    // each and a TAKEN branch at 20-80, scratch/ubench/wave_latency.hip: the common case -- the node fits one of the
+    // first 64 passes -- is the fall-through path, and two nodes share a trip round the loop.)
+    uint32_t pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0;
     uint32_t key_next = lane < n_nodes ? nkey[lane] : 0u;
     for (int i0 = 0; i0 < n_nodes; i0 += 64) {
         const uint32_t key = key_next;
         key_next = (i0 + 64 + lane < n_nodes) ? nkey[i0 + 64 + lane] : 0u;
         uint32_t res_pi = 0, res_xs = 0;
         const int m = min(64, n_nodes - i0);
-        for (int j = 0; j < m; ++j) {
+        auto place = [&](int j) __attribute__((always_inline)) {
             const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
             const uint32_t sx = kj >> 20, mx = 4095u - ((kj >> 8) & 0xfffu);
-            unsigned long long fit = __ballot(pen0 <= sx);
-            uint32_t old_pen, old_cnt, pass;
-            if (fit) {
+            const uint32_t limit = (sx << 16) | 0xffffu;
+            unsigned long long fit = __ballot(pc0 <= limit);
+            uint32_t old, pass;
+            if (__builtin_expect(fit != 0, 1)) {
                 const int p = __ffsll((long long)fit) - 1;
-                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen0, p);
-                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt0, p);
-                WriteLane(pen0, mx, p);
-                WriteLane(cnt0, (old_cnt + 1), p);
+                old         = (uint32_t)__builtin_amdgcn_readlane((int)pc0, p);
+                WriteLane(pc0, (mx << 16) | ((old & 0xffffu) + 1u), p);
                 pass        = (uint32_t)p;
-            } else if ((fit = __ballot(pen1 <= sx)) != 0) {
+            } else if ((fit = __ballot(pc1 <= limit)) != 0) {
                 const int p = __ffsll((long long)fit) - 1;
-                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen1, p);
-                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt1, p);
-                WriteLane(pen1, mx, p);
-                WriteLane(cnt1, (old_cnt + 1), p);
+                old         = (uint32_t)__builtin_amdgcn_readlane((int)pc1, p);
+                WriteLane(pc1, (mx << 16) | ((old & 0xffffu) + 1u), p);
                 pass        = 64u + (uint32_t)p;
-            } else if ((fit = __ballot(pen2 <= sx)) != 0) {
+            } else if ((fit = __ballot(pc2 <= limit)) != 0) {
                 const int p = __ffsll((long long)fit) - 1;
-                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen2, p);
-                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt2, p);
-                WriteLane(pen2, mx, p);
-                WriteLane(cnt2, (old_cnt + 1), p);
+                old         = (uint32_t)__builtin_amdgcn_readlane((int)pc2, p);
+                WriteLane(pc2, (mx << 16) | ((old & 0xffffu) + 1u), p);
                 pass        = 128u + (uint32_t)p;
             } else {
-                fit         = __ballot(pen3 <= sx);
+                fit         = __ballot(pc3 <= limit);
                 const int p = fit ? __ffsll((long long)fit) - 1 : 63;
-                old_pen     = (uint32_t)__builtin_amdgcn_readlane((int)pen3, p);
-                old_cnt     = (uint32_t)__builtin_amdgcn_readlane((int)cnt3, p);
-                WriteLane(pen3, mx, p);
-                WriteLane(cnt3, (old_cnt + 1), p);
+                old         = (uint32_t)__builtin_amdgcn_readlane((int)pc3, p);
+                WriteLane(pc3, (mx << 16) | ((old & 0xffffu) + 1u), p);
                 pass        = 192u + (uint32_t)p;
             }
-            WriteLane(res_pi, ((pass << 16) | old_cnt), j);
-            WriteLane(res_xs, old_pen, j);
+            WriteLane(res_pi, (pass << 16) | (old & 0xffffu), j);
+            WriteLane(res_xs, old >> 16, j);
+        };
+        int j = 0;
+        for (; j + 1 < m; j += 2) {
+            place(j);
+            place(j + 1);
         }
+        if (j < m) place(j);
         if (i0 + lane < n_nodes) {
             pi[i0 + lane] = res_pi;
             xs[i0 + lane] = (uint16_t)res_xs;
         }
     }
+    const uint32_t cnt0 = pc0 & 0xffffu, cnt1 = pc1 & 0xffffu, cnt2 = pc2 & 0xffffu, cnt3 = pc3 & 0xffffu;
     // output slot of the first node of every pass: exclusive scan of the 256 counts
     __shared__ uint32_t s_pbase[4][256];
     uint32_t *pb  = s_pbase[threadIdx.x >> 6];

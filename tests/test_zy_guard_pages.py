@@ -52,7 +52,9 @@ def test_the_guard_itself_catches_an_over_read_and_an_over_write():
     (poisoned slack, checked at free) and fault in mode end4."""
     r = _child(["-c", _LIE % {"root": ROOT, "what": "read"}], "end4", 300)
     assert r.returncode != 0 and "survived" not in r.stdout, (r.stdout, r.stderr[-400:])
-    assert "Memory access fault" in r.stderr + r.stdout, r.stderr[-600:]
+    # (how the fault surfaces is the box's: the runtime aborts the process with "Memory access fault by GPU ...", or -- seen on
+    # a lease of round 4 -- the synchronising call returns hipErrorIllegalAddress and the library reports it)
+    assert "Memory access fault" in r.stderr + r.stdout or "illegal memory access" in r.stderr + r.stdout, r.stderr[-600:]
     r = _child(["-c", _LIE % {"root": ROOT, "what": "write"}], "start", 300)
     assert r.returncode != 0 and "timg_hip GUARD" in r.stderr, (r.returncode, r.stderr[-600:])
     r = _child(["-c", _LIE % {"root": ROOT, "what": "write"}], "end4", 300)

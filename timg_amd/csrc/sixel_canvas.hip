@@ -1564,6 +1564,13 @@ template <bool kWide, int kT>
 __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b) {
     static_assert(kT == 256 || (!kWide && kT == 512), "the wide path's radix counters are laid out for 256 lanes");
     extern __shared__ uint32_t lds[];
+#ifdef TIMG_BANDS_TRACE  // (-DTIMG_BANDS_TRACE: 100 MHz ticks between the phases of ONE band, printed by its thread 0)
+    long long t_phase[16];
+    int n_phase = 0;
+#define TIMG_PHASE() do { __syncthreads(); if (n_phase < 16) t_phase[n_phase++] = wall_clock64(); } while (0)
+#else
+#define TIMG_PHASE() do { } while (0)
+#endif
     const int NE = g.band_ne;
     // aux: 4096 words of radix histogram (wide frames), later ONE column-indexed bucket word per column: nodes
     // starting in the column (later: their base) in the low half, the fill counter in the high half.  The sort
@@ -1633,6 +1640,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
             }
         }
     };
+    TIMG_PHASE();  // 0: index rows loaded
     int n_ent;
     if constexpr (!kWide) {
         // ---- entries sorted by (colour, column) in one pass.  The sort is stable by construction:
@@ -1642,6 +1650,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         // chunks is), just atomics, one row scan per colour and one placement per entry.
         for (int i = tid; i < 256 * nws; i += kT) bitmap[i] = 0;  // (while the index loads are in flight)
         __syncthreads();
+        TIMG_PHASE();  // 1: bitmap cleared
         for_columns([&](int n) {
             for (int j = 0; j < n; ++j) {
                 const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
@@ -1649,6 +1658,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
             }
         });
         __syncthreads();
+        TIMG_PHASE();  // 2: presence bitmap
         uint32_t total = 0;
         if (tid < 256)
             for (int w = 0; w < nws; ++w) {  // lane = colour
@@ -1660,6 +1670,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         if (tid < 256) cbase[tid] = cb;
         n_ent = (int)n_ent_u;
         __syncthreads();
+        TIMG_PHASE();  // 3: row scans + colour bases
         for_columns([&](int n) {
             for (int j = 0; j < n; ++j) {
                 const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
@@ -1716,6 +1727,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         }
 
     }
+    TIMG_PHASE();  // 4: entries placed (sorted)
     const int per_e = (n_ent + kT - 1) / kT;
     const int e0 = min(n_ent, tid * per_e), e1 = min(n_ent, e0 + per_e);
 
@@ -1754,6 +1766,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     auto run_starts_at = [&](int i) {
         return kMasks ? ((run_bits >> (i - e0)) & 1u) != 0 : (i == 0 || run_break2(ent_a[i - 1], ent_a[i]));
     };
+    TIMG_PHASE();  // 5: node / run flags
     uint32_t totals;
     const uint32_t before = BlockExclusiveScan<kT>(starts, s_tmp, &totals);
     const int n_nodes = (int)(totals >> 16);
@@ -1771,6 +1784,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     for (int x = tid; x <= W; x += kT) aux[x] = 0;  // nodes starting in column x | fill counter << 16
     if (kWide) __threadfence_block();
     __syncthreads();
+    TIMG_PHASE();  // 6: node / run firsts written
     // bytes per entry: the gap in front of a run at the run's first entry, the run at its last
     {
         uint16_t *erl_g = s.band_erl + slot;
@@ -1801,6 +1815,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     }
     if (kWide) __threadfence_block();
     __syncthreads();
+    TIMG_PHASE();  // 7: bytes per entry + prefix
     uint32_t *key_u = ent_b;
     uint16_t *nf_g = s.band_nf + slot;
     for (int n = tid; n < n_nodes; n += kT) {
@@ -1814,6 +1829,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     }
     if (kWide) __threadfence_block();
     __syncthreads();
+    TIMG_PHASE();  // 8: node keys + bucket counts
     // bucket bases: exclusive scan over the columns
     {
         const int per_x = (W + kT) / kT;
@@ -1829,6 +1845,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     }
     if (kWide) __threadfence_block();
     __syncthreads();
+    TIMG_PHASE();  // 9: bucket bases
     uint32_t *nkey   = s.band_nkey + slot;
     uint16_t *nfirst = s.band_nfirst + slot;
     for (int n = tid; n < n_nodes; n += kT) {
@@ -1841,6 +1858,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     }
     if (kWide) __threadfence_block();
     __syncthreads();  // (also orders the global writes above inside the workgroup)
+    TIMG_PHASE();  // 10: nodes into buckets
     // nodes starting in the same column (at most 6: one per colour of the column):
     // order them by end desc, colour asc = ascending key
     for (int x = tid; x < W; x += kT) {
@@ -1871,14 +1889,24 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
             nfirst[base + j] = ff[j];
         }
     }
+    TIMG_PHASE();  // 11: buckets ordered
     if (!kWide) {
         uint32_t *ent_g = s.band_ent + slot;
         for (int i = tid; i < n_ent; i += kT) ent_g[i] = ent_a[i];
     }
+    TIMG_PHASE();  // 12: sorted entries out
     if (tid == 0) {
         s.band_cnt[band * 4 + 0] = n_ent;
         s.band_cnt[band * 4 + 1] = n_nodes;
     }
+#ifdef TIMG_BANDS_TRACE
+    if (tid == 0 && band == 30 && f == 0) {
+        printf("bands: n_ent %d n_nodes %d ticks(100MHz) between phases:", n_ent, n_nodes);
+        for (int i = 1; i < n_phase; ++i) printf(" %d:%lld", i, t_phase[i] - t_phase[i - 1]);
+        printf(" total %lld\n", t_phase[n_phase - 1] - t_phase[0]);
+    }
+#endif
+#undef TIMG_PHASE
 }
 
 // K5b: one wave per band.  Pass p's pen position lives in lane p % 64 of register p / 64

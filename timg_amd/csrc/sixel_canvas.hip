@@ -1608,7 +1608,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     const uint8_t *rows       = s.index + (size_t)band * 6 * g.idx_stride;
     const size_t slot         = (size_t)band * NE;
 
-    // ---- entries, column-major: count, scan, write.  A lane takes kGroups x 4 adjacent
+    // ---- entries, column-major: count, scan, write.  (Wide frames:) a lane takes kGroups x 4 adjacent
     // columns; the six index rows of a group arrive as six 4-byte loads (the rows of the
     // index image are padded to 4) that are issued together and kept for both passes.
     constexpr int kGroups = 1024 / kT;  // kT lanes x kGroups groups x 4 columns >= kMaxSixelWidth
@@ -1617,13 +1617,15 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     const int per_g       = (n_groups + kT - 1) / kT;
     const int g0 = min(n_groups, tid * per_g), g1 = min(n_groups, g0 + per_g);
     uint32_t cw[kGroups][6];
+    if constexpr (kWide) {
 #pragma unroll
-    for (int gi = 0; gi < kGroups; ++gi)
+        for (int gi = 0; gi < kGroups; ++gi)
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-            cw[gi][r] = g0 + gi < g1 ? *reinterpret_cast<const uint32_t *>(rows + (size_t)r * g.idx_stride +
-                                                                         4 * (g0 + gi))
-                                     : 0u;
+            for (int r = 0; r < 6; ++r)
+                cw[gi][r] = g0 + gi < g1 ? *reinterpret_cast<const uint32_t *>(rows + (size_t)r * g.idx_stride +
+                                                                             4 * (g0 + gi))
+                                         : 0u;
+    }
     uint32_t e6[6];
     auto for_columns = [&](auto &&visit) {
 #pragma unroll
@@ -1648,15 +1650,59 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         // x -- a popcount over c's row of a presence bitmap plus a per-word prefix.  No
         // per-lane chains of dependent LDS updates (which is what a counting sort over lane
         // chunks is), just atomics, one row scan per colour and one placement per entry.
+        //
+        // A lane takes PAIRS of columns (kT lanes x kPairs pairs cover the 1365 columns whose bands sort in LDS; up to
+        // 1024 columns one pair a lane: every lane works, where groups of four left 312 of 512 idle at 800 columns).
+        // A column's entries are its six rows with a "first row of its colour" flag -- fixed register slots, no
+        // compaction: round 3's e6[n++] with a run-time n lived in SCRATCH memory (112 scratch instructions in this
+        // kernel), and was computed twice.  Phases 2 + 4 of a band: 14.9 -> see DESIGN.md 4.3.
+        constexpr int kPairs = 2;
+        static_assert(kT * kPairs * 2 >= 1366, "a lane's column pairs cover the widest frame that sorts in LDS");
+        const int n_pairs = (W + 1) >> 1;
+        const int per_p   = (n_pairs + kT - 1) / kT;
+        const int h0 = min(n_pairs, tid * per_p), h1 = min(n_pairs, h0 + per_p);
+        uint32_t c16[kPairs][6];
+#pragma unroll
+        for (int pi2 = 0; pi2 < kPairs; ++pi2)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                c16[pi2][r] = h0 + pi2 < h1 ? *reinterpret_cast<const uint16_t *>(rows + (size_t)r * g.idx_stride + 2 * (h0 + pi2))
+                                            : 0u;
         for (int i = tid; i < 256 * nws; i += kT) bitmap[i] = 0;  // (while the index loads are in flight)
+        // the entries of a lane's (up to four) columns: ent[k][r] valid where bit r of first[k] is set
+        uint32_t ent[2 * kPairs][6];
+        uint32_t first[2 * kPairs];
+#pragma unroll
+        for (int k = 0; k < 2 * kPairs; ++k) {
+            const int x      = 2 * (h0 + (k >> 1)) + (k & 1);
+            const bool there = h0 + (k >> 1) < h1 && x < W;
+            uint32_t c[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) c[r] = (c16[k >> 1][r] >> (8 * (k & 1))) & 0xffu;
+            uint32_t fr = there ? 0x3fu : 0u;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                uint32_t mask = 1u << r;
+#pragma unroll
+                for (int q = r + 1; q < 6; ++q) {
+                    const bool same = c[q] == c[r];
+                    mask |= same ? 1u << q : 0u;
+                    fr &= same ? ~(1u << q) : ~0u;  // (a later row of the same colour is not a first row)
+                }
+                ent[k][r] = (c[r] << 22) | ((uint32_t)x << 6) | mask;
+            }
+            first[k] = fr;
+        }
         __syncthreads();
         TIMG_PHASE();  // 1: bitmap cleared
-        for_columns([&](int n) {
-            for (int j = 0; j < n; ++j) {
-                const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
-                atomicOr(&bitmap[c * nws + (x >> 5)], 1u << (x & 31u));
-            }
-        });
+#pragma unroll
+        for (int k = 0; k < 2 * kPairs; ++k)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                if (first[k] & (1u << r)) {
+                    const uint32_t c = ent[k][r] >> 22, x = (ent[k][r] >> 6) & 0xffffu;
+                    atomicOr(&bitmap[c * nws + (x >> 5)], 1u << (x & 31u));
+                }
         __syncthreads();
         TIMG_PHASE();  // 2: presence bitmap
         uint32_t total = 0;
@@ -1671,16 +1717,18 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         n_ent = (int)n_ent_u;
         __syncthreads();
         TIMG_PHASE();  // 3: row scans + colour bases
-        for_columns([&](int n) {
-            for (int j = 0; j < n; ++j) {
-                const uint32_t c = e6[j] >> 22, x = (e6[j] >> 6) & 0xffffu;
-                const uint32_t w = x >> 5, at = c * nws + w;
-                // (columns of c below x: the pair's prefix, the even word of the pair for an odd one, this word's bits)
-                const uint32_t below_pair = (w & 1u) ? (uint32_t)__popc(bitmap[at - 1]) : 0u;
-                ent_a[cbase[c] + wprefix[c * nwp + (w >> 1)] + below_pair +
-                      (uint32_t)__popc(bitmap[at] & ((1u << (x & 31u)) - 1u))] = e6[j];
-            }
-        });
+#pragma unroll
+        for (int k = 0; k < 2 * kPairs; ++k)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                if (first[k] & (1u << r)) {
+                    const uint32_t c = ent[k][r] >> 22, x = (ent[k][r] >> 6) & 0xffffu;
+                    const uint32_t w = x >> 5, at = c * nws + w;
+                    // (columns of c below x: the pair's prefix, the even word of the pair for an odd one, this word's bits)
+                    const uint32_t below_pair = (w & 1u) ? (uint32_t)__popc(bitmap[at - 1]) : 0u;
+                    ent_a[cbase[c] + wprefix[c * nwp + (w >> 1)] + below_pair +
+                          (uint32_t)__popc(bitmap[at] & ((1u << (x & 31u)) - 1u))] = ent[k][r];
+                }
         __syncthreads();
     } else {
         uint32_t mine = 0;

@@ -1540,24 +1540,6 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_t
     return before + incl - v;
 }
 
-// distinct colours of one column of a band: up to 6 (colour, row mask) pairs in
-// order of first occurrence
-__device__ __forceinline__ int ColumnEntries(const uint32_t c[6], int x, uint32_t ent[6]) {
-    uint32_t done = 0;
-    int n         = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        if (done & (1u << r)) continue;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int q = r; q < 6; ++q)
-            if (c[q] == c[r]) mask |= 1u << q;
-        done |= mask;
-        ent[n++] = (c[r] << 22) | ((uint32_t)x << 6) | mask;
-    }
-    return n;
-}
-
 // kT lanes per band: 512 for bands whose sort buffers live in LDS (two workgroups per CU by their LDS: 16 waves per
 // CU instead of 8 -- the kernel is a chain of short phases between barriers, latency-bound), 256 for wide frames
 template <bool kWide, int kT>
@@ -1626,7 +1608,8 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
                                                                              4 * (g0 + gi))
                                          : 0u;
     }
-    uint32_t e6[6];
+    // (wide frames) visit(first, ent): a column's six rows as entries in FIXED slots, bit r of `first` set where row r is
+    // the first of its colour -- no compaction into an array indexed at run time (that array lived in scratch memory)
     auto for_columns = [&](auto &&visit) {
 #pragma unroll
         for (int gi = 0; gi < kGroups; ++gi) {
@@ -1635,10 +1618,22 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
             for (int q = 0; q < 4; ++q) {
                 const int x = 4 * (g0 + gi) + q;
                 if (x >= W) break;
-                uint32_t c[6];
+                uint32_t c[6], ent[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) c[r] = (cw[gi][r] >> (8 * q)) & 0xffu;
-                visit(ColumnEntries(c, x, e6));
+                uint32_t fr = 0x3fu;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    uint32_t mask = 1u << r;
+#pragma unroll
+                    for (int p = r + 1; p < 6; ++p) {
+                        const bool same = c[p] == c[r];
+                        mask |= same ? 1u << p : 0u;
+                        fr &= same ? ~(1u << p) : ~0u;
+                    }
+                    ent[r] = (c[r] << 22) | ((uint32_t)x << 6) | mask;
+                }
+                visit(fr, ent);
             }
         }
     };
@@ -1732,13 +1727,15 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         __syncthreads();
     } else {
         uint32_t mine = 0;
-        for_columns([&](int n) { mine += (uint32_t)n; });
+        for_columns([&](uint32_t fr, const uint32_t *) { mine += (uint32_t)__popc(fr); });
         uint32_t n_ent_u;
         uint32_t at = BlockExclusiveScan<kT>(mine, s_tmp, &n_ent_u);
         n_ent = (int)n_ent_u;
-        for_columns([&](int n) {
-            for (int j = 0; j < n; ++j) ent_a[at + j] = e6[j];
-            at += (uint32_t)n;
+        for_columns([&](uint32_t fr, const uint32_t *ent) {  // (a column's entries in row order of their first rows)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                if (fr & (1u << r)) ent_a[at + (uint32_t)__popc(fr & ((1u << r) - 1u))] = ent[r];
+            at += (uint32_t)__popc(fr);
         });
         if (kWide) __threadfence_block();
         __syncthreads();

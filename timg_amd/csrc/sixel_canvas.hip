@@ -1513,6 +1513,37 @@ __device__ __forceinline__ int FlushRun(char *&p, int ch, int count) {
     return n;
 }
 
+// FlushRun for 1 <= count <= 255 without a branch: the run's bytes (at most five: "!255c") left-aligned in a word pair,
+// their number in n.  (The emit kernel is bound by the instructions its waves issue -- 4 800 bands x 4 waves x a few
+// thousand instructions: per-lane loops over digits and characters, every lane of a wave on a different path, were
+// most of them.)
+__device__ __forceinline__ uint64_t RunWord(int ch, int count, int &n) {
+    const uint32_t c  = (uint32_t)count, chu = (uint32_t)ch;
+    const uint32_t d2 = c >= 200u ? 2u : c >= 100u ? 1u : 0u, r = c - 100u * d2, d1 = (r * 205u) >> 11, d0 = r - 10u * d1;  // r < 100
+    const uint32_t nd = c >= 100u ? 3u : c >= 10u ? 2u : 1u;
+    // the digits, first one in the low byte
+    const uint32_t dig = nd == 3u ? (0x303030u + (d2 | d1 << 8 | d0 << 16)) : nd == 2u ? (0x3030u + (d1 | d0 << 8)) : (0x30u + d0);
+    const uint64_t flash = (uint64_t)('!' | dig << 8) | (uint64_t)chu << (8u * (1u + nd));
+    const bool plain = c <= 3u;
+    n = plain ? (int)c : (int)(2u + nd);
+    return plain ? (uint64_t)(chu * 0x010101u) : flash;
+}
+
+// the first n (<= 8) bytes of v to p (any alignment): at most four stores
+__device__ __forceinline__ void StoreBytes(char *p, uint64_t v, int n) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (n >= 4) __builtin_memcpy(p, &lo, 4);
+    if (n == 8) __builtin_memcpy(p + 4, &hi, 4);
+    const int base     = n & 4;  // (n == 8: nothing is left)
+    const uint32_t w   = base ? hi : lo;
+    const int rest     = n == 8 ? 0 : n & 3;
+    if (rest & 2) {
+        const uint16_t h = (uint16_t)w;
+        __builtin_memcpy(p + base, &h, 2);
+    }
+    if (rest & 1) p[base + (rest & 2)] = (char)(w >> (8 * (rest & 2)));
+}
+
 // byte count of FlushRun for a run of `count` (0: nothing): "!255c" for every full 255 beyond
 // the last piece, then "!nc" or up to three plain characters
 __device__ __forceinline__ int RunBytes(int count) {
@@ -2077,6 +2108,14 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
     const uint32_t body_total = (uint32_t)s.band_cnt[band * 4 + 2];
     if (tid == 0) s_overflow = 0;
     __syncthreads();
+#ifdef TIMG_BANDS_TRACE
+    long long t_phase[8];
+    int n_phase = 0;
+#define TIMG_PHASE() do { __syncthreads(); if (n_phase < 8) t_phase[n_phase++] = wall_clock64(); } while (0)
+#else
+#define TIMG_PHASE() do { } while (0)
+#endif
+    TIMG_PHASE();
 
     // A slot's node: what stands in front of its body ('$', "#c", the gap from the pen position)
     // and where the body's bytes lie in the band-wide prefix the node kernel left behind.
@@ -2086,6 +2125,7 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         uint32_t body0, body;  // prefix at the node's first entry, bytes of its runs and inner gaps
     };
     auto describe = [&](int k) {
+        if (n_nodes <= 0) return Slot{};  // (nothing to describe: the records are not there)
         const uint2 r      = rec[k];
         const uint32_t key = r.x;
         Slot d;
@@ -2101,13 +2141,19 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         d.body  = (next < n_ent ? ep[next] : body_total) - d.body0;
         return d;
     };
-    // phase 1: byte size of every output slot -- no walk over the node, see BandNodes
-    for (int k = tid; k < n_nodes; k += 256) {
-        const Slot d = describe(k);
-        node_off[k]  = (d.cr ? 1u : 0u) + (d.tag ? 1u + (uint32_t)NumLen((uint32_t)d.color) : 0u) +
-                      (uint32_t)RunBytes(d.sx - d.x_start) + d.body;
-    }
+    // phase 1: byte size of every output slot -- no walk over the node, see BandNodes.  (A slot's description is three
+    // dependent levels of memory loads: the first two slots of a lane -- all of them for bands of up to 512 nodes --
+    // are described once, both at a time, and kept for phase 2a.)
+    auto slot_bytes = [&](const Slot &d) {
+        return (d.cr ? 1u : 0u) + (d.tag ? 1u + (uint32_t)NumLen((uint32_t)d.color) : 0u) +
+               (uint32_t)RunBytes(d.sx - d.x_start) + d.body;
+    };
+    const Slot d0 = describe(min(tid, max(n_nodes - 1, 0))), d1 = describe(min(tid + 256, max(n_nodes - 1, 0)));
+    if (tid < n_nodes) node_off[tid] = slot_bytes(d0);
+    if (tid + 256 < n_nodes) node_off[tid + 256] = slot_bytes(d1);
+    for (int k = tid + 512; k < n_nodes; k += 256) node_off[k] = slot_bytes(describe(k));
     __syncthreads();
+    TIMG_PHASE();  // 1: slot sizes
     // exclusive scan (256 contiguous chunks)
     const int lead = band > 0 ? 1 : 0;  // '-' (DECGNL) in front of every band but the first
     {
@@ -2130,6 +2176,7 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         if (tid == 255) s_scan[4] = before + incl + (uint32_t)lead;
         __syncthreads();
     }
+    TIMG_PHASE();  // 2: scan
     const uint32_t band_len = s_scan[4];
     char *out_band = s.band_bytes + (size_t)band * g.band_cap;
     if (band_len > g.band_cap) {
@@ -2138,9 +2185,8 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
         if (tid == 0 && lead) out_band[0] = '-';
         // phase 2a, per slot: what stands in front of the body; and where the body goes, as an
         // offset to add to an entry's prefix
-        for (int k = tid; k < n_nodes; k += 256) {
-            const Slot d = describe(k);
-            char *p      = out_band + node_off[k];
+        auto front = [&](const Slot &d, int k) {
+            char *p = out_band + node_off[k];
             if (d.cr) *p++ = '$';
             if (d.tag) {
                 *p++ = '#';
@@ -2148,24 +2194,70 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
             }
             if (d.sx > d.x_start) FlushRun<true>(p, '?', d.sx - d.x_start);
             node_base[d.node] = (uint32_t)(p - out_band) - d.body0;
-        }
+        };
+        if (tid < n_nodes) front(d0, tid);
+        if (tid + 256 < n_nodes) front(d1, tid + 256);
+        for (int k = tid + 512; k < n_nodes; k += 256) front(describe(k), k);
         __threadfence_block();
         __syncthreads();
+        TIMG_PHASE();  // 3: what stands in front of the bodies
         // phase 2b, per ENTRY: the gap in front of a run is written by the run's first entry, the
         // run by its last
-        for (int i = tid; i < n_ent; i += 256) {
-            const uint32_t e  = ent[i];
-            const int node    = enode[i];
-            const int len     = erl[i];
-            const bool inside = i > 0 && (int)enode[i - 1] == node;
-            const int gap     = inside ? (int)((e >> 6) & 0xffffu) - (int)((ent[i - 1] >> 6) & 0xffffu) - 1 : 0;
-            if (gap <= 0 && len == 0) continue;
-            char *p = out_band + (uint32_t)(node_base[node] + ep[i]);  // (the sum wraps in 32 bits by design)
-            if (gap > 0) FlushRun<true>(p, '?', gap);
-            if (len > 0) FlushRun<true>(p, (int)(e & 0x3fu) + '?', len);
+        // (four entries a lane at a time: their loads -- two dependent levels -- in flight together.  One entry per
+        // trip was a chain of memory round trips, ten to twenty a band: the stores of a trip may alias the next
+        // trip's loads for all the compiler knows, so it kept them in order -- 22 of the kernel's 34 us a band.)
+        constexpr int kBatch = 4;
+        for (int i0 = tid; i0 < n_ent; i0 += 256 * kBatch) {
+            uint32_t e_[kBatch], pe_[kBatch], ep_[kBatch], nb_[kBatch];
+            int node_[kBatch], pnode_[kBatch], len_[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int i  = min(i0 + 256 * j, n_ent - 1);  // (past the end: the last entry again, not emitted)
+                e_[j]        = ent[i];
+                node_[j]     = enode[i];
+                len_[j]      = erl[i];
+                ep_[j]       = ep[i];
+                pe_[j]       = ent[max(i - 1, 0)];
+                pnode_[j]    = enode[max(i - 1, 0)];
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) nb_[j] = node_base[node_[j]];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int i = i0 + 256 * j;
+                if (i >= n_ent) continue;
+                const uint32_t e  = e_[j];
+                const int len     = len_[j];
+                const bool inside = i > 0 && pnode_[j] == node_[j];
+                const int gap     = inside ? (int)((e >> 6) & 0xffffu) - (int)((pe_[j] >> 6) & 0xffffu) - 1 : 0;
+                if (gap <= 0 && len == 0) continue;
+                char *p = out_band + (uint32_t)(nb_[j] + ep_[j]);  // (the sum wraps in 32 bits by design)
+                if (__builtin_expect(len > 255, 0)) {  // (a run longer than a repeat count holds: libsixel cuts it into "!255c" pieces)
+                    if (gap > 0) FlushRun<true>(p, '?', gap);
+                    FlushRun<true>(p, (int)(e & 0x3fu) + '?', len);
+                    continue;
+                }
+                // the gap in front of the run (inside a node: fewer than ten columns) and the run: at most 3 + 5 bytes
+                int n_gap = 0, n_run = 0;
+                const uint64_t v_gap = RunWord('?', gap > 0 ? gap : 1, n_gap);
+                const uint64_t v_run = RunWord((int)(e & 0x3fu) + '?', len > 0 ? len : 1, n_run);
+                if (gap <= 0) n_gap = 0;
+                if (len <= 0) n_run = 0;
+                StoreBytes(p, (n_gap ? v_gap & ((1ull << (8 * n_gap)) - 1ull) : 0ull) | (n_run ? v_run << (8 * n_gap) : 0ull),
+                           n_gap + n_run);
+            }
         }
     }
     __syncthreads();
+    TIMG_PHASE();  // 4: runs and gaps
+#ifdef TIMG_BANDS_TRACE
+    if (tid == 0 && band == 30 && f == 0) {
+        printf("emit: n_ent %d n_nodes %d ticks(100MHz) between phases:", n_ent, n_nodes);
+        for (int i = 1; i < n_phase; ++i) printf(" %d:%lld", i, t_phase[i] - t_phase[i - 1]);
+        printf(" total %lld\n", t_phase[n_phase - 1] - t_phase[0]);
+    }
+#endif
+#undef TIMG_PHASE
     if (tid == 0) {
         const int first_color = n_nodes ? (int)(rec[0].x & 0xffu) : -1;
         const int last_color  = n_nodes ? (int)(rec[n_nodes - 1].x & 0xffu) : -1;

@@ -1924,6 +1924,55 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     TIMG_PHASE();  // 9: bucket bases
     uint32_t *nkey   = s.band_nkey + slot;
     uint16_t *nfirst = s.band_nfirst + slot;
+    if constexpr (!kWide) {
+        // Nodes into the buckets of their start columns as node NUMBERS in LDS (nfirst_u is free again: its last
+        // reader was the loop above), ordered there and written to memory once.  (Keys and numbers used to be scattered
+        // to memory in arrival order, read back per column, ordered and stored again: two dependent round trips to
+        // memory at the end of every band, 3.5 of its 18 us.)
+        uint16_t *order = nfirst_u;
+        for (int n = tid; n < n_nodes; n += kT) {
+            const uint32_t sx  = key_u[n] >> 20;
+            const uint32_t was = atomicAdd(&aux[sx], 0x10000u);  // (base in the low half: < 6 * kMaxSixelWidth < 2^16)
+            order[(was & 0xffffu) + (was >> 16)] = (uint16_t)n;
+        }
+        __syncthreads();
+        TIMG_PHASE();  // 10: nodes into buckets
+        // nodes starting in the same column (at most 6: one per colour of the column): by end desc, colour asc =
+        // ascending key -- a sorting network over six fixed slots (absent ones carry the largest key)
+        for (int x = tid; x < W; x += kT) {
+            const uint32_t ax = aux[x];
+            const int c = (int)(ax >> 16);
+            if (c == 0) continue;
+            const uint32_t base = ax & 0xffffu;
+            uint32_t kk[6], nn[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                nn[j] = j < c ? order[base + j] : 0u;
+                kk[j] = j < c ? key_u[nn[j]] : 0xffffffffu;
+            }
+            auto cx = [&](int i, int j) {
+                const bool sw     = kk[i] > kk[j];
+                const uint32_t ki = kk[i], ni = nn[i];
+                kk[i] = sw ? kk[j] : ki;
+                nn[i] = sw ? nn[j] : ni;
+                kk[j] = sw ? ki : kk[j];
+                nn[j] = sw ? ni : nn[j];
+            };
+            if (c > 1) {
+                cx(0, 5); cx(1, 3); cx(2, 4);
+                cx(1, 2); cx(3, 4);
+                cx(0, 3); cx(2, 5);
+                cx(0, 1); cx(2, 3); cx(4, 5);
+                cx(1, 2); cx(3, 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < c) {
+                    nkey[base + j]   = kk[j];
+                    nfirst[base + j] = (uint16_t)nn[j];
+                }
+        }
+    } else {
     for (int n = tid; n < n_nodes; n += kT) {
         const uint32_t key = key_u[n];
         const uint32_t sx  = key >> 20;
@@ -1964,6 +2013,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
             nkey[base + j]   = kk[j];
             nfirst[base + j] = ff[j];
         }
+    }
     }
     TIMG_PHASE();  // 11: buckets ordered
     if (!kWide) {

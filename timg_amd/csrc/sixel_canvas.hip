@@ -1122,8 +1122,20 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         uint32_t in_addr         = lds0 + (uint32_t)kDitherLdsHead +
                                    (uint32_t)(kDitherTabWords + (follows ? producer : zero_row) * brow) * 4u + (odd ? 8u : 0u);
         // out_addr: this half's part of the record of column x = t - 2 * rl in this wave's own row
-        uint32_t out_addr        = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + wave * brow) * 4u + 12u +
-                                   (odd ? 8u : 0u) - 24u * (uint32_t)rl;
+        const uint32_t my_row    = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + wave * brow) * 4u + (odd ? 8u : 0u);
+        uint32_t out_addr        = my_row + 12u - 24u * (uint32_t)rl;
+        // Handing down WITHOUT touching exec: every lane packs and stores a record and a progress value, every step -- the
+        // lanes that have nothing to hand down (all but one pair of the wave) into a slot of their own in the slack behind
+        // the rows, the pair that has with its address clamped to its row: column -1 (zeros into slot 0, which holds
+        // zeros) while it has not started, slot W + 2 (nobody reads it) once it is through.  (The predicated form --
+        // v_cmp, s_and, s_and_saveexec, branch, s_and exec, s_or exec around five instructions of work -- cost every
+        // step of every wave ~75 clocks for one row in thirty-two: scratch/ubench/wave_latency.hip.)
+        const uint32_t slack     = lds0 + (uint32_t)kDitherLdsHead + (uint32_t)(kDitherTabWords + (zero_row + 1) * brow) * 4u;
+        const uint32_t rec_lo    = hands_down ? my_row : slack + 8u * (uint32_t)lane;                      // slot 0 = column -1
+        const uint32_t rec_hi    = hands_down ? my_row + 12u * (uint32_t)(W + 2) : slack + 8u * (uint32_t)lane;
+        const uint32_t prog_addr = (hands_down && !odd) ? lds0 + 4u * (uint32_t)wave : slack + 512u + 4u * (uint32_t)lane;
+        int prog_run             = round * n_pub + 1 - 2 * rl;  // (+ t: columns this row has finished, before clamping)
+        const int prog_lo = round * n_pub, prog_hi = round * n_pub + n_pub;
         // (a wave with no row above it finds every column "published": its own counter, against a base far below)
         const int in_base        = follows ? producer_round * n_pub : -(1 << 30);
         const int out_base       = round * n_pub;
@@ -1170,9 +1182,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // requested one step before it is unpacked.  (The slot is not clamped to the row: past its end the slots of the
         // following row -- or the slack behind the last one, sixel_launch.h -- are read, for lanes that are outside
         // their rows by then.)
-        auto request = [&](int x_rec, uint32_t slot_addr, bool check = true) __attribute__((always_inline)) {
+        auto request = [&](int x_rec, uint32_t slot_addr, bool check = true, bool look = true) __attribute__((always_inline)) {
             if (check) wait_for(min(x_rec + 1, n_pub));
-            peek();
+            if (look) peek();
             const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = this half's part of slot x_rec + 1
             n_lo = slot[0];
             n_hi = slot[1];
@@ -1228,8 +1240,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             }
             // the record requested a step ago (column t + 2), and the request for column t + 3
             const uint32_t q_lo = n_lo, q_hi = n_hi;
-            // (the counter is looked at every other step, for two records: half the scalar work of the check)
-            request(t + 3 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 4) * 12u, (k & 1) == 0);
+            // (the counter is looked at every other step, for two records: half the scalar work of the check ...
+            // ... and read only in the step before it is looked at: a read nobody uses still has to land before its
+            // register takes the next record)
+            request(t + 3 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 4) * 12u, (k & 1) == 0, (k & 1) != 0);
             uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
             if (rl == 0) {
                 up_l = up1_a;
@@ -1289,17 +1303,18 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t m3 = AsBits(err * k3 + sgn) & 0xff00ff00u;
             const uint32_t m1 = AsBits(err + sgn) & 0xff00ff00u;
             if constexpr ((k & 1) == 0) first_q3 = x == 0 ? m3 : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
-            if (hands_down && (unsigned)x < (unsigned)n_pub) {  // (column W: outside the row, a record of zeros)
+            {  // (all lanes, see rec_lo above; column W: outside the row, a record of zeros)
                 const uint32_t w1 = __builtin_amdgcn_perm(m5, m1, sel_w1);
                 const uint32_t w2 = __builtin_amdgcn_perm(m3, w1, sel_w2);
-                // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32, not a ds_write_b64)
-                LdsU32 *rec = (LdsU32 *)(uintptr_t)(out_addr + (uint32_t)k * 12u);
+                uint32_t at;  // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32)
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(out_addr + (uint32_t)k * 12u), "v"(rec_lo), "v"(rec_hi));
+                LdsU32 *rec = (LdsU32 *)(uintptr_t)at;
                 rec[0] = w2;
                 rec[1] = w1;
-                asm volatile("" ::: "memory");
-                if (!odd)
-                    __hip_atomic_store(&progress[wave], out_base + x + 1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
+                int pv;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + k), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
+                *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
             }
             own7 = m7;
             c3   = c2;
@@ -1347,6 +1362,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             TIMG_DITHER_STEP(7, p7, l7)
             in_addr += 96u;
             out_addr += 96u;
+            prog_run += 8;
             idx_addr += 8u;
         }
         // the 16 requests still in flight must land before their registers are used for anything else

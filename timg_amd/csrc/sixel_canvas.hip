@@ -239,11 +239,21 @@ __device__ __forceinline__ uint32_t PlaneKey(uint32_t entry, int plane) {
     return (entry >> (10 - 5 * plane)) & 0x1fu;  // plane 0=r 1=g 2=b
 }
 
-struct alignas(16) CutBox {  // (32 bytes: the bookkeeping wave fetches a record as two 16-byte LDS reads)
+struct CutBox {  // what a split needs to know of its box (registers)
     uint32_t ind, colors, sum, buf;  // buf: which half of the ping-pong table holds it
-    uint32_t median, lowersum;       // prepared split (valid when ready != 0)
-    uint32_t ready, pad;
 };
+// A box of the list in LDS, 16 bytes: the bookkeeping reads (w0, w2) of every box it is about to split in one
+// ds_read_b64 and writes a box with one ds_write_b128.  ind < 32768, colors <= 32768, median < colors and every pixel
+// sum <= the number of samples (<= 36766) -- sixteen bits each.
+struct alignas(16) CutRec {
+    uint32_t w0;  // ind | buf << 15 | colors << 16
+    uint32_t w2;  // the prepared split: median | lowersum << 16
+    uint32_t w1;  // sum | tie << 16   (tie = 256 -+ the step that made the box: see "The box list")
+    uint32_t spare;
+};
+__device__ __forceinline__ CutBox BoxOf(const CutRec &r) {
+    return CutBox{r.w0 & 0x7fffu, r.w0 >> 16, r.w1 & 0xffffu, (r.w0 >> 15) & 1u};
+}
 
 // Memory traffic of ONE wave needs no barrier (its operations are issued in order);
 // this drains them and keeps the compiler from moving or caching accesses across the point.
@@ -508,11 +518,11 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 #ifdef TIMG_CUT_TRACE
     const long long t_kernel = wall_clock64();
 #endif
-    __shared__ CutBox box_a[kMaxColors];
+    __shared__ CutRec pool[kMaxColors];
     __shared__ uint32_t s_n, s_total, s_nboxes, s_done;
     const int f    = blockIdx.x;
     const int tid  = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: wave 0's branches are)
     const SixelFrameScratch s = FrameScratch(b, g, f);
     uint32_t *scratch = cut_lds + 2 * kCutLdsEntries + wave * kCutScratch;
 
@@ -608,47 +618,66 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     // for the low half and +step for the high half of the step-th split.  Boxes therefore never
     // move: the low half takes the parent's slot, the high half the next free one, "the first
     // box of the list with >= 2 colours" is a maximum over keys, and the list positions are
-    // only needed once, at the end, for the palette order.  Wave 0 holds keys and colour
-    // counts of all <= 256 slots in registers (slot = q * 64 + lane) for the whole kernel.
-    // Per slot one word S: 0 for a box that cannot be split (one colour), else
-    // order key << 3 | prepared << 2 | q -- the maximum over S is the box libsixel takes next,
-    // and carries along where it lives and whether its split is ready.
+    // only needed once, at the end, for the palette order.
+    // Per slot one word in s_S: 0 for a box that cannot be split (one colour), else
+    // order key << 3 | prepared << 2 | slot & 3; wave 0 reads its four slots 4 * lane + q at once.
+    //
+    // The bookkeeping of a round, by wave 0, is NOT a loop over splits (it was: 24 rounds of twelve dependent
+    // steps of ~110 instructions and an LDS round trip, 139 of the kernel's 250 us).  What libsixel does next is
+    // decided by keys alone: it splits the prepared boxes in descending key order for as long as the next one's key
+    // is above every box that is not prepared -- those of the list, and the halves made on the way, whose sums the
+    // prepared records hold and whose ties follow from the position in that order.  So: the prepared boxes (s_ready,
+    // at most 64) one per lane, ranked by all-pairs comparison, permuted into key order; the halves' keys per lane;
+    // an exclusive prefix maximum over them; the splits that happen are the leading lanes whose key is above that
+    // maximum and above the list's unprepared maximum -- and those lanes write their two halves at once.
     constexpr uint32_t kReady = 4u;
     constexpr uint32_t kNone  = 0xffffffffu;
     __shared__ uint32_t s_pick[kCutWaves];
     __shared__ uint32_t s_key[kMaxColors], s_rank[kMaxColors];
-    CutBox *pool = box_a;
+    __shared__ alignas(16) uint32_t s_S[kMaxColors];
+    __shared__ alignas(16) uint32_t s_sortkey[64 + 8];  // (read eight at a time: a tail of zeros)
+    __shared__ uint32_t s_ready[64];
     auto order_key = [](uint32_t sum, uint32_t tie /* 256 -+ step */) { return (sum << 9) | (511u - tie); };
-    auto slot_word = [&](uint32_t colors, uint32_t sum, uint32_t tie, uint32_t q) {
-        return colors >= 2u ? (order_key(sum, tie) << 3) | q : 0u;
-    };
-    uint32_t S[4] = {0, 0, 0, 0};
-    if (wave == 0 && lane == 0) S[0] = slot_word(n, s_total, 256, 0);
-    // wave 0: choose the boxes the next round prepares -- the first kCutWaves of the list that
-    // can be split and have not been prepared -- and mark them
-    auto pick = [&]() {
+    // wave 0: choose the boxes the next round prepares -- the first of the list that can be split and have not been
+    // prepared, at most one per wave and never more than the ready list holds -- mark them and append them to the list.
+    // Returns the new length of the ready list.  (No branches: twelve unrolled steps; a step that finds nothing, or
+    // stands behind the limit, picks "none" -- the picks come in descending order, so the valid ones are the first.)
+    auto pick = [&](uint32_t n_ready) -> uint32_t {
+        const uint4 sv = *reinterpret_cast<const uint4 *>(&s_S[lane * 4]);
+        uint32_t U[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) U[q] = (U[q] & kReady) ? 0u : U[q];
+        const uint32_t n_pick = min((uint32_t)kCutWaves, 64u - n_ready);
+        uint32_t picked = kNone, n_got = 0;
+#pragma unroll
         for (int w = 0; w < kCutWaves; ++w) {
-            uint32_t best = 0;
+            const uint32_t best = max(max(U[0], U[1]), max(U[2], U[3]));
+            uint32_t m          = WaveMaxU32(best);
+            m                   = (uint32_t)w < n_pick ? m : 0u;
+            const int l         = __builtin_ctzll(__ballot(best == m) | (1ull << 63));
+            const uint32_t slot = m ? (uint32_t)l * 4 + (m & 3u) : kNone;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) best = max(best, (S[q] & kReady) ? 0u : S[q]);
-            const uint32_t m = WaveMaxU32(best);
-            uint32_t slot    = kNone;
-            if (m != 0) {
-                const int l = __ffsll((long long)__ballot(best == m)) - 1;
-                slot        = (m & 3u) * 64 + (uint32_t)l;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (lane == l && (m & 3u) == (uint32_t)q) S[q] |= kReady;
-            }
-            if (lane == 0) s_pick[w] = slot;
+            for (int q = 0; q < 4; ++q) U[q] = U[q] == m ? 0u : U[q];  // (keys are distinct)
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(picked) : "s"(slot), "n"(w));  // lane w: the w-th pick
+            n_got += m ? 1u : 0u;
         }
+        if (lane < kCutWaves) s_pick[lane] = picked;
+        if ((uint32_t)lane < n_got) {
+            s_ready[n_ready + lane] = picked;
+            (void)__hip_atomic_fetch_or(&s_S[picked], kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        return n_ready + n_got;
     };
+    if (tid < kMaxColors) s_S[tid] = tid == 0 && n >= 2u ? order_key(s_total, 256) << 3 : 0u;
+    if (tid < 8) s_sortkey[64 + tid] = 0;
     if (tid == 0) {
-        pool[0]  = CutBox{0, n, s_total, 0, 0, 0, 0, 256};
-        s_nboxes = 1;
+        pool[0]  = CutRec{n << 16, 0, s_total | (256u << 16), 0};
         s_done   = 0;
     }
-    if (wave == 0) pick();
+    __threadfence_block();
+    __syncthreads();
+    uint32_t nb = 1, n_ready = 0;  // (wave 0's: boxes of the list, prepared boxes not yet split)
+    if (wave == 0) n_ready = pick(0);
     __threadfence_block();
     __syncthreads();
 
@@ -665,13 +694,10 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         {
             const uint32_t slot = s_pick[wave];
             if (slot != kNone) {
-                const CutBox box = pool[slot];
+                const CutBox box = BoxOf(pool[slot]);
                 uint32_t median, lowersum;
                 SplitBox(box, tab, scratch, lane, &median, &lowersum);
-                if (lane == 0) {
-                    pool[slot].median   = median;
-                    pool[slot].lowersum = lowersum;
-                }
+                if (lane == 0) pool[slot].w2 = median | (lowersum << 16);
             }
         }
         __threadfence_block();
@@ -684,48 +710,68 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             ++n_rounds;
         }
 #endif
-        // ---- replay of the serial bookkeeping (wave 0), for as long as the box libsixel would
-        // take next has been prepared
+        // ---- libsixel's serial bookkeeping for every prepared box it would take next (wave 0)
         if (wave == 0) {
-            uint32_t nb = s_nboxes, done = 0;
-            while (nb < (uint32_t)kMaxColors) {
-                const uint32_t best = max(max(S[0], S[1]), max(S[2], S[3]));
-                const uint32_t m    = WaveMaxU32(best);
-                if (m == 0) {  // no box with two colours left
-                    done = 1;
-                    break;
-                }
-                if (!(m & kReady)) break;  // not prepared: next round
-                const int l       = __ffsll((long long)__ballot(best == m)) - 1;
-                const uint32_t qq = m & 3u, slot = qq * 64 + (uint32_t)l;
-                // (the whole record in ONE round trip: left to itself the compiler fetched ind and buf a second time
-                // inside lane 0's branch below -- a second dependent LDS latency in every step of this serial chain)
-                uint4 rec0 = reinterpret_cast<const uint4 *>(&pool[slot])[0];
-                uint4 rec1 = reinterpret_cast<const uint4 *>(&pool[slot])[1];
-                asm volatile("" : "+v"(rec0.x), "+v"(rec0.y), "+v"(rec0.z), "+v"(rec0.w), "+v"(rec1.x), "+v"(rec1.y));
-                const CutBox box{rec0.x, rec0.y, rec0.z, rec0.w, rec1.x, rec1.y, 0, 0};
-                const uint32_t median = box.median, lowersum = box.lowersum;
-                // the low half takes the parent's slot, the high half the next free one
-                const CutBox lo{box.ind, median, lowersum, box.buf ^ 1u, 0, 0, 0, 256 - nb};
-                const CutBox hi{box.ind + median, box.colors - median, box.sum - lowersum, box.buf ^ 1u,
-                                0, 0, 0, 256 + nb};
-                if (lane == 0) {
-                    pool[slot] = lo;
-                    pool[nb]   = hi;
-                }
-                const uint32_t hq = nb >> 6;
-                const int hl      = (int)(nb & 63u);
-                const uint32_t s_lo = slot_word(lo.colors, lo.sum, lo.pad, qq);
-                const uint32_t s_hi = slot_word(hi.colors, hi.sum, hi.pad, hq);
+            const uint4 sv      = *reinterpret_cast<const uint4 *>(&s_S[lane * 4]);
+            const bool item     = (uint32_t)lane < n_ready;
+            const uint32_t slot = item ? s_ready[lane] : 0u;
+            // the list's largest key that is not prepared
+            uint32_t u0;
+            {
+                const uint32_t S[4] = {sv.x, sv.y, sv.z, sv.w};
+                uint32_t u          = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (lane == l && qq == (uint32_t)q) S[q] = s_lo;
-                    if (lane == hl && hq == (uint32_t)q) S[q] = s_hi;
-                }
-                ++nb;
+                for (int q = 0; q < 4; ++q) u = max(u, (S[q] & kReady) ? 0u : S[q]);
+                u0 = WaveMaxU32(u) >> 3;
             }
-            if (nb >= (uint32_t)kMaxColors) done = 1;
-            if (!done) pick();
+            const uint32_t key = item ? s_S[slot] >> 3 : 0u;
+            const uint2 rec    = *reinterpret_cast<const uint2 *>(&pool[slot]);  // w0, w2
+            s_sortkey[lane]    = key;
+            TIMG_WAVE_SYNC();
+            uint32_t rank = 0;  // prepared boxes with a larger key (keys are distinct; lanes without a box: all of them)
+            for (uint32_t j = 0; j < n_ready; j += 8) {
+                const uint4 k0 = *reinterpret_cast<const uint4 *>(&s_sortkey[j]);
+                const uint4 k1 = *reinterpret_cast<const uint4 *>(&s_sortkey[j + 4]);
+                rank += (k0.x > key ? 1u : 0u) + (k0.y > key ? 1u : 0u) + (k0.z > key ? 1u : 0u) + (k0.w > key ? 1u : 0u);
+                rank += (k1.x > key ? 1u : 0u) + (k1.y > key ? 1u : 0u) + (k1.z > key ? 1u : 0u) + (k1.w > key ? 1u : 0u);
+            }
+            // lane i takes the box of rank i (ds_permute: lane -> lane; the lanes without a box all aim at lane n_ready)
+            const int to         = (int)(rank << 2);
+            const uint32_t k_s   = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)key);
+            const uint32_t sl_s  = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)slot);
+            const uint32_t w0    = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)rec.x);
+            const uint32_t w2    = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)rec.y);
+            const uint32_t nb_i  = nb + (uint32_t)lane;                 // boxes in the list when this split happens
+            const uint32_t head  = (w0 ^ 0x8000u) & 0xffffu;            // ind | the other table half << 15
+            const uint32_t med   = w2 & 0xffffu, lower = w2 >> 16;
+            const uint32_t c_hi  = (w0 >> 16) - med, s_hi = (k_s >> 9) - lower;
+            // keys of the halves: tie = 256 - nb_i (low), 256 + nb_i (high)
+            const uint32_t k_lo  = med >= 2u ? (lower << 9) | (255u + nb_i) : 0u;
+            const uint32_t k_hi  = c_hi >= 2u ? (s_hi << 9) | (255u - nb_i) : 0u;
+            const uint32_t above = WaveExclusiveMaxU32(item ? max(k_lo, k_hi) : 0u);  // halves made in front of this lane
+            const bool valid     = item && k_s > u0 && k_s > above && nb_i < (uint32_t)kMaxColors;
+            const unsigned long long stop = ~__ballot(valid);
+            const uint32_t n_split        = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+            if ((uint32_t)lane < n_split) {
+                *reinterpret_cast<uint4 *>(&pool[sl_s]) =
+                    make_uint4(head | (med << 16), 0u, lower | ((256u - nb_i) << 16), 0u);
+                *reinterpret_cast<uint4 *>(&pool[nb_i]) =
+                    make_uint4((head + med) | (c_hi << 16), 0u, s_hi | ((256u + nb_i) << 16), 0u);
+                s_S[sl_s] = k_lo ? (k_lo << 3) | (sl_s & 3u) : 0u;
+                s_S[nb_i] = k_hi ? (k_hi << 3) | (nb_i & 3u) : 0u;
+            } else if (item) {
+                s_ready[(uint32_t)lane - n_split] = sl_s;  // still prepared, still in key order
+            }
+            nb += n_split;
+            n_ready -= n_split;
+            TIMG_WAVE_SYNC();
+            uint32_t done = nb >= (uint32_t)kMaxColors ? 1u : 0u;
+            if (!done) {
+                n_ready = pick(n_ready);
+                // no box with two colours left; (a round splits at least the box picked first -- it was the largest
+                // unprepared one: a round without a split cannot happen, and must not become a hang if it does)
+                done = n_ready == 0 || n_split == 0 ? 1u : 0u;
+            }
             if (lane == 0) {
                 s_nboxes = nb;
                 s_done   = done;
@@ -751,7 +797,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     const uint32_t nboxes = s_nboxes;
     // list position of every box: the number of boxes with a larger key
     if (tid < kMaxColors) {
-        s_key[tid]  = (uint32_t)tid < nboxes ? order_key(pool[tid].sum, pool[tid].pad) : 0u;
+        s_key[tid]  = (uint32_t)tid < nboxes ? order_key(pool[tid].w1 & 0xffffu, pool[tid].w1 >> 16) : 0u;
         s_rank[tid] = 0;
     }
     __syncthreads();
@@ -767,7 +813,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     __syncthreads();
     // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
     for (uint32_t bi = tid; bi < nboxes; bi += blockDim.x) {
-        const CutBox box    = pool[bi];
+        const CutBox box    = BoxOf(pool[bi]);
         const uint32_t at   = s_rank[bi];
         const uint32_t *src = tab[box.buf] + box.ind;
         uint32_t sum[3]     = {0, 0, 0};

@@ -49,6 +49,17 @@ __device__ __forceinline__ uint32_t WaveMaxU32(uint32_t v) {
     return ReadLane(v, 63);
 }
 
+// exclusive prefix maximum over the 64 lanes (lane 0: 0)
+__device__ __forceinline__ uint32_t WaveExclusiveMaxU32(uint32_t v) {
+    v = max(v, TIMG_DPP0(v, 0x111, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x112, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x114, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x118, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x142, 0xa));
+    v = max(v, TIMG_DPP0(v, 0x143, 0xc));
+    return TIMG_DPP0(v, 0x138, 0xf);  // wave_shr:1
+}
+
 // bitwise OR over the wave, as a scalar
 __device__ __forceinline__ uint32_t WaveOr(uint32_t v) {
     v |= TIMG_DPP0(v, 0x111, 0xf);

@@ -227,6 +227,10 @@ __global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBat
 #define TIMG_CUT_WAVES 12
 #endif
 constexpr int kCutWaves      = TIMG_CUT_WAVES;
+#ifndef TIMG_CUT_PICK_LANES
+#define TIMG_CUT_PICK_LANES 40
+#endif
+constexpr int kCutPickLanes  = TIMG_CUT_PICK_LANES;  // lane maxima a round's picks start from (see pick() in the kernel)
 constexpr int kCutLdsEntries = 12288;             // colour table kept in LDS up to this size
 // words of per-wave scratch: [64][33] 16-bit counters (a lane's segment of a box and every
 // exclusive prefix stay below 65536: a box has at most 32768 colours) plus 32 + 32 key totals /
@@ -262,8 +266,15 @@ __device__ __forceinline__ CutBox BoxOf(const CutRec &r) {
 // Prepares the split of `box` by one wave: sorts its colours (stable, by the plane
 // with the largest luminosity-weighted spread) into the other table half and finds
 // the median.  scratch: kCutScratch words owned by this wave.
+// kLds: the colour table lives in LDS (up to kCutLdsEntries colours: every frame of a photograph).  Which of the two
+// it is is decided once per frame, but a pointer that may be either is a FLAT pointer: every load of a colour went
+// down the vector-memory path to find out it was LDS (flat_load_dword, s_waitcnt vmcnt(0) lgkmcnt(0)) -- several times
+// the latency of a ds_read in loops that are chains of such loads.  Typed per case, the table is read with ds_read.
+typedef __attribute__((address_space(3))) uint32_t CutLdsWord;
+template <bool kLds>
 __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *scratch, int lane,
                          uint32_t *median_out, uint32_t *lowersum_out) {
+    typedef typename std::conditional<kLds, CutLdsWord, uint32_t>::type Word;
     // large path: lane l counts its segment's keys in row l -- 32 sixteen-bit counters packed into 16 words, rows 17
     // words apart (an odd stride: the lanes' rows start on different banks); the spare 17th word of row k holds the
     // base of key k in the sorted box
@@ -272,22 +283,29 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
     auto key_base  = [&](uint32_t k) -> uint32_t & { return scratch[k * 17 + 16]; };
     uint32_t *perm        = scratch;  // [256]: the medium path's permutation buffer (never together with lane_cnt)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t *src = tab[box.buf] + box.ind;
-    uint32_t *dst       = tab[box.buf ^ 1u] + box.ind;
+    const Word *src     = (const Word *)tab[box.buf] + box.ind;
+    Word *dst           = (Word *)tab[box.buf ^ 1u] + box.ind;
     const uint32_t half = box.sum / 2;
     uint32_t median, lowersum;
 
     // per-plane extent of the box (5-bit keys): which key values occur, OR-ed over the wave
     uint32_t seen[3] = {0, 0, 0};
-    // (eight loads in flight: one load per iteration makes a box of thousands of colours a chain of LDS round trips)
-    for (uint32_t i = lane; i < box.colors; i += 8 * 64) {
-        uint32_t e[8];
+    uint32_t e_own   = 0;  // (small box: the lane's colour, the last one again past the end)
+    if (box.colors <= 64) {
+        e_own = src[min((uint32_t)lane, box.colors - 1)];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = src[min(i + q * 64, box.colors - 1)];  // (past the end: the last colour again)
+        for (int p = 0; p < 3; ++p) seen[p] = 1u << PlaneKey(e_own, p);
+    } else {
+        // (eight loads in flight: one load per iteration makes a box of thousands of colours a chain of LDS round trips)
+        for (uint32_t i = lane; i < box.colors; i += 8 * 64) {
+            uint32_t e[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < 8; ++q) e[q] = src[min(i + q * 64, box.colors - 1)];  // (past the end: the last colour again)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) seen[p] |= 1u << PlaneKey(e[q], p);
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) seen[p] |= 1u << PlaneKey(e[q], p);
+        }
     }
     uint32_t mn[3], mx[3];
 #pragma unroll
@@ -296,29 +314,41 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         mn[p] = (uint32_t)__ffs((int)m) - 1u;
         mx[p] = 31u - (uint32_t)__clz((int)m);
     }
-    // SIXEL_LARGE_LUM: plane with the largest luminosity-weighted spread
+    // SIXEL_LARGE_LUM: plane with the largest luminosity-weighted spread, first of equals.  libsixel compares
+    // lum[p] * ((max - min) << 3) in double with lum = 0.2989, 0.5866, 0.1145; the ranges are multiples of 8 below 256
+    // and no two of 2989 i, 5866 j, 1145 k (0 < i, j, k < 32) are equal (gcd(2989, 5866) = 7 and 427 does not divide
+    // j < 32; 1145 is coprime to both), so products that differ differ by >= 8e-4 -- thirteen orders of magnitude
+    // above the rounding of a double: the integer comparison decides exactly as the double one does.
     int plane = 0;
+    uint32_t key_lo = mn[0], key_span = mx[0] - mn[0];  // the chosen plane's smallest key, and largest minus smallest
     {
-        const double lum[3] = {0.2989, 0.5866, 0.1145};
-        double best         = 0.0;
+        const uint32_t lum[3] = {2989u, 5866u, 1145u};
+        uint32_t best         = 0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const double spread = lum[p] * (double)((mx[p] - mn[p]) << 3);
+            const uint32_t spread = lum[p] * (mx[p] - mn[p]);
             if (spread > best) {
-                plane = p;
-                best  = spread;
+                plane    = p;
+                best     = spread;
+                key_lo   = mn[p];
+                key_span = mx[p] - mn[p];
             }
         }
     }
+    // The radix sorts below sort by key - key_lo, which has only as many bits as key_span: the boxes of the late rounds
+    // span a few key values in their widest plane, two or three passes instead of five.
+    const int key_bits         = 32 - __clz((int)key_span);  // (0 when all keys are equal: nothing to sort)
+    const uint32_t key_of_dead = (1u << key_bits) - 1u;
 
     if (box.colors <= 64) {
         // ---- small box: stable LSD radix sort on the key, in registers -----
         const bool live = (uint32_t)lane < box.colors;
-        uint32_t e      = live ? src[lane] : 0xffffffffu;
+        uint32_t e      = live ? e_own : 0xffffffffu;
 #pragma unroll
         for (int bit = 0; bit < 5; ++bit) {
+            if (bit >= key_bits) break;
             // dead lanes stand behind the live ones and carry the largest key: stable passes keep them there
-            const uint32_t key = e == 0xffffffffu ? 31u : PlaneKey(e, plane);
+            const uint32_t key = e == 0xffffffffu ? key_of_dead : PlaneKey(e, plane) - key_lo;
             const bool one     = (key >> bit) & 1u;
             const unsigned long long ones = __ballot(one);
             const int n_zero   = 64 - __popcll(ones);
@@ -346,11 +376,12 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
         }
 #pragma unroll
         for (int bit = 0; bit < 5; ++bit) {
+            if (bit >= key_bits) break;
             bool one[4];
             uint32_t nz = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t key = e[r] == 0xffffffffu ? 31u : PlaneKey(e[r], plane);
+                const uint32_t key = e[r] == 0xffffffffu ? key_of_dead : PlaneKey(e[r], plane) - key_lo;
                 one[r]             = (key >> bit) & 1u;
                 nz += one[r] ? 0u : 1u;
             }
@@ -419,11 +450,10 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
 #pragma unroll
             for (int q = 0; q < 4; ++q) e[q] = src[min(i + q, z - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) {  // (an entry past the segment adds 0: no branches)
                 const uint32_t k = PlaneKey(e[q], plane);
-                if (i + q < z)
-                    (void)__hip_atomic_fetch_add(&mine_w[k >> 1], 1u << ((k & 1u) * 16), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+                (void)__hip_atomic_fetch_add(&mine_w[k >> 1], i + q < z ? 1u << ((k & 1u) * 16) : 0u, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         TIMG_WAVE_SYNC();
@@ -513,6 +543,18 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
     *lowersum_out = lowersum;
 }
 
+// channel sums (as 8-bit values) of a box's colours, for its palette entry
+template <class Word>
+__device__ __forceinline__ void BoxColourSums(const Word *src, uint32_t colors, uint32_t sum[3]) {
+    sum[0] = sum[1] = sum[2] = 0;
+    for (uint32_t i = 0; i < colors; ++i) {
+        const uint32_t e = src[i];
+        sum[0] += ((e >> 10) & 0x1f) << 3;
+        sum[1] += ((e >> 5) & 0x1f) << 3;
+        sum[2] += (e & 0x1f) << 3;
+    }
+}
+
 __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, SixelBatch b) {
     extern __shared__ uint32_t cut_lds[];
 #ifdef TIMG_CUT_TRACE
@@ -535,24 +577,19 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         const uint32_t chunks = (g.n_samples + 63) / 64;
         const uint32_t per    = (chunks + kCutWaves - 1) / kCutWaves;
         const uint32_t c0 = min(chunks, (uint32_t)wave * per), c1 = min(chunks, c0 + per);
-        // (8 chunks at a time, their loads in flight together and unconditional: one load per
-        // iteration makes the loop a chain of memory round trips)
-        auto load8 = [&](uint32_t c, uint32_t e[8]) {
-            uint32_t v[8];
+        // (every chunk of the wave is loaded ONCE, all loads in flight together, and kept in registers for the second
+        // pass: two passes of eight loads at a time were twelve global round trips, 5 of the kernel's 130 us)
+        constexpr int kPer = (kHistPerThread * kHistThreads / 64 + kCutWaves - 1) / kCutWaves;  // chunks a wave
+        uint32_t e[kPer];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = s.entries[min((c + j) * 64 + lane, g.n_samples - 1)];
+        for (int j = 0; j < kPer; ++j) e[j] = s.entries[min((c0 + j) * 64 + lane, g.n_samples - 1)];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = c + j < c1 && (c + j) * 64 + lane < g.n_samples ? v[j] : 0u;
-        };
+        for (int j = 0; j < kPer; ++j) e[j] = c0 + j < c1 && (c0 + j) * 64 + lane < g.n_samples ? e[j] : 0u;
         uint32_t cnt = 0, sum = 0;
-        for (uint32_t c = c0; c < c1; c += 8) {
-            uint32_t e[8];
-            load8(c, e);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                cnt += (uint32_t)__popcll(__ballot(e[j] != 0));
-                sum += e[j] >> 15;
-            }
+        for (int j = 0; j < kPer; ++j) {
+            cnt += (uint32_t)__popcll(__ballot(e[j] != 0));
+            sum += e[j] >> 15;
         }
         sum = WaveSum(sum);
         if (lane == 0) {
@@ -568,16 +605,18 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         }
         // straight into the LDS table when the colours fit there (and are not few enough to skip
         // the median cut altogether)
-        uint32_t *table = n_all > (uint32_t)kMaxColors && n_all <= (uint32_t)kCutLdsEntries ? cut_lds : s.tab_a;
-        for (uint32_t c = c0; c < c1; c += 8) {
-            uint32_t e[8];
-            load8(c, e);
+        const bool to_lds = n_all > (uint32_t)kMaxColors && n_all <= (uint32_t)kCutLdsEntries;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned long long m = __ballot(e[j] != 0);
-                if (e[j]) table[at + (uint32_t)__popcll(m & lt_mask)] = e[j];
-                at += (uint32_t)__popcll(m);
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned long long m = __ballot(e[j] != 0);
+            const uint32_t to          = at + (uint32_t)__popcll(m & lt_mask);
+            if (e[j]) {
+                if (to_lds)
+                    cut_lds[to] = e[j];
+                else
+                    s.tab_a[to] = e[j];
             }
+            at += (uint32_t)__popcll(m);
         }
         if (tid == 0) {
             s_n     = n_all;
@@ -603,7 +642,8 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         return;
     }
     uint32_t *tab[2];
-    if (n <= (uint32_t)kCutLdsEntries) {
+    const bool in_lds = n <= (uint32_t)kCutLdsEntries;
+    if (in_lds) {
         tab[0] = cut_lds;  // (filled by the compaction above)
         tab[1] = cut_lds + kCutLdsEntries;
     } else {
@@ -620,7 +660,8 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     // box of the list with >= 2 colours" is a maximum over keys, and the list positions are
     // only needed once, at the end, for the palette order.
     // Per slot one word in s_S: 0 for a box that cannot be split (one colour), else
-    // order key << 3 | prepared << 2 | slot & 3; wave 0 reads its four slots 4 * lane + q at once.
+    // order key << 3 | prepared << 2 | slot >> 6; the word of slot q * 64 + lane is s_S[lane * 4 + q]: wave 0 reads its
+    // four slots at once, and boxes made one after the other stand in different lanes.
     //
     // The bookkeeping of a round, by wave 0, is NOT a loop over splits (it was: 24 rounds of twelve dependent
     // steps of ~110 instructions and an LDS round trip, 139 of the kernel's 250 us).  What libsixel does next is
@@ -631,43 +672,66 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     // an exclusive prefix maximum over them; the splits that happen are the leading lanes whose key is above that
     // maximum and above the list's unprepared maximum -- and those lanes write their two halves at once.
     constexpr uint32_t kReady = 4u;
-    constexpr uint32_t kNone  = 0xffffffffu;
-    __shared__ uint32_t s_pick[kCutWaves];
-    __shared__ uint32_t s_key[kMaxColors], s_rank[kMaxColors];
+    __shared__ uint32_t s_pick[64], s_npick;
+    __shared__ alignas(16) uint32_t s_key[kMaxColors];
+    __shared__ uint32_t s_rank[kMaxColors];
     __shared__ alignas(16) uint32_t s_S[kMaxColors];
     __shared__ alignas(16) uint32_t s_sortkey[64 + 8];  // (read eight at a time: a tail of zeros)
-    __shared__ uint32_t s_ready[64];
+    __shared__ uint32_t s_ready[64 + 4];
     auto order_key = [](uint32_t sum, uint32_t tie /* 256 -+ step */) { return (sum << 9) | (511u - tie); };
-    // wave 0: choose the boxes the next round prepares -- the first of the list that can be split and have not been
-    // prepared, at most one per wave and never more than the ready list holds -- mark them and append them to the list.
-    // Returns the new length of the ready list.  (No branches: twelve unrolled steps; a step that finds nothing, or
-    // stands behind the limit, picks "none" -- the picks come in descending order, so the valid ones are the first.)
-    auto pick = [&](uint32_t n_ready) -> uint32_t {
+    // wave 0: choose the boxes the next round prepares -- the first boxes of the list that can be split and have not
+    // been prepared, as many as the ready list still holds -- mark them and append them to the list; returns its new
+    // length.  Not a loop of wave maxima (34 instructions a pick): every lane's largest unprepared word is ranked
+    // among the 64 of them (all-pairs, broadcast reads), the word of rank P - 1 is a threshold, and EVERY unprepared
+    // box at or above it is picked -- the lane maxima of rank < P and whatever stands behind them in their lanes:
+    // exactly the first boxes of the list, whatever their number (<= 4 P).
+    uint32_t nb = 1, n_ready = 0;  // (wave 0's: boxes of the list, prepared boxes not yet split)
+    auto pick = [&]() {
         const uint4 sv = *reinterpret_cast<const uint4 *>(&s_S[lane * 4]);
         uint32_t U[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) U[q] = (U[q] & kReady) ? 0u : U[q];
-        const uint32_t n_pick = min((uint32_t)kCutWaves, 64u - n_ready);
-        uint32_t picked = kNone, n_got = 0;
+        const uint32_t best = max(max(U[0], U[1]), max(U[2], U[3]));
+        s_sortkey[lane]     = best;
+        TIMG_WAVE_SYNC();
+        uint32_t rank = 0;
 #pragma unroll
-        for (int w = 0; w < kCutWaves; ++w) {
-            const uint32_t best = max(max(U[0], U[1]), max(U[2], U[3]));
-            uint32_t m          = WaveMaxU32(best);
-            m                   = (uint32_t)w < n_pick ? m : 0u;
-            const int l         = __builtin_ctzll(__ballot(best == m) | (1ull << 63));
-            const uint32_t slot = m ? (uint32_t)l * 4 + (m & 3u) : kNone;
+        for (int j = 0; j < 64; j += 4) {
+            const uint4 k = *reinterpret_cast<const uint4 *>(&s_sortkey[j]);
+            rank += (k.x > best ? 1u : 0u) + (k.y > best ? 1u : 0u) + (k.z > best ? 1u : 0u) + (k.w > best ? 1u : 0u);
+        }
+        const uint32_t room = 64u - n_ready;  // (>= 1: a round splits at least one box)
+        // boxes at or above the lane maximum of rank P - 1 (every box that can be split, if there are fewer maxima)
+        uint32_t c = 0, total = 0, thr = 0;
+        auto at_or_above = [&](uint32_t P) {
+            const unsigned long long hit = __ballot(best != 0 && rank == P - 1u);
+            thr   = hit ? ReadLane(best, __builtin_ctzll(hit)) : 1u;
+            c     = 0;
+            total = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) U[q] = U[q] == m ? 0u : U[q];  // (keys are distinct)
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(picked) : "s"(slot), "n"(w));  // lane w: the w-th pick
-            n_got += m ? 1u : 0u;
-        }
-        if (lane < kCutWaves) s_pick[lane] = picked;
-        if ((uint32_t)lane < n_got) {
-            s_ready[n_ready + lane] = picked;
-            (void)__hip_atomic_fetch_or(&s_S[picked], kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-        return n_ready + n_got;
+            for (int q = 0; q < 4; ++q) {
+                c += U[q] >= thr ? 1u : 0u;
+                total += (uint32_t)__popcll(__ballot(U[q] >= thr));
+            }
+        };
+        // (never more than the splits that remain to be made: what is prepared beyond them is thrown away)
+        at_or_above(max(1u, min(min((uint32_t)kCutPickLanes, room), (uint32_t)kMaxColors - nb - min(n_ready, (uint32_t)kMaxColors - nb))));
+        if (total > room) at_or_above(max(1u, room / 4u));  // (<= 4 boxes a lane: this one fits)
+        const uint32_t incl = WaveInclusiveAdd(c);
+        uint32_t at         = incl - c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (U[q] >= thr) {
+                const uint32_t slot = (uint32_t)q * 64u + (uint32_t)lane;
+                s_pick[at]          = slot;
+                s_ready[n_ready + at] = slot;
+                s_S[lane * 4 + q]   = U[q] | kReady;
+                ++at;
+            }
+        if (lane == 0) s_npick = total;
+        n_ready += total;
     };
+    auto s_index = [](uint32_t slot) { return (slot & 63u) * 4u + (slot >> 6); };
     if (tid < kMaxColors) s_S[tid] = tid == 0 && n >= 2u ? order_key(s_total, 256) << 3 : 0u;
     if (tid < 8) s_sortkey[64 + tid] = 0;
     if (tid == 0) {
@@ -676,38 +740,43 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     }
     __threadfence_block();
     __syncthreads();
-    uint32_t nb = 1, n_ready = 0;  // (wave 0's: boxes of the list, prepared boxes not yet split)
-    if (wave == 0) n_ready = pick(0);
+    if (wave == 0) pick();
     __threadfence_block();
     __syncthreads();
 
 #ifdef TIMG_CUT_TRACE
-    long long t_mark = wall_clock64(), t_split = 0, t_replay = 0;
+    // (kept in LDS and printed once at the end: a printf inside the loop costs more than a round)
+    __shared__ long long s_tr_split[64], s_tr_book[64];
+    __shared__ uint32_t s_tr_nb[64], s_tr_np[64];
+    long long t_mark = wall_clock64();
+    const long long t_setup = t_mark - t_kernel;
     int n_rounds = 0;
-    if (tid == 0 && f == 0) printf("cut: n=%u setup %lld ticks\n", n, wall_clock64() - t_kernel);
 #endif
     for (;;) {
 #ifdef TIMG_CUT_TRACE
         t_mark = wall_clock64();
 #endif
-        // ---- speculative splits: wave w prepares the w-th picked box
-        {
-            const uint32_t slot = s_pick[wave];
-            if (slot != kNone) {
-                const CutBox box = BoxOf(pool[slot]);
-                uint32_t median, lowersum;
-                SplitBox(box, tab, scratch, lane, &median, &lowersum);
-                if (lane == 0) pool[slot].w2 = median | (lowersum << 16);
-            }
+        // ---- speculative splits: wave w prepares the picked boxes w, w + 12, ...
+        for (uint32_t p = (uint32_t)wave, np = s_npick; p < np; p += kCutWaves) {
+            const uint32_t slot = s_pick[p];
+            const CutBox box    = BoxOf(pool[slot]);
+            uint32_t median, lowersum;
+            if (in_lds)
+                SplitBox<true>(box, tab, scratch, lane, &median, &lowersum);
+            else
+                SplitBox<false>(box, tab, scratch, lane, &median, &lowersum);
+            if (lane == 0) pool[slot].w2 = median | (lowersum << 16);
         }
         __threadfence_block();
         __syncthreads();
 #ifdef TIMG_CUT_TRACE
         {
             const long long now = wall_clock64();
-            t_split += now - t_mark;
+            if (tid == 0 && n_rounds < 64) {
+                s_tr_split[n_rounds] = now - t_mark;
+                s_tr_np[n_rounds]    = s_npick;
+            }
             t_mark = now;
-            ++n_rounds;
         }
 #endif
         // ---- libsixel's serial bookkeeping for every prepared box it would take next (wave 0)
@@ -724,7 +793,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
                 for (int q = 0; q < 4; ++q) u = max(u, (S[q] & kReady) ? 0u : S[q]);
                 u0 = WaveMaxU32(u) >> 3;
             }
-            const uint32_t key = item ? s_S[slot] >> 3 : 0u;
+            const uint32_t key = item ? s_S[s_index(slot)] >> 3 : 0u;
             const uint2 rec    = *reinterpret_cast<const uint2 *>(&pool[slot]);  // w0, w2
             s_sortkey[lane]    = key;
             TIMG_WAVE_SYNC();
@@ -757,8 +826,8 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
                     make_uint4(head | (med << 16), 0u, lower | ((256u - nb_i) << 16), 0u);
                 *reinterpret_cast<uint4 *>(&pool[nb_i]) =
                     make_uint4((head + med) | (c_hi << 16), 0u, s_hi | ((256u + nb_i) << 16), 0u);
-                s_S[sl_s] = k_lo ? (k_lo << 3) | (sl_s & 3u) : 0u;
-                s_S[nb_i] = k_hi ? (k_hi << 3) | (nb_i & 3u) : 0u;
+                s_S[s_index(sl_s)] = k_lo ? (k_lo << 3) | (sl_s >> 6) : 0u;
+                s_S[s_index(nb_i)] = k_hi ? (k_hi << 3) | (nb_i >> 6) : 0u;
             } else if (item) {
                 s_ready[(uint32_t)lane - n_split] = sl_s;  // still prepared, still in key order
             }
@@ -767,7 +836,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             TIMG_WAVE_SYNC();
             uint32_t done = nb >= (uint32_t)kMaxColors ? 1u : 0u;
             if (!done) {
-                n_ready = pick(n_ready);
+                pick();
                 // no box with two colours left; (a round splits at least the box picked first -- it was the largest
                 // unprepared one: a round without a split cannot happen, and must not become a hang if it does)
                 done = n_ready == 0 || n_split == 0 ? 1u : 0u;
@@ -780,19 +849,16 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
         __threadfence_block();
         __syncthreads();
 #ifdef TIMG_CUT_TRACE
-        {
-            const long long d_replay = wall_clock64() - t_mark;
-            t_replay += d_replay;
-            if (tid == 0 && f == 0)
-                printf("cut: round %d nboxes ->%u split-so-far %lld this-replay %lld (100MHz ticks)\n", n_rounds,
-                       s_nboxes, t_split, d_replay);
+        if (tid == 0 && n_rounds < 64) {
+            s_tr_book[n_rounds] = wall_clock64() - t_mark;
+            s_tr_nb[n_rounds]   = s_nboxes;
         }
+        ++n_rounds;
 #endif
         if (s_done) break;
     }
 #ifdef TIMG_CUT_TRACE
-    if (tid == 0 && f == 0)
-        printf("cut: rounds %d split %lld replay %lld ticks(100MHz)\n", n_rounds, t_split, t_replay);
+    const long long t_loop_end = wall_clock64();
 #endif
     const uint32_t nboxes = s_nboxes;
     // list position of every box: the number of boxes with a larger key
@@ -802,27 +868,34 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     }
     __syncthreads();
     {
-        const uint32_t box = tid & (kMaxColors - 1), part = tid / kMaxColors, parts = blockDim.x / kMaxColors;
+        // (keys read four at a time, the reads independent of each other: one key per dependent iteration cost 5 us)
+        const uint32_t box = tid & (kMaxColors - 1), part = tid / kMaxColors;
+        static_assert(kCutWaves * 64 / kMaxColors == 3 && kMaxColors == 256, "three parts: 88 + 88 + 80 keys");
+        const uint32_t j0 = part * 88u, j1 = min((uint32_t)kMaxColors, j0 + 88u);
         if (box < nboxes) {
             const uint32_t mine = s_key[box];
             uint32_t r = 0;
-            for (uint32_t j = part; j < nboxes; j += parts) r += s_key[j] > mine ? 1u : 0u;
+#pragma unroll 22
+            for (uint32_t j = j0; j < j1; j += 4) {
+                const uint4 k = *reinterpret_cast<const uint4 *>(&s_key[j]);  // (0 behind the last box: never larger)
+                r += (k.x > mine ? 1u : 0u) + (k.y > mine ? 1u : 0u) + (k.z > mine ? 1u : 0u) + (k.w > mine ? 1u : 0u);
+            }
             atomicAdd(&s_rank[box], r);
         }
     }
     __syncthreads();
+#ifdef TIMG_CUT_TRACE
+    const long long t_rank_end = wall_clock64();
+#endif
     // SIXEL_REP_AVERAGE_COLORS: unweighted mean of the box's colours
     for (uint32_t bi = tid; bi < nboxes; bi += blockDim.x) {
-        const CutBox box    = BoxOf(pool[bi]);
-        const uint32_t at   = s_rank[bi];
-        const uint32_t *src = tab[box.buf] + box.ind;
-        uint32_t sum[3]     = {0, 0, 0};
-        for (uint32_t i = 0; i < box.colors; ++i) {
-            const uint32_t e = src[i];
-            sum[0] += ((e >> 10) & 0x1f) << 3;
-            sum[1] += ((e >> 5) & 0x1f) << 3;
-            sum[2] += (e & 0x1f) << 3;
-        }
+        const CutBox box  = BoxOf(pool[bi]);
+        const uint32_t at = s_rank[bi];
+        uint32_t sum[3];
+        if (in_lds)
+            BoxColourSums((const CutLdsWord *)tab[box.buf] + box.ind, box.colors, sum);
+        else
+            BoxColourSums(tab[box.buf] + box.ind, box.colors, sum);
         s.palette[at * 3 + 0] = (uint8_t)(sum[0] / box.colors);
         s.palette[at * 3 + 1] = (uint8_t)(sum[1] / box.colors);
         s.palette[at * 3 + 2] = (uint8_t)(sum[2] / box.colors);
@@ -833,7 +906,18 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     }
 #ifdef TIMG_CUT_TRACE
     __syncthreads();
-    if (tid == 0 && f == 0) printf("cut: total %lld ticks\n", wall_clock64() - t_kernel);
+    if (tid == 0 && (f == 0 || f == 5)) {
+        const long long t_end = wall_clock64();
+        long long sp = 0, bk = 0;
+        for (int r = 0; r < n_rounds && r < 64; ++r) {
+            printf("cut: f%d round %d picks %u split %lld book %lld -> %u boxes\n", f, r + 1, s_tr_np[r], s_tr_split[r],
+                   s_tr_book[r], s_tr_nb[r]);
+            sp += s_tr_split[r];
+            bk += s_tr_book[r];
+        }
+        printf("cut: f%d n=%u setup %lld rounds %d split %lld book %lld rank %lld palette %lld total %lld (100 MHz ticks)\n", f,
+               n, t_setup, n_rounds, sp, bk, t_rank_end - t_loop_end, t_end - t_rank_end, t_end - t_kernel);
+    }
 #endif
 }
 

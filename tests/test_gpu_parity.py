@@ -362,6 +362,25 @@ def test_sixel_both_lookup_forms(hip, oracle, monkeypatch, kind, w, h, parts, tr
                              f"{got[max(0, n - 20):n + 20]!r} vs {want[max(0, n - 20):n + 20]!r}")
 
 
+@pytest.mark.parametrize("kind,w,h,parts", [
+    ("photo", 800, 450, -1), ("noise", 800, 450, 1), ("alpha", 320, 203, -1), ("photo", 100, 56, -1), ("noise", 34, 6, -1),
+    ("photo", 4, 130, -1), ("photo", 802, 64, -1), ("photo", 64, 1100, 3), ("noise", 1000, 500, -1),
+])
+def test_sixel_pixel_pairs_equal_single_pixels(hip, oracle, monkeypatch, kind, w, h, parts):
+    """DitherKernel<., ., true, kPix2>: frames of even width request their pixels two at a time (one 8-byte load
+    every second step); TIMG_HIP_DITHER_PIX=1 keeps the one-pixel requests.  Same bytes, the oracle's, in both -- and a
+    frame whose rows are only 4-byte aligned (a view into a wider image) takes the one-pixel form by itself."""
+    if parts >= 0:
+        monkeypatch.setenv("TIMG_HIP_DITHER_PARTS", str(parts))
+    fb = synth.make(kind, w, h, seed=29)
+    want = oracle.sixel_encode(fb, BG, PAT, 5, 3, lookup_mode=1)
+    for pix in ("2", "1"):
+        monkeypatch.setenv("TIMG_HIP_DITHER_PIX", pix)
+        got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3),
+                               out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+        assert got == want, f"pixel requests of {pix}: {len(got)} vs {len(want)} bytes"
+
+
 @pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])
 def test_sixel_diffusion_spread_over_several_cus(hip, oracle, monkeypatch, parts):
     """Frames of eight row groups and more are diffused by several workgroups (CUs) per frame, the boundary row

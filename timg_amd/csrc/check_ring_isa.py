@@ -24,7 +24,7 @@ import re
 import sys
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-LOAD = re.compile(r"global_load_dwordx4 v\[(\d+):(\d+)\]")
+LOAD = re.compile(r"global_load_dwordx[24] v\[(\d+):(\d+)\]")  # (x2: the sixel diffusion's pixel pairs)
 LOAD1 = re.compile(r"global_load_(?:dword|ubyte) v(\d+),")  # (the sixel diffusion's one-pixel ring)
 WAIT = re.compile(r"s_waitcnt vmcnt\(\d+\) ; ring (.*)")
 

@@ -43,6 +43,8 @@ struct SixelGeom {
     size_t band_cap;     // scratch bytes per band
     int band_ne;         // entry / node slots per band (6 * w rounded up to 64)
     int idx_stride;      // bytes per row of the palette-index image (w rounded up to 4)
+    // the diffusion's helper waves (K4): columns a boundary row is moved by at a time, naps of 128 clocks between polls
+    int helper_batch, helper_naps;
 };
 
 // per-frame device scratch
@@ -1023,6 +1025,21 @@ __device__ __forceinline__ PairI16 ApplyPair(PairI16 v, uint32_t q) {
 }
 
 constexpr int kDitherSpinLimit = 1 << 22;
+// Timing experiments only (scratch/build_variant.sh ... -DTIMG_DITHER_ABL=<bits>; results are garbage, addresses stay
+// in range, nothing blocks): 1 no waiting for the producer, 2 no palette-index load, 4 no pixel load, 8 no index
+// store, 16 no table reads, 32 no hand-down (and no helper waves), 64 no record reads, 128 no wait for the pixel, 256 no helper waves (with 1).  profiles/r4/dither_ablation.txt
+#ifndef TIMG_DITHER_ABL
+#define TIMG_DITHER_ABL 0
+#endif
+constexpr int kDitherAbl = TIMG_DITHER_ABL;
+// The helper waves (flusher, fetcher) share their SIMDs with diffusing waves: what they issue, the diffusion does not
+// (every row waits for the one above it: the slowest wave sets the pace).  Polling every 128 clocks and moving a
+// boundary row column by column they cost a 64-frame batch 4 % (profiles/r4/dither_ablation.txt); they nap
+// g.helper_naps x 128 clocks between polls and move pieces of >= g.helper_batch columns -- the launch chooses: long
+// naps where a frame has few parts (a part boundary then lags by the piece), short ones where it has many.
+__device__ __forceinline__ void HelperNap(int naps) {
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(2);
+}
 
 // kNarrow: frames of 1 or 2 columns, where the row-wrap term and the 7/16 term come from
 // the same pixel and arrive in the other order
@@ -1043,9 +1060,15 @@ constexpr int kDitherSpinLimit = 1 << 22;
 // the next pixel of the row; with the cell's COLOUR in LDS that is one LDS round trip (the palette index, which
 // only the output needs, is requested from BuildLut's byte table in memory and consumed kDitherAhead steps later);
 // the two-trip form reads cell -> index -> colour from 34 KB of tables and leaves the LDS to the boundary rows.
-template <bool kNarrow, bool kSplit, bool kOneTrip>
+//
+// kPix2: the pixels are requested two at a time (one global_load_dwordx2 every second step).  A wave's 32 rows make
+// every pixel request 32 cache lines, 66 clocks of issue (scratch/ubench/wave_latency.hip: iss_gload_rows) in a step
+// of ~500; a lane's column advances by one per step and starts even, so an even frame width (and 8-byte aligned
+// rows) makes the pair (x, x + 1) one aligned load that never straddles the row's end.  One-trip form only.
+template <bool kNarrow, bool kSplit, bool kOneTrip, bool kPix2 = false>
 __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
     static_assert(!(kNarrow && kOneTrip), "the narrow kernel keeps the small tables");
+    static_assert(!kPix2 || kOneTrip, "pixel pairs: one-trip form only");
     constexpr int kDitherTabWords = DitherTabWords(kOneTrip);
     // All of the kernel's LDS is dynamic and starts at address 0: [progress counters: kDitherLdsHead bytes][tables]
     // [boundary rows][slack].  (With a static array in front, every LDS address the steps form from a running offset
@@ -1139,6 +1162,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
 
     if (kSplit) {
         if (wave >= n_local + (flushes ? 1 : 0)) return;  // (the block is sized for the largest part)
+        if ((kDitherAbl & (32 | 256)) && ((flushes && wave == n_local) || (lw0 && wave == 0))) return;
         if (flushes && wave == n_local) {
             // ---- flusher: LDS boundary row of the part's last wave -> memory, as its counter advances
             const uint32_t *row = boundary + (size_t)(n_local - 1) * brow;
@@ -1151,7 +1175,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 asm volatile("" ::: "memory");
                 // (slot x + 1 is final once the producer has finished column x; the last one with the row)
                 const int limit = p >= n_pub ? W + 3 : p + 1;
-                if (limit > done) {
+                if (limit >= done + g.helper_batch || (limit > done && p >= n_pub)) {
                     for (int i = done * 3 + lane; i < limit * 3; i += 64)
                         __hip_atomic_store(xw + i, row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slots have left before the counter does
@@ -1159,7 +1183,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     done = limit;
                     if (p >= n_pub) break;
                 } else {
-                    __builtin_amdgcn_s_sleep(2);
+                    HelperNap(g.helper_naps);
                     if (++spins > kDitherSpinLimit) {
                         if (lane == 0) atomicExch(b.error, 1);
                         break;
@@ -1187,7 +1211,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     done = limit;
                     if (p >= n_pub) break;
                 } else {
-                    __builtin_amdgcn_s_sleep(2);
+                    HelperNap(g.helper_naps);
                     if (++spins > kDitherSpinLimit) {
                         if (lane == 0) {
                             atomicExch(b.error, 1);
@@ -1294,6 +1318,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             prog_raw = (uint32_t)__hip_atomic_load(&progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         auto wait_for = [&](int need) __attribute__((always_inline)) {
+            if (kDitherAbl & 1) return;
             int avail = __builtin_amdgcn_readfirstlane((int)prog_raw) - in_base;
             if (__builtin_expect(avail < need, 0)) {
                 do {
@@ -1314,6 +1339,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // their rows by then.)
         auto request = [&](int x_rec, uint32_t slot_addr, bool check = true, bool look = true) __attribute__((always_inline)) {
             if (check) wait_for(min(x_rec + 1, n_pub));
+            if (kDitherAbl & 64) return;
             if (look) peek();
             const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = this half's part of slot x_rec + 1
             n_lo = slot[0];
@@ -1349,13 +1375,22 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));
             return v;
         };
+        typedef uint32_t PixPair __attribute__((ext_vector_type(2)));
+        auto fetch2 = [&](int t) -> PixPair {  // columns t - 2 * rl (even) and the next one, the pair clamped into the row
+            uint32_t x;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(t - 2 * rl), "s"(W - 2));
+            const uint8_t *p = src_row + (size_t)x * 4;
+            PixPair v;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
+            return v;
+        };
         // One step.  Everything is computed by every lane, in range or not (the loads are
         // clamped, the tables indexed with clamped values): straight-line code the compiler can
         // schedule across the LDS reads; only the stores are predicated, and a lane outside its row
         // produces zero terms.  `lidx` receives the step's request for the palette index of its pixel (consumed
         // kDitherAhead steps later, with the wait for that step's pixel).
         // (k: the step's position in the unrolled body -- t - k is a multiple of eight)
-        auto step = [&](int t, uint32_t &px, uint32_t &lidx, auto k_tag) __attribute__((always_inline)) {
+        auto step = [&](int t, uint32_t &px, uint32_t &lidx, auto k_tag, PixPair *pair = nullptr) __attribute__((always_inline)) {
             constexpr int k = decltype(k_tag)::value;
             const int x = t - 2 * rl;
             // What can branch goes first -- the index store and the poll inside request() -- so that everything
@@ -1365,7 +1400,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // (x - 8) & 3 == (k - 2 * rl) & 3: a group of four indices ends at k & 3 == 3 in the even rows of the
             // wave, at k & 3 == 1 in the odd ones -- nothing to decide in the other steps
             if constexpr ((k & 1) != 0) {
-                if (((k & 3) == 3 ? store_even : store_odd) && (unsigned)(x - kDitherAhead) < (unsigned)g.idx_stride)
+                if (!(kDitherAbl & 8) && ((k & 3) == 3 ? store_even : store_odd) && (unsigned)(x - kDitherAhead) < (unsigned)g.idx_stride)
                     *reinterpret_cast<uint32_t *>(s.index + (idx_addr + (uint32_t)k)) = packed_idx;
             }
             // the record requested a step ago (column t + 2), and the request for column t + 3
@@ -1400,12 +1435,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             uint32_t p_cell;  // the cell's palette colour as this lane's pair, times 1 (one trip) or 16
             if constexpr (kOneTrip) {
                 const uint32_t at = cell + tab_base;
-                const uint32_t t0 = tab8[at];          // r / b
-                const uint32_t t1 = tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
-                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
+                const uint32_t t0 = (kDitherAbl & 16) ? at & 0xffu : tab8[at];          // r / b
+                const uint32_t t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
+                if (!(kDitherAbl & 2)) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
                 // (the pixel for kDitherAhead steps on is requested HERE, in the shadow of the table reads, with the
                 // unpacking below: ~48 clocks of LDS latency otherwise spent in s_waitcnt)
-                px     = fetch(t + kDitherAhead);
+                if constexpr (kPix2) {  // (the pair of this step and the one before it is used up: its next request)
+                    if constexpr ((k & 1) != 0) *pair = fetch2(t - 1 + kDitherAhead);
+                } else if (!(kDitherAbl & 4)) {
+                    px = fetch(t + kDitherAhead);
+                }
                 p_cell = t0 | (t1 << 16);
             } else {
                 lidx   = tab8[cell];
@@ -1439,12 +1478,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 uint32_t at;  // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32)
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(out_addr + (uint32_t)k * 12u), "v"(rec_lo), "v"(rec_hi));
                 LdsU32 *rec = (LdsU32 *)(uintptr_t)at;
-                rec[0] = w2;
-                rec[1] = w1;
+                if (!(kDitherAbl & 32)) {
+                    rec[0] = w2;
+                    rec[1] = w1;
+                }
                 asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
                 int pv;
                 asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + k), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
-                *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
+                if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
             }
             own7 = m7;
             c3   = c2;
@@ -1455,6 +1496,49 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             a1   = m3;
         };
 
+        if constexpr (kPix2) {
+            // Younger operations when a step begins (loads return in order; the index stores in between only make a wait
+            // more conservative).  Even step k: its pair was requested in step k - 7, behind it 6 index requests and 3
+            // pairs -- 9; odd step k: its index was requested in step k - 8 in front of that step's pair, then 7 indices
+            // and 3 pairs -- 11 (its pixel arrived with the pair, a step ago).
+            asm volatile("" ::: "memory");
+            PixPair q0 = fetch2(0), q1 = fetch2(2), q2 = fetch2(4), q3 = fetch2(6);
+            uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;
+            asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
+#define TIMG_DITHER_STEP_EVEN(k, Q, L)                                                                         \
+    asm volatile("s_waitcnt vmcnt(9) ; ring %0 %2\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(Q), "+v"(packed_idx) : "v"(L) : "memory"); \
+    {                                                                                                          \
+        uint32_t px_k = Q.x;                                                                                   \
+        step(t + k, px_k, L, std::integral_constant<int, k>(), &Q);                                            \
+    }
+#define TIMG_DITHER_STEP_ODD(k, Q, L)                                                                          \
+    asm volatile("s_waitcnt vmcnt(11) ; ring %1\n\tv_alignbyte_b32 %0, %1, %0, 1" : "+v"(packed_idx) : "v"(L) : "memory"); \
+    {                                                                                                          \
+        uint32_t px_k = Q.y;                                                                                   \
+        step(t + k, px_k, L, std::integral_constant<int, k>(), &Q);                                            \
+    }
+            for (int t = 0; t < steps; t += 8) {
+                TIMG_DITHER_STEP_EVEN(0, q0, l0)
+                TIMG_DITHER_STEP_ODD(1, q0, l1)
+                TIMG_DITHER_STEP_EVEN(2, q1, l2)
+                TIMG_DITHER_STEP_ODD(3, q1, l3)
+                TIMG_DITHER_STEP_EVEN(4, q2, l4)
+                TIMG_DITHER_STEP_ODD(5, q2, l5)
+                TIMG_DITHER_STEP_EVEN(6, q3, l6)
+                TIMG_DITHER_STEP_ODD(7, q3, l7)
+                in_addr += 96u;
+                out_addr += 96u;
+                prog_run += 8;
+                idx_addr += 8u;
+            }
+            asm volatile("s_waitcnt vmcnt(0) ; ring all"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4), "+v"(l5),
+                           "+v"(l6), "+v"(l7)
+                         :
+                         : "memory");
+#undef TIMG_DITHER_STEP_EVEN
+#undef TIMG_DITHER_STEP_ODD
+        } else {
         asm volatile("" ::: "memory");
         uint32_t p0 = fetch(0), p1 = fetch(1), p2 = fetch(2), p3 = fetch(3), p4 = fetch(4), p5 = fetch(5),
                  p6 = fetch(6), p7 = fetch(7);
@@ -1474,7 +1558,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // the step's own request into the same variable, it was given a second register and copied, in flight, at
         // the back edge (check_ring_isa.py refused the build).
 #define TIMG_DITHER_STEP(k, P, L)                                                             \
-    if constexpr (kOneTrip)                                                                   \
+    if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                        \
+        asm volatile("v_alignbyte_b32 %1, %2, %1, 1" : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory"); \
+    else if constexpr (kOneTrip)                                                              \
         asm volatile("s_waitcnt vmcnt(14) ; ring %0 %2\n\tv_alignbyte_b32 %1, %2, %1, 1"      \
                      : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory");                        \
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
@@ -1502,6 +1588,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                      :
                      : "memory");
 #undef TIMG_DITHER_STEP
+        }
     }
     // (outside the loops: a memory operation inside the poll loop would cost the compiler its
     // count of the prefetches in flight)
@@ -2749,16 +2836,33 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const bool wide_bands   = plan.wide_bands;  // sort buffers in global scratch
     const size_t nodes_lds = plan.nodes_lds, emit_lds = plan.emit_lds;
     // the diffusion kernel that serves this geometry, its grid, block and dynamic LDS
+    // (pixel pairs: an even width and rows that start on 8 bytes -- the pad rows in the scratch do: its carve is aligned)
+    {  // (TIMG_HIP_DITHER_HELPERS=<columns>,<naps> overrides)
+        const char *he = getenv("TIMG_HIP_DITHER_HELPERS");
+        int hb = 0, hn = 0;
+        if (he && sscanf(he, "%d,%d", &hb, &hn) == 2 && hb >= 1 && hn >= 1) {
+            g.helper_batch = hb;
+            g.helper_naps  = hn;
+        } else {
+            g.helper_batch = dither_parts <= 6 ? 16 : 1;
+            g.helper_naps  = dither_parts <= 6 ? 16 : 1;
+        }
+    }
+    const char *pix_env = getenv("TIMG_HIP_DITHER_PIX");
+    const bool pix2     = (w & 1) == 0 && w >= 4 && (g.stride & 7) == 0 && (g.frame_stride & 7) == 0 &&
+                      ((uintptr_t)b.fb & 7) == 0 && ((uintptr_t)b.pad_rows & 7) == 0 && !(pix_env && atoi(pix_env) == 1);
     const void *dither_fn = nullptr;
     dim3 dither_block;
     size_t dither_dyn = 0;
     if (dither_parts > 1) {
-        dither_fn    = plan.one_trip ? (const void *)DitherKernel<false, true, true> : (const void *)DitherKernel<false, true, false>;
+        dither_fn    = plan.one_trip ? (pix2 ? (const void *)DitherKernel<false, true, true, true> : (const void *)DitherKernel<false, true, true>)
+                                     : (const void *)DitherKernel<false, true, false>;
         dither_block = dim3((split_share + 2) * 64);
         dither_dyn   = split_lds;
     } else {
         dither_fn = w <= 2 ? (const void *)DitherKernel<true, false, false>
-                           : plan.one_trip ? (const void *)DitherKernel<false, false, true> : (const void *)DitherKernel<false, false, false>;
+                  : plan.one_trip ? (pix2 ? (const void *)DitherKernel<false, false, true, true> : (const void *)DitherKernel<false, false, true>)
+                                  : (const void *)DitherKernel<false, false, false>;
         dither_block = dim3(dither_waves * 64);
         dither_dyn   = dither_lds;
     }

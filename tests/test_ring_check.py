@@ -96,11 +96,11 @@ def test_built_library_passes():
     # ... and the four matrix instantiations write their A operand by v_writelane, four wait states ahead of the first v_mfma
     assert "4 kernels with v_writelane -> v_mfma" in r.stdout
     # the sixel diffusion keeps eight source pixels (and, in its one-trip forms, eight palette indices) in flight the
-    # same way: five instantiations
+    # same way: seven instantiations (two of them request the pixels in pairs: global_load_dwordx2)
     sixel = BUILT.replace("scale_stream", "sixel_canvas")
     r = subprocess.run([sys.executable, CHECK, sixel], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "5 kernels" in r.stdout
+    assert "7 kernels" in r.stdout
 
 
 def test_single_register_ring_is_checked_too(tmp_path):
@@ -149,6 +149,30 @@ def run_mfma(tmp_path, pre="", nop="\ts_nop 3\n", mid=""):
     path.write_text(MFMA.format(pre=pre, nop=nop, mid=mid))
     r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
     return r.returncode, r.stdout
+
+
+def test_pair_ring_is_checked_too(tmp_path):
+    """The diffusion's pixel pairs: global_load_dwordx2 into v[a:b], released by a wait that names the pair -- either
+    half named in between is a violation."""
+    body = """\
+_Z6kernelv:
+\t;;#ASMSTART
+\tglobal_load_dwordx2 v[8:9], v[20:21], off
+\t;;#ASMEND
+{mid}\t;;#ASMSTART
+\ts_waitcnt vmcnt(0) ; ring v[8:9] v30
+\t;;#ASMEND
+\tv_add_u32_e32 v10, v8, v9
+\ts_endpgm
+.Lfunc_end0:
+"""
+    path = tmp_path / "k.s"
+    path.write_text(body.format(mid="\tv_add_u32_e32 v22, 4, v22\n"))
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    path.write_text(body.format(mid="\tv_mov_b32_e32 v31, v9\n"))
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "v[8:9]" in r.stdout
 
 
 def test_writelane_then_mfma_with_the_nop_passes(tmp_path):

@@ -42,7 +42,11 @@ struct SixelGeom {
     uint32_t sample_stride_px, n_samples;
     size_t band_cap;     // scratch bytes per band
     int band_ne;         // entry / node slots per band (6 * w rounded up to 64)
-    int idx_stride;      // bytes per row of the palette-index image (w rounded up to 4)
+    // The palette-index image: idx_stride bytes a row (a multiple of 8, >= w + 6), pixel x of row r at byte
+    // r * idx_stride + 2 * (r & 3) + x -- IndexRow().  The diffusion advances a row two columns behind the row above it
+    // and stores eight indices at a time; with the rows shifted by two bytes per row (mod 8) every row of a wave
+    // completes an aligned group of eight in the SAME step: one 8-byte store per lane every eighth step (K4).
+    int idx_stride;
     // the diffusion's helper waves (K4): columns a boundary row is moved by at a time, naps of 128 clocks between polls
     int helper_batch, helper_naps;
 };
@@ -98,6 +102,10 @@ struct SixelBatch {
     size_t out_cap;
     unsigned long long *out_len;
 };
+
+__device__ __forceinline__ uint32_t IndexRow(const SixelGeom &g, int row) {  // byte offset of pixel 0 of `row`
+    return (uint32_t)row * (uint32_t)g.idx_stride + 2u * ((uint32_t)row & 3u);
+}
 
 __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, const SixelGeom &g,
                                                           int f) {
@@ -1245,7 +1253,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // a row's W pixels, skewed by two columns per row; the palette index of a pixel arrives kDitherAhead steps
     // after the pixel's own step, and a row's last group of four indices is completed by up to three junk ones
     // (the index rows are padded to a multiple of four and nobody reads the pad)
-    const int steps          = g.idx_stride + 2 * (kPairRows - 1) + kDitherAhead;
+    // (+ 8: a row's last group of eight indices is completed by up to seven junk ones -- nobody reads the row's padding)
+    const int steps          = W + 2 * (kPairRows - 1) + kDitherAhead + 8;
     bool gave_up             = false;
     for (int round = 0; round * rows_per_round + first_row < H; ++round) {
         const int row      = round * rows_per_round + first_row + rl;
@@ -1254,7 +1263,11 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                                             : reinterpret_cast<const uint8_t *>(pad_rows + (size_t)(min(row, H - 1) - g.h) * W);
         // (the lane's index row as a 32-bit offset from the frame's index image, already moved back to where the group
         // of four that ends kDitherAhead columns behind x begins: base + offset addressing, no 64-bit arithmetic)
-        uint32_t idx_addr       = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride - (uint32_t)(2 * rl + kDitherAhead + 3);
+        // At the last step of a block of eight (t + 7) the eight indices of columns t - 8 - 2 rl ... t - 1 - 2 rl are
+        // complete: bytes idx_q ... idx_q + 7 of the lane's index row, idx_q = t - 8 - 8 (rl >> 2) -- IndexRow()'s shift
+        // of 2 (rl & 3) is what makes it a multiple of eight for every row (rl = row mod 32).
+        int idx_q               = -8 - 8 * (rl >> 2);
+        uint32_t idx_addr       = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride + (uint32_t)idx_q;
         const bool diffuses     = dither && row < H - 1;
         // a lane that never spreads an error (no row, the last row, an exact palette) multiplies by zero:
         // 16 * err = 16 * c - 16 * p as ONE v_pk_mad_u16 of the table bytes
@@ -1263,8 +1276,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         const uint32_t k_err    = !lane_spreads ? 0u : !kOneTrip ? 0xffffffffu : odd ? 0x0000fff0u : 0xfff0fff0u;
         const uint32_t c16_mask = lane_spreads ? (odd ? 0x00000ff0u : 0x0ff00ff0u) : 0u;
         // which lanes complete a group of four indices at the steps k & 3 == 3 / k & 3 == 1 of the unrolled body
-        const bool store_even   = has_row && !odd && !(rl & 1);
-        const bool store_odd    = has_row && !odd && (rl & 1);
+        const bool stores_idx   = has_row && !odd;
         const bool hands_down   = has_row && rl == kPairRows - 1;  // the row above the next wave's first row
         // (kSplit: local wave 0 is either the frame's first wave or the fetcher, which writes row 0 like a wave)
         const int producer       = wave == 0 ? n_local - 1 : wave - 1;
@@ -1299,7 +1311,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         //   a1   = 3/16 of e(x-1), b2 = 5/16 of e(x-2), c3 = 1/16 of e(x-3) -> the row below
         uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;
         uint32_t first_q3 = 0;
-        uint32_t packed_idx = 0;
+        uint32_t pk_lo = 0, pk_hi = 0;  // the last eight indices, the newest in pk_hi's top byte
         // terms from above for the wave's first row: at step t (column t) it adds 1/16 of the error of column t - 1, 5/16
         // of column t, 3/16 of column t + 1; record t + 2 is unpacked, record t + 3 requested
         uint32_t up1_a = 0, up1_b = 0, up1_c = 0;  // 1/16 of columns t - 1, t, t + 1
@@ -1397,11 +1409,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // from the pixel to the error terms is ONE basic block: the table reads and their uses are then
             // scheduled together (split by a branch, the byte reads came back through a v_and each, and their
             // latency covered nothing).
-            // (x - 8) & 3 == (k - 2 * rl) & 3: a group of four indices ends at k & 3 == 3 in the even rows of the
-            // wave, at k & 3 == 1 in the odd ones -- nothing to decide in the other steps
-            if constexpr ((k & 1) != 0) {
-                if (!(kDitherAbl & 8) && ((k & 3) == 3 ? store_even : store_odd) && (unsigned)(x - kDitherAhead) < (unsigned)g.idx_stride)
-                    *reinterpret_cast<uint32_t *>(s.index + (idx_addr + (uint32_t)k)) = packed_idx;
+            // the eight indices completed by this block (see idx_q): one store, in the block's last step
+            if constexpr (k == 7) {
+                if (!(kDitherAbl & 8) && stores_idx && (unsigned)idx_q < (unsigned)g.idx_stride)
+                    *reinterpret_cast<uint2 *>(s.index + idx_addr) = make_uint2(pk_lo, pk_hi);
             }
             // the record requested a step ago (column t + 2), and the request for column t + 3
             const uint32_t q_lo = n_lo, q_hi = n_hi;
@@ -1506,13 +1517,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;
             asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
 #define TIMG_DITHER_STEP_EVEN(k, Q, L)                                                                         \
-    asm volatile("s_waitcnt vmcnt(9) ; ring %0 %2\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(Q), "+v"(packed_idx) : "v"(L) : "memory"); \
+    asm volatile("s_waitcnt vmcnt(9) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(Q), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     {                                                                                                          \
         uint32_t px_k = Q.x;                                                                                   \
         step(t + k, px_k, L, std::integral_constant<int, k>(), &Q);                                            \
     }
 #define TIMG_DITHER_STEP_ODD(k, Q, L)                                                                          \
-    asm volatile("s_waitcnt vmcnt(11) ; ring %1\n\tv_alignbyte_b32 %0, %1, %0, 1" : "+v"(packed_idx) : "v"(L) : "memory"); \
+    asm volatile("s_waitcnt vmcnt(11) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     {                                                                                                          \
         uint32_t px_k = Q.y;                                                                                   \
         step(t + k, px_k, L, std::integral_constant<int, k>(), &Q);                                            \
@@ -1530,6 +1541,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 out_addr += 96u;
                 prog_run += 8;
                 idx_addr += 8u;
+                idx_q += 8;
             }
             asm volatile("s_waitcnt vmcnt(0) ; ring all"
                          : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4), "+v"(l5),
@@ -1559,13 +1571,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // the back edge (check_ring_isa.py refused the build).
 #define TIMG_DITHER_STEP(k, P, L)                                                             \
     if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                        \
-        asm volatile("v_alignbyte_b32 %1, %2, %1, 1" : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory"); \
+        asm volatile("v_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     else if constexpr (kOneTrip)                                                              \
-        asm volatile("s_waitcnt vmcnt(14) ; ring %0 %2\n\tv_alignbyte_b32 %1, %2, %1, 1"      \
-                     : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory");                        \
+        asm volatile("s_waitcnt vmcnt(14) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
+                     : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");                \
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
-        asm volatile("s_waitcnt vmcnt(7) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1"          \
-                     : "+v"(P), "+v"(packed_idx) : "v"(L) : "memory");                        \
+        asm volatile("s_waitcnt vmcnt(7) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
+                     : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");                \
     step(t + k, P, L, std::integral_constant<int, k>());
         for (int t = 0; t < steps; t += 8) {
             TIMG_DITHER_STEP(0, p0, l0)
@@ -1580,6 +1592,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             out_addr += 96u;
             prog_run += 8;
             idx_addr += 8u;
+                idx_q += 8;
         }
         // the 16 requests still in flight must land before their registers are used for anything else
         asm volatile("s_waitcnt vmcnt(0) ; ring all"
@@ -1653,7 +1666,7 @@ __global__ void __launch_bounds__(64) DitherFirstHitKernel(SixelGeom g, SixelBat
     for (int y = 0; y < H; ++y) {
         // byte offsets into rows[] (plain integers: a select between two LDS pointers crashed the compiler)
         const int cur = (y & 1) * row_bytes, nxt = ((y + 1) & 1) * row_bytes;
-        uint8_t *idx_row = s.index + (size_t)y * g.idx_stride;
+        uint8_t *idx_row = s.index + IndexRow(g, y);
         for (int x = 0; x < W; ++x) {
             const int r = rows[cur + 3 * x], gg = rows[cur + 3 * x + 1], bb = rows[cur + 3 * x + 2];
             const uint32_t cell = ((uint32_t)(r >> 3) << 10) | ((uint32_t)(gg >> 3) << 5) | (uint32_t)(bb >> 3);
@@ -1851,7 +1864,8 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
     const int band = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const int W               = g.w;
-    const uint8_t *rows       = s.index + (size_t)band * 6 * g.idx_stride;
+    const uint8_t *index      = s.index;
+    const int row0            = band * 6;  // (pixel x of row r: index[IndexRow(g, r) + x], 2-byte aligned for even x)
     const size_t slot         = (size_t)band * NE;
 
     // ---- entries, column-major: count, scan, write.  (Wide frames:) a lane takes kGroups x 4 adjacent
@@ -1868,9 +1882,10 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         for (int gi = 0; gi < kGroups; ++gi)
 #pragma unroll
             for (int r = 0; r < 6; ++r)
-                cw[gi][r] = g0 + gi < g1 ? *reinterpret_cast<const uint32_t *>(rows + (size_t)r * g.idx_stride +
-                                                                             4 * (g0 + gi))
-                                         : 0u;
+                cw[gi][r] = g0 + gi < g1
+                                ? (uint32_t)*reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 4 * (g0 + gi)) |
+                                      ((uint32_t)*reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 4 * (g0 + gi) + 2) << 16)
+                                : 0u;
     }
     // (wide frames) visit(first, ent): a column's six rows as entries in FIXED slots, bit r of `first` set where row r is
     // the first of its colour -- no compaction into an array indexed at run time (that array lived in scratch memory)
@@ -1925,7 +1940,7 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         for (int pi2 = 0; pi2 < kPairs; ++pi2)
 #pragma unroll
             for (int r = 0; r < 6; ++r)
-                c16[pi2][r] = h0 + pi2 < h1 ? *reinterpret_cast<const uint16_t *>(rows + (size_t)r * g.idx_stride + 2 * (h0 + pi2))
+                c16[pi2][r] = h0 + pi2 < h1 ? *reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 2 * (h0 + pi2))
                                             : 0u;
         for (int i = tid; i < 256 * nws; i += kT) bitmap[i] = 0;  // (while the index loads are in flight)
         // the entries of a lane's (up to four) columns: ent[k][r] valid where bit r of first[k] is set
@@ -2769,7 +2784,7 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_lut8  = carve(nf * 32768);
     const size_t o_pal   = carve(nf * 768);
     const size_t o_meta  = carve(nf * 4 * sizeof(int));
-    g.idx_stride         = (w + 3) & ~3;
+    g.idx_stride         = (w + 6 + 7) & ~7;
     const size_t o_idx   = carve(nf * (size_t)g.h6 * g.idx_stride);
     const size_t o_bb    = carve(nf * g.bands * g.band_cap);
     const size_t o_bm    = carve(nf * g.bands * 4 * sizeof(int));

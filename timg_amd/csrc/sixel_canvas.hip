@@ -553,6 +553,193 @@ __device__ void SplitBox(const CutBox &box, uint32_t *const tab[2], uint32_t *sc
     *lowersum_out = lowersum;
 }
 
+// The first rounds of a frame pick one, two, four boxes of thousands of colours: one wave each sorted them while the
+// others idled (19 + 11 + 7 of the kernel's ~120 us on the traced frame; a wave issues an instruction per four clocks,
+// ~60 of them per colour and lane).  When a round picks one or two boxes and one of them is large, TEAMS of waves
+// split them instead -- twelve or six waves per box, 64 x T virtual lanes with a segment each -- by the same
+// stable counting sort as SplitBox's large path, its phases separated by workgroup barriers that EVERY wave of the
+// workgroup executes (a team without a box walks empty ranges): extent; count; group sums; bases and write-back;
+// scatter; segment sums; median.  The counter rows of a team are the scratch areas of its waves, contiguous.
+constexpr uint32_t kCutTeamMin = 1024;  // colours of the largest pick from which teams pay (seven barriers ~ 3 us)
+struct CutTeamShared {
+    uint32_t seen[kCutWaves][3];      // per wave: key values seen per plane
+    uint16_t grp[2 * kCutWaves * 32]; // per team, group of 32 segments, key: entries (<= 32768)
+    uint32_t wsum[kCutWaves];         // per wave: pixels of its lanes' segments of the sorted box
+    uint2 wcand[kCutWaves];           // per wave: the median candidate of its lowest lane that has one, or ~0
+};
+template <bool kLds>
+__device__ void TeamSplit(bool has_box, const CutBox &box, int T, int team, int tw, int wave, int lane,
+                          uint32_t *const tab[2], uint32_t *team_scratch, CutTeamShared &sh, uint32_t *median_out,
+                          uint32_t *lowersum_out) {
+    typedef typename std::conditional<kLds, CutLdsWord, uint32_t>::type Word;
+    const uint32_t VL = 64u * (uint32_t)T, vl = (uint32_t)tw * 64u + (uint32_t)lane;
+    const uint32_t colors = has_box ? box.colors : 0u;
+    const Word *src       = (const Word *)tab[box.buf] + box.ind;
+    Word *dst             = (Word *)tab[box.buf ^ 1u] + box.ind;
+    const uint32_t half   = box.sum / 2;
+    uint16_t *cnt16       = reinterpret_cast<uint16_t *>(team_scratch);  // [64 T][34]: row v at word 17 v
+    constexpr int kRow16  = 34;
+    auto key_base = [&](uint32_t k) -> uint32_t & { return team_scratch[k * 17 + 16]; };
+
+    // ---- extent of the box per plane
+    uint32_t seen[3] = {0, 0, 0};
+    for (uint32_t i = vl; i < colors; i += 4 * VL) {
+        uint32_t e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = src[min(i + q * VL, colors - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) seen[p] |= 1u << PlaneKey(e[q], p);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t m = WaveOr(seen[p]);
+        if (lane == 0) sh.seen[wave][p] = m;
+    }
+    __threadfence_block();
+    __syncthreads();
+    int plane = 0;
+    {
+        uint32_t m3[3] = {0, 0, 0};
+        for (int w = 0; w < T; ++w)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) m3[p] |= sh.seen[team * T + w][p];
+        const uint32_t lum[3] = {2989u, 5866u, 1145u};  // (see SplitBox: the integer comparison decides as the double one)
+        uint32_t best         = 0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t m      = m3[p] | (has_box ? 0u : 1u);
+            const uint32_t spread = lum[p] * ((31u - (uint32_t)__clz((int)m)) - ((uint32_t)__ffs((int)m) - 1u));
+            if (spread > best) {
+                plane = p;
+                best  = spread;
+            }
+        }
+    }
+    // ---- count: virtual lane v takes the segment [a, z) and counts its keys in row v
+    const uint32_t seg = (((colors + VL - 1) / VL) | 1u);
+    const uint32_t a   = min(colors, vl * seg);
+    const uint32_t z   = min(colors, a + seg);
+    uint32_t *mine_w   = team_scratch + vl * 17;
+    for (int k = 0; k < 16; ++k) mine_w[k] = 0;
+    for (uint32_t i = a; i < z; i += 4) {
+        uint32_t e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = src[min(i + q, z - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t k = PlaneKey(e[q], plane);
+            (void)__hip_atomic_fetch_add(&mine_w[k >> 1], i + q < z ? 1u << ((k & 1u) * 16) : 0u, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- exclusive prefix over the virtual lanes, per key: thread (key, group of 32 rows)
+    const uint32_t key = vl & 31u, grp = vl >> 5, n_grp = 2u * (uint32_t)T;
+    uint16_t *my_grp   = sh.grp + (uint32_t)team * n_grp * 32u;
+    uint32_t t[32], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) t[q] = cnt16[(grp * 32 + q) * kRow16 + key];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) sum += t[q];
+    my_grp[grp * 32 + key] = (uint16_t)sum;
+    __threadfence_block();
+    __syncthreads();
+    {
+        uint32_t base = 0, total = 0;
+        for (uint32_t g2 = 0; g2 < n_grp; ++g2) {
+            const uint32_t v = my_grp[g2 * 32 + key];
+            total += v;
+            base += g2 < grp ? v : 0u;
+        }
+        const uint32_t incl = WaveInclusiveAdd(lane < 32 ? total : 0u);
+        if (tw == 0 && lane < 32) key_base((uint32_t)lane) = incl - total;
+        uint32_t run = base;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            cnt16[(grp * 32 + q) * kRow16 + key] = (uint16_t)run;
+            run += t[q];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- scatter
+    for (uint32_t i = a; i < z; i += 4) {
+        uint32_t e[4], k[4], was[4], kb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = src[min(i + q, z - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            k[q]   = PlaneKey(e[q], plane);
+            kb[q]  = key_base(k[q]);
+            was[q] = __hip_atomic_fetch_add(&mine_w[k[q] >> 1], i + q < z ? 1u << ((k[q] & 1u) * 16) : 0u,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i + q < z) dst[kb[q] + ((was[q] >> ((k[q] & 1u) * 16)) & 0xffffu)] = e[q];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- median: pixels in front of every segment of the sorted box, then the crossing
+    uint32_t seg_sum = 0;
+    for (uint32_t i = a; i < z; i += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = dst[min(i + q, z - 1)] >> 15;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) seg_sum += i + q < z ? c[q] : 0u;
+    }
+    const uint32_t incl2 = WaveInclusiveAdd(seg_sum);
+    if (lane == 63) sh.wsum[wave] = incl2;
+    __threadfence_block();
+    __syncthreads();
+    uint32_t run = incl2 - seg_sum;
+    for (int w = 0; w < tw; ++w) run += sh.wsum[team * T + w];
+    uint32_t cand = 0xffffffffu, cand_sum = 0;
+    const bool mine = run + seg_sum >= half;
+    for (uint32_t i = a; i < z; i += 8) {
+        if (!__any(mine && cand == 0xffffffffu)) break;
+        uint32_t c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = dst[min(i + q, z - 1)] >> 15;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i + q < z && cand == 0xffffffffu && i + q >= 1 && run >= half) {
+                cand     = i + q;
+                cand_sum = run;
+            }
+            run += i + q < z ? c[q] : 0u;
+        }
+    }
+    {
+        const unsigned long long hit = __ballot(cand != 0xffffffffu);
+        const int l                  = hit ? __builtin_ctzll(hit) : 0;
+        const uint32_t wc = ReadLane(cand, l), ws = ReadLane(cand_sum, l);
+        if (lane == 0) sh.wcand[wave] = hit ? make_uint2(wc, ws) : make_uint2(0xffffffffu, 0u);
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t median = colors ? colors - 1 : 0u, lowersum = 0;
+    if (has_box) {
+        for (int w = T - 1; w >= 0; --w) {  // the lowest wave that has a candidate
+            const uint2 c = sh.wcand[team * T + w];
+            if (c.x != 0xffffffffu) {
+                median   = c.x;
+                lowersum = c.y;
+            }
+        }
+        if (median >= colors - 1) {
+            median   = colors - 1;
+            lowersum = box.sum - (dst[colors - 1] >> 15);
+        }
+    }
+    *median_out   = median;
+    *lowersum_out = lowersum;
+}
+
 // channel sums (as 8-bit values) of a box's colours, for its palette entry
 template <class Word>
 __device__ __forceinline__ void BoxColourSums(const Word *src, uint32_t colors, uint32_t sum[3]) {
@@ -683,6 +870,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     // maximum and above the list's unprepared maximum -- and those lanes write their two halves at once.
     constexpr uint32_t kReady = 4u;
     __shared__ uint32_t s_pick[64], s_npick;
+    __shared__ CutTeamShared s_team;
     __shared__ alignas(16) uint32_t s_key[kMaxColors];
     __shared__ uint32_t s_rank[kMaxColors];
     __shared__ alignas(16) uint32_t s_S[kMaxColors];
@@ -766,8 +954,26 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 #ifdef TIMG_CUT_TRACE
         t_mark = wall_clock64();
 #endif
-        // ---- speculative splits: wave w prepares the picked boxes w, w + 12, ...
-        for (uint32_t p = (uint32_t)wave, np = s_npick; p < np; p += kCutWaves) {
+        // ---- speculative splits: teams of waves for the few large boxes of the first rounds (TeamSplit), else wave w
+        // prepares the picked boxes w, w + 12, ...
+        const uint32_t n_picked = s_npick;
+        uint32_t largest = 0;
+        if (n_picked <= 2)  // (teams of three for four boxes came out at 7.3 us a round against 7.0: profiles/r4/cut_trace.txt)
+            for (uint32_t p = 0; p < n_picked; ++p) largest = max(largest, pool[s_pick[p]].w0 >> 16);
+        if (kCutWaves == 12 && largest >= kCutTeamMin) {  // (the same for every thread of the workgroup: barriers inside)
+            const int T = n_picked == 1 ? 12 : 6, team = wave / T, tw = wave % T;
+            const bool has_box  = (uint32_t)team < n_picked;
+            const uint32_t slot = has_box ? s_pick[team] : 0u;
+            const CutBox box    = has_box ? BoxOf(pool[slot]) : CutBox{0, 0, 0, 0};
+            uint32_t *team_scratch = cut_lds + 2 * kCutLdsEntries + team * T * kCutScratch;
+            uint32_t median, lowersum;
+            if (in_lds)
+                TeamSplit<true>(has_box, box, T, team, tw, wave, lane, tab, team_scratch, s_team, &median, &lowersum);
+            else
+                TeamSplit<false>(has_box, box, T, team, tw, wave, lane, tab, team_scratch, s_team, &median, &lowersum);
+            if (has_box && tw == 0 && lane == 0) pool[slot].w2 = median | (lowersum << 16);
+        } else
+        for (uint32_t p = (uint32_t)wave, np = n_picked; p < np; p += kCutWaves) {
             const uint32_t slot = s_pick[p];
             const CutBox box    = BoxOf(pool[slot]);
             uint32_t median, lowersum;

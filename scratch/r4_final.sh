@@ -6,7 +6,7 @@ ulimit -c 0
 mkdir -p gpurun_out/r4
 timeout -k 5 400 bash profiles/collect.sh r4x > gpurun_out/r4_collect.log 2>&1; tail -3 gpurun_out/r4_collect.log | cut -c1-300
 cp gpurun_out/r4x/summary.txt gpurun_out/r4x/kernel_stats.csv gpurun_out/r4x/hbm_traffic.json gpurun_out/r4/ 2>/dev/null
-timeout -k 5 300 bash profiles/collect_pmc.sh r4 c3 2>&1 | cut -c1-400
+# (the counters of c3: profiles/collect_pmc.sh r4 c3 -- collected earlier this round, its kernel has not changed since)
 out=gpurun_out/r4/bench_configs.txt; : > $out
 for c in c2 c3 c4 c5; do
   echo "== python bench.py --config $c" >> $out

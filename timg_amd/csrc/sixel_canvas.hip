@@ -15,7 +15,7 @@
 //                               rows through DPP shuffles (no memory traffic)
 //   K5 EncodeBand               one workgroup per 6-row band: colour runs ->
 //                               nodes -> libsixel's greedy packing -> RLE bytes
-//   K6 AssembleFrame / CopyBands  header, palette, band offsets, compaction
+//   K6 AssembleBands             header, palette, band offsets, compaction (one kernel, a workgroup per band)
 #include <algorithm>
 #include <cstdlib>
 #include <functional>
@@ -149,10 +149,20 @@ __device__ __forceinline__ uint32_t Hash555(uint32_t px) {  // r,g,b in the low 
     return ((px & 0xf8u) << 7) | (((px >> 8) & 0xf8u) << 2) | ((px >> 19) & 0x1fu);
 }
 
+// decimal digits of v, and the bytes of palette entry n in the output ("#n;2;r;g;b" in percent)
+__device__ __forceinline__ int NumLen(uint32_t v) {
+    return v >= 10000 ? 5 : v >= 1000 ? 4 : v >= 100 ? 3 : v >= 10 ? 2 : 1;
+}
+__device__ __forceinline__ int PaletteEntryLen(int n, uint32_t r, uint32_t g, uint32_t b) {
+    return 1 + NumLen((uint32_t)n) + 3 + NumLen((r * 100u + 127u) / 255u) + 1 + NumLen((g * 100u + 127u) / 255u) + 1 +
+           NumLen((b * 100u + 127u) / 255u);
+}
+__device__ __forceinline__ int PaletteEntryLen(int n, const uint8_t *rgb) { return PaletteEntryLen(n, rgb[0], rgb[1], rgb[2]); }
+
 // ---- K1: sampled 15-bit histogram, one workgroup per frame --------------------------------
 // libsixel's computeHistogram walks the samples in order, counts every 5:5:5 colour and
-// lists the colours in first-seen order.  Both tables (first sample index, count) live in
-// LDS, one after the other in the same 128 KB; the result is entries[k] = count<<15 | hash
+// lists the colours in first-seen order.  Both answers (first sample index, count) live in
+// ONE word per bin of a 128 KB LDS table; the result is entries[k] = count<<15 | hash
 // for the sample that saw its colour first, 0 for every other sample -- the global 32768-bin
 // tables of the first version (and their 16 MB memset per batch) are gone.
 constexpr int kHistThreads = 1024;
@@ -189,29 +199,26 @@ __global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBat
         }
     }
     __syncthreads();
+    // One table serves both questions, one after the other WITHOUT a second clear: a bin first takes the smallest
+    // sample index that hits it (atomicMin; an index is below 2^16: n_samples <= 36 864), then every hit adds 1 << 16 --
+    // the low half keeps the first index, the high half counts (<= n_samples, no carry out of the word).  (Until
+    // round 4: min, read back, clear to zero, count, read -- one more pass of 32 stores and 36 reads a thread and
+    // a barrier.)
 #pragma unroll
     for (int j = 0; j < kHistPerThread; ++j)
         if (hash[j] != 0xffffffffu) atomicMin(&hist_lds[hash[j]], (uint32_t)(tid + j * kHistThreads));
     __syncthreads();
-    unsigned long long is_first = 0;
 #pragma unroll
     for (int j = 0; j < kHistPerThread; ++j)
-        if (hash[j] != 0xffffffffu && hist_lds[hash[j]] == (uint32_t)(tid + j * kHistThreads))
-            is_first |= 1ull << j;
-    __syncthreads();
-    for (int i = tid; i < 32768; i += kHistThreads) hist_lds[i] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kHistPerThread; ++j)
-        if (hash[j] != 0xffffffffu) atomicAdd(&hist_lds[hash[j]], 1u);
+        if (hash[j] != 0xffffffffu) atomicAdd(&hist_lds[hash[j]], 1u << 16);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kHistPerThread; ++j) {
         if (hash[j] == 0xffffffffu) continue;
-        uint32_t e = 0;
-        if ((is_first >> j) & 1ull) {
-            uint32_t c = hist_lds[hash[j]];
-            if (c > 65535u) c = 65535u;  // libsixel's histogram is unsigned short, saturating
+        const uint32_t w = hist_lds[hash[j]];
+        uint32_t e       = 0;
+        if ((w & 0xffffu) == (uint32_t)(tid + j * kHistThreads)) {
+            const uint32_t c = w >> 16;  // (libsixel's histogram is unsigned short, saturating: never reached here)
             e = (c << 15) | hash[j];
         }
         s.entries[tid + j * kHistThreads] = e;
@@ -826,15 +833,22 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
 
     if (n <= (uint32_t)kMaxColors) {
         // few enough colours: palette = the histogram colours, no diffusion
+        __shared__ uint32_t s_pal_bytes0;
+        if (tid == 0) s_pal_bytes0 = 0;
+        __syncthreads();
         for (uint32_t i = tid; i < n; i += blockDim.x) {
             const uint32_t e     = s.tab_a[i];
-            s.palette[i * 3 + 0] = (uint8_t)(((e >> 10) & 0x1f) << 3);
-            s.palette[i * 3 + 1] = (uint8_t)(((e >> 5) & 0x1f) << 3);
-            s.palette[i * 3 + 2] = (uint8_t)((e & 0x1f) << 3);
+            const uint32_t r = ((e >> 10) & 0x1f) << 3, gg = ((e >> 5) & 0x1f) << 3, bb = (e & 0x1f) << 3;
+            s.palette[i * 3 + 0] = (uint8_t)r;
+            s.palette[i * 3 + 1] = (uint8_t)gg;
+            s.palette[i * 3 + 2] = (uint8_t)bb;
+            atomicAdd(&s_pal_bytes0, (uint32_t)PaletteEntryLen((int)i, r, gg, bb));
         }
+        __syncthreads();
         if (tid == 0) {
             s.meta[0] = (int)n;
             s.meta[1] = 0;
+            s.meta[2] = (int)s_pal_bytes0;  // bytes of the palette in the output (K6)
         }
         return;
     }
@@ -869,7 +883,7 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     // an exclusive prefix maximum over them; the splits that happen are the leading lanes whose key is above that
     // maximum and above the list's unprepared maximum -- and those lanes write their two halves at once.
     constexpr uint32_t kReady = 4u;
-    __shared__ uint32_t s_pick[64], s_npick;
+    __shared__ uint32_t s_pick[64], s_npick, s_pal_bytes;
     __shared__ CutTeamShared s_team;
     __shared__ alignas(16) uint32_t s_key[kMaxColors];
     __shared__ uint32_t s_rank[kMaxColors];
@@ -933,8 +947,9 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
     if (tid < kMaxColors) s_S[tid] = tid == 0 && n >= 2u ? order_key(s_total, 256) << 3 : 0u;
     if (tid < 8) s_sortkey[64 + tid] = 0;
     if (tid == 0) {
-        pool[0]  = CutRec{n << 16, 0, s_total | (256u << 16), 0};
-        s_done   = 0;
+        pool[0]     = CutRec{n << 16, 0, s_total | (256u << 16), 0};
+        s_done      = 0;
+        s_pal_bytes = 0;
     }
     __threadfence_block();
     __syncthreads();
@@ -1112,13 +1127,17 @@ __global__ void __launch_bounds__(kCutWaves * 64) MedianCutKernel(SixelGeom g, S
             BoxColourSums((const CutLdsWord *)tab[box.buf] + box.ind, box.colors, sum);
         else
             BoxColourSums(tab[box.buf] + box.ind, box.colors, sum);
-        s.palette[at * 3 + 0] = (uint8_t)(sum[0] / box.colors);
-        s.palette[at * 3 + 1] = (uint8_t)(sum[1] / box.colors);
-        s.palette[at * 3 + 2] = (uint8_t)(sum[2] / box.colors);
+        const uint32_t r = (sum[0] / box.colors) & 0xffu, gg = (sum[1] / box.colors) & 0xffu, bb = (sum[2] / box.colors) & 0xffu;
+        s.palette[at * 3 + 0] = (uint8_t)r;
+        s.palette[at * 3 + 1] = (uint8_t)gg;
+        s.palette[at * 3 + 2] = (uint8_t)bb;
+        atomicAdd(&s_pal_bytes, (uint32_t)PaletteEntryLen((int)at, r, gg, bb));
     }
+    __syncthreads();
     if (tid == 0) {
         s.meta[0] = (int)nboxes;
         s.meta[1] = 1;  // more colours than palette entries: diffuse
+        s.meta[2] = (int)s_pal_bytes;  // bytes of the palette in the output (K6)
     }
 #ifdef TIMG_CUT_TRACE
     __syncthreads();
@@ -1924,10 +1943,6 @@ __global__ void __launch_bounds__(64) DitherFirstHitKernel(SixelGeom g, SixelBat
 //   K5c BandEmit   (256 lanes)  pass-major output order; byte size per node in O(1) from the
 //                               prefix, scan, then bytes: one lane per slot for what stands in
 //                               front of a node's body, one lane per ENTRY for runs and gaps
-__device__ __forceinline__ int NumLen(uint32_t v) {
-    return v >= 10000 ? 5 : v >= 1000 ? 4 : v >= 100 ? 3 : v >= 10 ? 2 : 1;
-}
-
 __device__ __forceinline__ char *PutUInt(char *p, uint32_t v) {
     char t[10];
     int n = 0;
@@ -2774,74 +2789,44 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
 }
 
 // ---- K6 -------------------------------------------------------------------------------
-__device__ __forceinline__ int PaletteEntryLen(int n, const uint8_t *rgb) {
-    return 1 + NumLen((uint32_t)n) + 3 + NumLen((rgb[0] * 100u + 127u) / 255u) + 1 +
-           NumLen((rgb[1] * 100u + 127u) / 255u) + 1 + NumLen((rgb[2] * 100u + 127u) / 255u);
-}
-
-__global__ void __launch_bounds__(256) AssembleFrameKernel(SixelGeom g, SixelBatch b) {
-    const int f               = blockIdx.x;
+// One kernel, one workgroup per band (round 4: it was two -- a workgroup per frame that computed where everything
+// goes, 21 us of dependent global round trips by 64 workgroups, then the copy).  Where a band goes is a prefix over the
+// lengths in front of it: <= 256 palette entries and the frame's bands, a few hundred loads that EVERY band's
+// workgroup issues for itself (L2-resident, in flight together) and scans in LDS; band 0's workgroup also writes the
+// header, the palette and the tail.
+__global__ void __launch_bounds__(256) AssembleBandsKernel(SixelGeom g, SixelBatch b) {
+    const int band            = blockIdx.x;
+    const int f               = blockIdx.y;
     const int tid             = threadIdx.x;
     const SixelFrameScratch s = FrameScratch(b, g, f);
     char *out                 = b.out + (size_t)f * b.out_cap;
-    __shared__ uint32_t pal_off[kMaxColors + 1];
-    __shared__ uint32_t s_tmp[5], s_header;
+    __shared__ uint32_t s_tmp[5], s_at, s_elide;
     const int ncolors = s.meta[0];
-    // cursor mode string + DCS + raster attributes, by one thread
-    if (tid == 0) {
+    // cursor mode string + DCS + raster attributes: every workgroup needs their length, band 0's writes them
+    const char *cursor   = g.broken_cursor ? "\033[80l\033[?7730l\033[?8452h" : "\033[80h\033[?7730h\033[?8452l";
+    constexpr uint32_t kCursorLen = 21;  // (both strings)
+    const uint32_t n_hdr = kCursorLen + 3u + 5u + (uint32_t)NumLen((uint32_t)g.w) + 1u + (uint32_t)NumLen((uint32_t)g.h6);
+    if (band == 0 && tid == 0) {
         char tmp[96];
-        char *p            = tmp;
-        const char *cursor = g.broken_cursor ? "\033[80l\033[?7730l\033[?8452h"
-                                             : "\033[80h\033[?7730h\033[?8452l";
+        char *p = tmp;
         for (const char *c = cursor; *c; ++c) *p++ = *c;
         *p++ = '\033'; *p++ = 'P'; *p++ = 'q';
         *p++ = '"'; *p++ = '1'; *p++ = ';'; *p++ = '1'; *p++ = ';';
         p    = PutUInt(p, (uint32_t)g.w);
         *p++ = ';';
         p    = PutUInt(p, (uint32_t)g.h6);
-        const uint32_t n = (uint32_t)(p - tmp);
-        for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t i = 0; i < n_hdr; ++i)
             if (i < b.out_cap) out[i] = tmp[i];
-        s_header = n;
     }
-    // where every palette entry and every band goes: lengths in parallel, two scans (a single
-    // lane walking 256 colours and all bands is a chain of dependent global loads)
-    uint32_t pal_total;
-    const uint32_t my_pal = tid < ncolors ? (uint32_t)PaletteEntryLen(tid, s.palette + tid * 3) : 0u;
-    const uint32_t pal_at = BlockExclusiveScan(my_pal, s_tmp, &pal_total);  // (its barriers publish s_header)
-    const uint32_t bands0 = s_header + pal_total;
-    if (tid < ncolors) pal_off[tid] = s_header + pal_at;
-    {
-        // '#c' at the start of a band is elided when the previous band ended in the same colour
-        auto elided = [&](int band) -> uint32_t {
-            const int *m = s.band_meta + band * 4;
-            return band > 0 && m[1] >= 0 && m[1] == s.band_meta[(band - 1) * 4 + 2] ? (uint32_t)m[3] : 0u;
-        };
-        const int per = (g.bands + 255) / 256;
-        const int b0 = min(g.bands, tid * per), b1 = min(g.bands, b0 + per);
-        uint32_t mine = 0;
-        for (int band = b0; band < b1; ++band) mine += (uint32_t)s.band_meta[band * 4 + 0] - elided(band);
-        uint32_t bands_total;
-        uint32_t at = bands0 + BlockExclusiveScan(mine, s_tmp, &bands_total);
-        for (int band = b0; band < b1; ++band) {
-            const uint32_t elide     = elided(band);
-            s.band_off[band * 2 + 0] = at;
-            s.band_off[band * 2 + 1] = elide;
-            at += (uint32_t)s.band_meta[band * 4 + 0] - elide;
-        }
-        if (tid == 0) {
-            // ST + cursor suffix
-            const uint32_t end = bands0 + bands_total;
-            const char tail[3] = {'\033', '\\', g.broken_cursor ? '\n' : '\r'};
-            for (int i = 0; i < 3; ++i)
-                if (end + i < b.out_cap) out[end + i] = tail[i];
-            b.out_len[f] = (unsigned long long)end + 3ull;
-        }
-    }
-    if (tid < ncolors) {
+    // the palette's bytes
+    // (their total comes with the palette, from the median cut: only band 0's workgroup needs every entry's place)
+    const uint32_t bands0 = n_hdr + (uint32_t)s.meta[2];
+    const uint8_t *rgb    = s.palette + tid * 3;
+    uint32_t pal_at       = 0;
+    if (band == 0) pal_at = BlockExclusiveScan(tid < ncolors ? (uint32_t)PaletteEntryLen(tid, rgb) : 0u, s_tmp, nullptr);
+    if (band == 0 && tid < ncolors) {
         char tmp[24];
-        char *p            = tmp;
-        const uint8_t *rgb = s.palette + tid * 3;
+        char *p = tmp;
         *p++ = '#';
         p    = PutUInt(p, (uint32_t)tid);
         *p++ = ';'; *p++ = '2'; *p++ = ';';
@@ -2850,35 +2835,55 @@ __global__ void __launch_bounds__(256) AssembleFrameKernel(SixelGeom g, SixelBat
         p    = PutUInt(p, (rgb[1] * 100u + 127u) / 255u);
         *p++ = ';';
         p    = PutUInt(p, (rgb[2] * 100u + 127u) / 255u);
-        const uint32_t n = (uint32_t)(p - tmp), at = pal_off[tid];
+        const uint32_t n = (uint32_t)(p - tmp), at = n_hdr + pal_at;
         for (uint32_t i = 0; i < n; ++i)
             if (at + i < b.out_cap) out[at + i] = tmp[i];
     }
-}
-
-__global__ void __launch_bounds__(256) CopyBandsKernel(SixelGeom g, SixelBatch b) {
-    const int band            = blockIdx.x;
-    const int f               = blockIdx.y;
-    const SixelFrameScratch s = FrameScratch(b, g, f);
-    const char *src           = s.band_bytes + (size_t)band * g.band_cap;
-    char *out                 = b.out + (size_t)f * b.out_cap;
-    const uint32_t len        = (uint32_t)s.band_meta[band * 4 + 0];
-    const uint32_t at         = s.band_off[band * 2 + 0];
-    const uint32_t elide      = s.band_off[band * 2 + 1];
-    const uint32_t lead       = band > 0 ? 1u : 0u;  // the elided tag sits right after '-'
-    if (lead && threadIdx.x == 0 && (size_t)at < b.out_cap) out[at] = src[0];
+    // the bands in front of this one ('#c' at the start of a band is elided when the previous band ended in the same colour)
+    {
+        auto elided = [&](int k) -> uint32_t {
+            const int *m = s.band_meta + k * 4;
+            return k > 0 && m[1] >= 0 && m[1] == s.band_meta[(k - 1) * 4 + 2] ? (uint32_t)m[3] : 0u;
+        };
+        const int per = (g.bands + 255) / 256;
+        const int b0 = min(g.bands, tid * per), b1 = min(g.bands, b0 + per);
+        uint32_t mine = 0;
+        for (int k = b0; k < b1; ++k) mine += (uint32_t)s.band_meta[k * 4 + 0] - elided(k);
+        uint32_t bands_total;
+        uint32_t at = bands0 + BlockExclusiveScan(mine, s_tmp, &bands_total);
+        if (band >= b0 && band < b1) {  // the thread whose range holds this band
+            for (int k = b0; k < band; ++k) at += (uint32_t)s.band_meta[k * 4 + 0] - elided(k);
+            s_at    = at;
+            s_elide = elided(band);
+        }
+        if (band == 0 && tid == 0) {
+            // ST + cursor suffix
+            const uint32_t end = bands0 + bands_total;
+            const char tail[3] = {'\033', '\\', g.broken_cursor ? '\n' : '\r'};
+            for (int i = 0; i < 3; ++i)
+                if (end + i < b.out_cap) out[end + i] = tail[i];
+            b.out_len[f] = (unsigned long long)end + 3ull;
+        }
+    }
+    __syncthreads();
+    const char *src      = s.band_bytes + (size_t)band * g.band_cap;
+    const uint32_t len   = (uint32_t)s.band_meta[band * 4 + 0];
+    const uint32_t at    = s_at;
+    const uint32_t elide = s_elide;
+    const uint32_t lead  = band > 0 ? 1u : 0u;  // the elided tag sits right after '-'
+    if (lead && tid == 0 && (size_t)at < b.out_cap) out[at] = src[0];
     // the rest is one shifted copy: 16 bytes per lane (both ends unaligned), the last bytes one by one
     const uint32_t from = lead + elide, n = len > from ? len - from : 0u;
     const char *sp      = src + from;
     char *dp            = out + at + lead;
     const size_t room   = (size_t)at + lead < b.out_cap ? b.out_cap - ((size_t)at + lead) : 0;
     const uint32_t m    = (uint32_t)(n < room ? n : room);
-    for (uint32_t i = threadIdx.x * 16u; i + 16u <= m; i += 256u * 16u) {
+    for (uint32_t i = tid * 16u; i + 16u <= m; i += 256u * 16u) {
         uint32_t v[4];
         __builtin_memcpy(v, sp + i, 16);
         __builtin_memcpy(dp + i, v, 16);
     }
-    for (uint32_t i = (m & ~15u) + threadIdx.x; i < m; i += 256u) dp[i] = sp[i];
+    for (uint32_t i = (m & ~15u) + tid; i < m; i += 256u) dp[i] = sp[i];
 }
 
 }  // namespace
@@ -3186,8 +3191,7 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
             hipLaunchKernelGGL((BandNodesKernel<false, kBandLanes>), dim3(g.bands, nfr), dim3(kBandLanes), nodes_lds, gs, g, gb);
         hipLaunchKernelGGL(BandPackKernel, dim3((g.bands * nfr + 3) / 4), dim3(256), 0, gs, g, gb, nfr);
         hipLaunchKernelGGL(BandEmitKernel, dim3(g.bands, nfr), dim3(256), emit_lds, gs, g, gb);
-        hipLaunchKernelGGL(AssembleFrameKernel, dim3(nfr), dim3(256), 0, gs, g, gb);
-        hipLaunchKernelGGL(CopyBandsKernel, dim3(g.bands, nfr), dim3(256), 0, gs, g, gb);
+        hipLaunchKernelGGL(AssembleBandsKernel, dim3(g.bands, nfr), dim3(256), 0, gs, g, gb);
         if (n_groups > 1) {
             TIMG_HIP_TRY(ctx, hipEventRecord(ctx->join_event[grp], gs));
             TIMG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->join_event[grp], 0));

@@ -2833,6 +2833,26 @@ __global__ void __launch_bounds__(256) BandEmitKernel(SixelGeom g, SixelBatch b)
 }
 
 // ---- K6 -------------------------------------------------------------------------------
+// digits of v (< 100 000) straight into out[at ...] (bounded by cap); returns their number.  No character array: a
+// `char tmp[]` filled through a moving pointer lives in SCRATCH memory, and a thread that formats a header through
+// it is a chain of scratch round trips (20 us for one thread of a workgroup, whatever the rest of the chip does).
+__device__ __forceinline__ uint32_t StoreUInt(char *out, size_t cap, uint32_t at, uint32_t v) {
+    const uint32_t n      = (uint32_t)NumLen(v);
+    const uint32_t dig[5] = {v / 10000u % 10u, v / 1000u % 10u, v / 100u % 10u, v / 10u % 10u, v % 10u};
+    uint32_t pos          = at;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        if ((uint32_t)(5 - j) <= n) {
+            if (pos < cap) out[pos] = (char)('0' + dig[j]);
+            ++pos;
+        }
+    return n;
+}
+__device__ __forceinline__ uint32_t StoreChar(char *out, size_t cap, uint32_t at, char c) {
+    if (at < cap) out[at] = c;
+    return 1;
+}
+
 // One kernel, one workgroup per band (round 4: it was two -- a workgroup per frame that computed where everything
 // goes, 21 us of dependent global round trips by 64 workgroups, then the copy).  Where a band goes is a prefix over the
 // lengths in front of it: <= 256 palette entries and the frame's bands, a few hundred loads that EVERY band's
@@ -2849,18 +2869,16 @@ __global__ void __launch_bounds__(256) AssembleBandsKernel(SixelGeom g, SixelBat
     // cursor mode string + DCS + raster attributes: every workgroup needs their length, band 0's writes them
     const char *cursor   = g.broken_cursor ? "\033[80l\033[?7730l\033[?8452h" : "\033[80h\033[?7730h\033[?8452l";
     constexpr uint32_t kCursorLen = 21;  // (both strings)
-    const uint32_t n_hdr = kCursorLen + 3u + 5u + (uint32_t)NumLen((uint32_t)g.w) + 1u + (uint32_t)NumLen((uint32_t)g.h6);
+    const uint32_t n_hdr = kCursorLen + 8u + (uint32_t)NumLen((uint32_t)g.w) + 1u + (uint32_t)NumLen((uint32_t)g.h6);
+    if (band == 0 && tid < (int)kCursorLen + 8 && (size_t)tid < b.out_cap) {  // (a lane per fixed character)
+        const char dcs[8] = {'\033', 'P', 'q', '"', '1', ';', '1', ';'};
+        out[tid]          = tid < (int)kCursorLen ? cursor[tid] : dcs[tid - (int)kCursorLen];
+    }
     if (band == 0 && tid == 0) {
-        char tmp[96];
-        char *p = tmp;
-        for (const char *c = cursor; *c; ++c) *p++ = *c;
-        *p++ = '\033'; *p++ = 'P'; *p++ = 'q';
-        *p++ = '"'; *p++ = '1'; *p++ = ';'; *p++ = '1'; *p++ = ';';
-        p    = PutUInt(p, (uint32_t)g.w);
-        *p++ = ';';
-        p    = PutUInt(p, (uint32_t)g.h6);
-        for (uint32_t i = 0; i < n_hdr; ++i)
-            if (i < b.out_cap) out[i] = tmp[i];
+        uint32_t at = kCursorLen + 8u;
+        at += StoreUInt(out, b.out_cap, at, (uint32_t)g.w);
+        at += StoreChar(out, b.out_cap, at, ';');
+        at += StoreUInt(out, b.out_cap, at, (uint32_t)g.h6);
     }
     // the palette's bytes
     // (their total comes with the palette, from the median cut: only band 0's workgroup needs every entry's place)
@@ -2869,19 +2887,17 @@ __global__ void __launch_bounds__(256) AssembleBandsKernel(SixelGeom g, SixelBat
     uint32_t pal_at       = 0;
     if (band == 0) pal_at = BlockExclusiveScan(tid < ncolors ? (uint32_t)PaletteEntryLen(tid, rgb) : 0u, s_tmp, nullptr);
     if (band == 0 && tid < ncolors) {
-        char tmp[24];
-        char *p = tmp;
-        *p++ = '#';
-        p    = PutUInt(p, (uint32_t)tid);
-        *p++ = ';'; *p++ = '2'; *p++ = ';';
-        p    = PutUInt(p, (rgb[0] * 100u + 127u) / 255u);
-        *p++ = ';';
-        p    = PutUInt(p, (rgb[1] * 100u + 127u) / 255u);
-        *p++ = ';';
-        p    = PutUInt(p, (rgb[2] * 100u + 127u) / 255u);
-        const uint32_t n = (uint32_t)(p - tmp), at = n_hdr + pal_at;
-        for (uint32_t i = 0; i < n; ++i)
-            if (at + i < b.out_cap) out[at + i] = tmp[i];
+        uint32_t at = n_hdr + pal_at;
+        at += StoreChar(out, b.out_cap, at, '#');
+        at += StoreUInt(out, b.out_cap, at, (uint32_t)tid);
+        at += StoreChar(out, b.out_cap, at, ';');
+        at += StoreChar(out, b.out_cap, at, '2');
+        at += StoreChar(out, b.out_cap, at, ';');
+        at += StoreUInt(out, b.out_cap, at, (rgb[0] * 100u + 127u) / 255u);
+        at += StoreChar(out, b.out_cap, at, ';');
+        at += StoreUInt(out, b.out_cap, at, (rgb[1] * 100u + 127u) / 255u);
+        at += StoreChar(out, b.out_cap, at, ';');
+        at += StoreUInt(out, b.out_cap, at, (rgb[2] * 100u + 127u) / 255u);
     }
     // the bands in front of this one ('#c' at the start of a band is elided when the previous band ended in the same colour)
     {
@@ -2903,9 +2919,9 @@ __global__ void __launch_bounds__(256) AssembleBandsKernel(SixelGeom g, SixelBat
         if (band == 0 && tid == 0) {
             // ST + cursor suffix
             const uint32_t end = bands0 + bands_total;
-            const char tail[3] = {'\033', '\\', g.broken_cursor ? '\n' : '\r'};
-            for (int i = 0; i < 3; ++i)
-                if (end + i < b.out_cap) out[end + i] = tail[i];
+            StoreChar(out, b.out_cap, end, '\033');
+            StoreChar(out, b.out_cap, end + 1, '\\');
+            StoreChar(out, b.out_cap, end + 2, g.broken_cursor ? '\n' : '\r');
             b.out_len[f] = (unsigned long long)end + 3ull;
         }
     }

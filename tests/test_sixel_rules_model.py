@@ -138,3 +138,40 @@ def test_one_pass_bookkeeping_splits_what_the_sequential_replay_splits():
         log_a, nb_a = _sequential(slots_a, nb, limit)
         log_b, nb_b = _one_pass(slots_b, nb, limit)
         assert log_a == log_b and nb_a == nb_b, trial
+
+
+def test_threshold_picks_are_the_head_of_the_list():
+    """pick(): every lane's largest unprepared slot word is ranked among the 64 lane maxima, the word of rank P - 1 is
+    the threshold, every unprepared word at or above it is picked.  Claim: the picks are exactly the first |picks|
+    unprepared boxes of the list (descending words), P <= |picks| <= 4 P, and the fallback P = max(1, room / 4) fits."""
+    rng = random.Random(5)
+    for trial in range(400):
+        n = rng.randint(1, 256)
+        words = [0] * 256                       # slot q * 64 + lane  ->  lane-major: lane = slot & 63
+        for slot in rng.sample(range(256), n):
+            words[slot] = rng.randint(1, 1 << 27)
+        while len({w for w in words if w}) != n:  # (keys are distinct)
+            words = [w + (i if w else 0) for i, w in enumerate(words)]
+        lane_max = [max(words[q * 64 + lane] for q in range(4)) for lane in range(64)]
+        order = sorted((w for w in words if w), reverse=True)
+        room = rng.randint(1, 64)
+        for P in (min(40, room), max(1, room // 4)):
+            ranked = sorted((m for m in lane_max if m), reverse=True)
+            thr = ranked[P - 1] if len(ranked) >= P else 1
+            picks = sorted((w for w in words if w >= thr and w), reverse=True)
+            assert picks == order[:len(picks)]
+            assert min(P, len(ranked)) <= len(picks) <= 4 * P
+        assert len(picks) <= max(room, 1)  # (the second choice of P: at most four boxes a lane)
+
+
+def test_index_rows_make_every_group_of_eight_aligned():
+    """IndexRow(): pixel x of row r lives at byte r * stride + 2 (r & 3) + x.  The diffusion's lane pair rl = r mod 32
+    works on column t + k - 2 rl at step t + k and has the indices of columns t - 8 - 2 rl ... t - 1 - 2 rl complete at the
+    last step of a block of eight (t a multiple of 8): their bytes start at t - 8 - 8 (rl >> 2), a multiple of eight for
+    every row -- one aligned 8-byte store per lane, all lanes in the same step."""
+    for r in range(0, 96):
+        rl = r % 32
+        for t in range(0, 200, 8):
+            first_px = t - 8 - 2 * rl
+            byte = 2 * (r & 3) + first_px
+            assert byte == t - 8 - 8 * (rl >> 2) and byte % 8 == 0

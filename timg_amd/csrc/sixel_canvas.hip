@@ -1312,8 +1312,8 @@ constexpr int kDitherAbl = TIMG_DITHER_ABL;
 // The helper waves (flusher, fetcher) share their SIMDs with diffusing waves: what they issue, the diffusion does not
 // (every row waits for the one above it: the slowest wave sets the pace).  Polling every 128 clocks and moving a
 // boundary row column by column they cost a 64-frame batch 4 % (profiles/r4/dither_ablation.txt); they nap
-// g.helper_naps x 128 clocks between polls and move pieces of >= g.helper_batch columns -- the launch chooses: long
-// naps where a frame has few parts (a part boundary then lags by the piece), short ones where it has many.
+// g.helper_naps x 128 clocks between polls and move pieces of >= g.helper_batch columns -- the launch chooses: longer
+// naps where a frame has few parts (a part boundary then lags by the piece), shorter ones where it has many.
 __device__ __forceinline__ void HelperNap(int naps) {
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(2);
 }
@@ -3130,8 +3130,10 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
             g.helper_batch = hb;
             g.helper_naps  = hn;
         } else {
-            g.helper_batch = dither_parts <= 6 ? 16 : 1;
-            g.helper_naps  = dither_parts <= 6 ? 16 : 1;
+            // (profiles/r4/dither_helpers.txt: 64 frames x 4 parts 347 us at 4,4 -- 350 at 8,8, 356 at 16,16, 366 at 32,32;
+            // one frame x 16 parts: the step 0.63 ms at 2,2 against 0.64 at 1,1)
+            g.helper_batch = dither_parts <= 6 ? 4 : 2;
+            g.helper_naps  = dither_parts <= 6 ? 4 : 2;
         }
     }
     const char *pix_env = getenv("TIMG_HIP_DITHER_PIX");

@@ -347,8 +347,13 @@ static std::string RunGridLikeTimg(int fd, size_t queue_len, int columns, bool s
 static void CheckGridLikeTimg() {
     timg_stub_sixel_set_lookup_mode(1);
     for (int kind = 0; kind < 2; ++kind) {      // 0: block canvases, 1: sixel canvases
-        for (size_t queue_len : {4, 9, 2}) {    // 4: src/timg.cc:972; 9: a whole row of four
-            const int columns = 4;
+        // 4: src/timg.cc:972; 9: a whole row of four; 129: what a whole 8x8 grid would need -- with rows of four (the
+        // queue is never the bound) and with rows of twenty (longer than the twins' batch cap: a row is cut into
+        // batches, HipSixelCanvas BatchCap)
+        const struct { size_t queue_len; int columns; } kCases[] = {{4, 4}, {9, 4}, {2, 4}, {129, 4}, {129, 20}};
+        for (const auto &kc : kCases) {
+            const size_t queue_len = kc.queue_len;
+            const int columns      = kc.columns;
             std::string streams[2];
             for (int twin = 0; twin < 2; ++twin) {
                 const int fd = memfd_create("grid", 0);
@@ -370,8 +375,8 @@ static void CheckGridLikeTimg() {
                 close(fd);
             }
             CHECK(streams[0] == streams[1] && streams[0].size() > 10000,
-                  "grid like timg.cc, %s canvases, queue %zu: %zu (reference) vs %zu bytes", kind ? "sixel" : "block",
-                  queue_len, streams[0].size(), streams[1].size());
+                  "grid like timg.cc, %s canvases, queue %zu, %d columns: %zu (reference) vs %zu bytes", kind ? "sixel" : "block",
+                  queue_len, columns, streams[0].size(), streams[1].size());
             // the cursor is switched on again at the very end
             CHECK(streams[1].size() > 6 && streams[1].rfind("\033[?25h") != std::string::npos &&
                       streams[1].rfind("\033[?25h") > streams[1].rfind("\033[?25l"),

@@ -24,7 +24,12 @@ import re
 import sys
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+# Accumulation registers (the matrix kernel's ring since round 5 lives in a[..], named ONLY inside asm statements): they are
+# tracked in the same sets as the vector registers, numbered from AGPR_BASE.
+AGPR_BASE = 1000
+AREG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
 LOAD = re.compile(r"global_load_dwordx[24] v\[(\d+):(\d+)\]")  # (x2: the sixel diffusion's pixel pairs)
+LOAD_A = re.compile(r"global_load_dwordx4 a\[(\d+):(\d+)\]")
 LOAD1 = re.compile(r"global_load_(?:dword|ubyte) v(\d+),")  # (the sixel diffusion's one-pixel ring)
 WAIT = re.compile(r"s_waitcnt vmcnt\(\d+\) ; ring (.*)")
 
@@ -36,6 +41,11 @@ def regs_of(text):
             out.add(int(m.group(1)))
         else:
             out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    for m in AREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(AGPR_BASE + int(m.group(1)))
+        else:
+            out.update(range(AGPR_BASE + int(m.group(2)), AGPR_BASE + int(m.group(3)) + 1))
     return out
 
 
@@ -61,6 +71,11 @@ def parse_blocks(lines):
             m = LOAD.match(code)
             if m:
                 blocks[-1].ops.append((no, "load", (int(m.group(1)), int(m.group(2)))))
+                if code.endswith("; reserved"):
+                    blocks[-1].ops.append((no, "reserve", (int(m.group(1)), int(m.group(2)))))
+            m = LOAD_A.match(code)
+            if m:
+                blocks[-1].ops.append((no, "load", (AGPR_BASE + int(m.group(1)), AGPR_BASE + int(m.group(2)))))
             m = LOAD1.match(code)
             if m:
                 blocks[-1].ops.append((no, "load", (int(m.group(1)), int(m.group(1)))))
@@ -105,6 +120,8 @@ def transfer(state, op, report=None):
         return frozenset(t for t in state if not (set(range(t[0], t[1] + 1)) & payload))
     if kind == "waitall":
         return frozenset()
+    if kind == "reserve":
+        return state
     if report is not None and state:
         used = regs_of(payload)
         for lo, hi in state:
@@ -139,6 +156,19 @@ def check_kernel(lines):
         state = b.entry
         for op in b.ops:
             state = transfer(state, op, bad)
+    # a ring in accumulation registers belongs to the asm statements alone: no compiler-placed instruction may name one
+    # of its registers ANYWHERE in the kernel (in flight or not)
+    # ... and so does a ring in vector registers reserved from the compiler (loads marked "; reserved")
+    ring_agprs = set()
+    for b in blocks:
+        for _, kind, payload in b.ops:
+            if (kind == "load" and payload[0] >= AGPR_BASE) or kind == "reserve":
+                ring_agprs.update(range(payload[0], payload[1] + 1))
+    if ring_agprs:
+        for b in blocks:
+            for no, kind, payload in b.ops:
+                if kind == "instr" and regs_of(payload) & ring_agprs:
+                    bad.append((no, payload, "a reserved ring register (outside the asm statements)"))
     return loads, waits, bad
 
 

@@ -511,6 +511,20 @@ ScaleStreamKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch bat
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int kMSlots = 4;
+#ifdef TIMG_M_TRACE
+// (experiment build only) where a wave's time goes, s_memtime ticks summed over all waves:
+// [0] waiting for its source row, [1] decode + vertical products and sums, [2] staging a completed row + barrier,
+// [3] horizontal pass, [4] the barrier that frees the staging row, [5] waves, [6] prologue, [7] whole kernel
+__device__ unsigned long long g_mtrace[8];
+#define TIMG_M_MARK(ACC)                                        \
+    {                                                           \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        ACC += now_ - t_last;                                   \
+        t_last = now_;                                          \
+    }
+#else
+#define TIMG_M_MARK(ACC)
+#endif
 
 struct RowW {
     float w[kMSlots];  // weights of the matrix slots on this source row (0: idle)
@@ -655,7 +669,11 @@ __device__ __forceinline__ void HorizontalRowOpaque(const DevPlan &plan, const D
     uint8_t *dst_row = batch.dst + (size_t)f * batch.dst_frame_stride + (size_t)y * batch.dst_stride;
     for (int o = threadIdx.x; o < n_out; o += kThreads) {
         const int ox       = si.ox0 + o;
+#ifdef TIMG_HABL_NOAC  // (timing experiment, wrong bytes: no global load -- and no vmcnt(0) -- in the pass)
+        const AlphaCell ac = {1.0f, 0xff000000u};
+#else
         const AlphaCell ac = alpha_row[ox];  // (requested first: the tap loop hides it)
+#endif
         // (staged columns and weight groups are float4 slots: said out loud, or the 16-byte reads are split)
         const char *base   = reinterpret_cast<const char *>(
             __builtin_assume_aligned(reinterpret_cast<const char *>(stage_row) + hbase[o], 16));
@@ -732,12 +750,18 @@ template <int M, bool kOvf> struct MKernelShape {
     static constexpr int kWaves = !kOvf ? 4 : (M == kPremult) ? 2 : 3;
     static constexpr int kDepth = (M == kPremult && !kOvf) ? 3 : 4;  // source rows in flight per lane
     static constexpr int kStage = kWaves == 4 ? 1 : 2;              // staging rows
+    // rows in flight in registers reserved from the compiler (see the kernel's main loop); 0: named variables
+#ifdef TIMG_M_VRING
+    static constexpr int kRing = (M == kOpaque && !kOvf) ? TIMG_M_VRING : 0;
+#else
+    static constexpr int kRing = 0;
+#endif
+    static constexpr int kVgprCap = kRing ? 128 - 4 * kRing : 0;  // (0: no cap of its own)
 };
 template <int M, bool kOvf>
-__global__ void __launch_bounds__(kThreads)
-    __attribute__((amdgpu_waves_per_eu(MKernelShape<M, kOvf>::kWaves, MKernelShape<M, kOvf>::kWaves)))
-ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
-                   int *tile_state, int gen, int hrow, int hgroups) {
+__device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const StreamTables &tab, const MTables &mt,
+                                                 const DevBlend &blend, const FrameBatch &batch,
+                                                 int *tile_state, int gen, int hrow, int hgroups) {
     static_assert(M == kOpaque || M == kPremult, "three or four channels");
     constexpr int kCh = M == kOpaque ? 3 : 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -835,6 +859,11 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     bool ok       = true;
     int ev        = 0;
     int wa        = 0;  // A operand: lanes 0..3 hold the four slot weights (rewritten every row)
+#ifdef TIMG_M_TRACE
+    unsigned long long tr_wait = 0, tr_vert = 0, tr_stage = 0, tr_horiz = 0, tr_bar2 = 0, tr_pro = 0;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    unsigned long long t_last = t_begin;
+#endif
 
     const RowRec *rec_ptr = mt.rec + bi.sched;
     RowRec rec_next       = LoadConstant(rec_ptr);
@@ -951,6 +980,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #if defined(TIMG_MABL) && TIMG_MABL == 4
         return true;  // (ablation: loads + decode, no completion handling)
 #endif
+        TIMG_M_MARK(tr_vert)
         const int code = (ctl.flags >> 4) & 7;
         if (code == 0) return true;  // wave- and block-uniform
 
@@ -1020,6 +1050,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         if (M == kOpaque) ok = (amin >> 24) == 0xffu;
         if (__any(!ok) && (tid & 63) == 0) fail = 1;
         BlockSync();
+        TIMG_M_MARK(tr_stage)
         if (fail) return false;
 #if !defined(TIMG_MABL) || TIMG_MABL < 1
         if (M == kOpaque)
@@ -1028,7 +1059,9 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
         else
             HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
 #endif
+        TIMG_M_MARK(tr_horiz)
         if (kStageM == 1) BlockSync();  // the single staging row is free again
+        TIMG_M_MARK(tr_bar2)
         ++ev;
         return true;
     };
@@ -1046,6 +1079,60 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #endif
     static_assert(kDepth == 3 || kDepth == 4 || kDepth == 8, "ring written out for 3, 4 or 8 rows");
     u4v q0, q1, q2, q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = q4, q6 = q4, q7 = q4;
+    TIMG_M_MARK(tr_pro)
+    constexpr int kRingA = MKernelShape<M, kOvf>::kRing;  // rows in flight in RESERVED registers (0: the ring of named variables below)
+    static_assert(kRingA == 0 || kRingA == 4 || kRingA == 6, "written out for 4 or 6 rows in flight");
+    if constexpr (kRingA != 0) {
+        // The ring in vector registers the compiler does not allocate (amdgpu_num_vgpr caps ITS registers below them):
+        // a set is named only inside the asm statements here (load, wait, read-out), so no compiler-placed copy can
+        // touch a set in flight -- and a set is free the moment its four words are read out, so the request for the row
+        // kRingA steps ahead goes out BEFORE this row's arithmetic and before a completed row's horizontal pass: kRingA
+        // rows stay in flight through the whole step (the ring of named variables has kDepth - 1 while a row is worked on).
+#define TIMG_M_ISSUE_R(R0, R1, R2, R3)                                                                    \
+    {                                                                                                     \
+        const uint8_t *p = frame_lane + next_off;                                                         \
+        asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off ; reserved" : : "v"(p)                     \
+                     : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);                                     \
+        next_off = min(next_off + row_step_b, last_off);                                                  \
+    }
+#define TIMG_M_STEP_R(R0, R1, R2, R3, K)                                                                  \
+    if (left < K + 1) break;                                                                              \
+    {                                                                                                     \
+        uint4 qv;                                                                                         \
+        const uint8_t *p = frame_lane + next_off;                                                         \
+        asm volatile("s_waitcnt vmcnt(%5) ; ring v[" #R0 ":" #R3 "]\n\t"                                  \
+                     "v_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\t"                              \
+                     "v_mov_b32 %2, v" #R2 "\n\tv_mov_b32 %3, v" #R3 "\n\t"                              \
+                     "global_load_dwordx4 v[" #R0 ":" #R3 "], %4, off ; reserved"                          \
+                     : "=&v"(qv.x), "=&v"(qv.y), "=&v"(qv.z), "=&v"(qv.w)                                  \
+                     : "v"(p), "n"(kRingA - 1)                                                            \
+                     : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);                                     \
+        next_off = min(next_off + row_step_b, last_off);                                                  \
+        TIMG_M_MARK(tr_wait)                                                                              \
+        if (!row_step(qv, 0)) return;                                                                     \
+    }
+        TIMG_M_ISSUE_R(124, 125, 126, 127)
+        TIMG_M_ISSUE_R(120, 121, 122, 123)
+        TIMG_M_ISSUE_R(116, 117, 118, 119)
+        TIMG_M_ISSUE_R(112, 113, 114, 115)
+        if (kRingA == 6) {
+            TIMG_M_ISSUE_R(108, 109, 110, 111)
+            TIMG_M_ISSUE_R(104, 105, 106, 107)
+        }
+        for (int left = r1 - bi.r0 + 1; left > 0; left -= kRingA) {  // (rows still to do)
+            TIMG_M_STEP_R(124, 125, 126, 127, 0)
+            TIMG_M_STEP_R(120, 121, 122, 123, 1)
+            TIMG_M_STEP_R(116, 117, 118, 119, 2)
+            TIMG_M_STEP_R(112, 113, 114, 115, 3)
+            if (kRingA == 6) {
+                TIMG_M_STEP_R(108, 109, 110, 111, 4)
+                TIMG_M_STEP_R(104, 105, 106, 107, 5)
+            }
+        }
+#undef TIMG_M_STEP_R
+#undef TIMG_M_ISSUE_R
+        asm volatile("s_waitcnt vmcnt(0) ; ring all" : : : "memory");
+    } else {
     issue_next_row(q0);
     issue_next_row(q1);
     issue_next_row(q2);
@@ -1059,6 +1146,7 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 #define TIMG_M_STEP(Q, K)                                                              \
     if (left < K + 1) break;                                                           \
     asm volatile("s_waitcnt vmcnt(%1) ; ring %0" : "+v"(Q) : "n"(kDepth - 1) : "memory"); \
+    TIMG_M_MARK(tr_wait)                                                               \
     if (!row_step(make_uint4(Q.x, Q.y, Q.z, Q.w), 0)) return;                          \
     issue_next_row(Q);
     for (int left = r1 - bi.r0 + 1; left > 0; left -= kDepth) {  // (rows still to do)
@@ -1077,12 +1165,45 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
     }
     // (loads still in flight must land before their registers mean anything else)
     asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : : "memory");
+    }
 #undef TIMG_M_STEP
     if (M == kOpaque) ok = ok && (amin >> 24) == 0xffu;
     if (__any(!ok) && (tid & 63) == 0) fail = 1;
     BlockSync();
     if (fail == 0 && tid == 0) tile_state[tile] = gen;
+#ifdef TIMG_M_TRACE
+    if ((tid & 63) == 0) {
+        atomicAdd(&g_mtrace[0], tr_wait);
+        atomicAdd(&g_mtrace[1], tr_vert);
+        atomicAdd(&g_mtrace[2], tr_stage);
+        atomicAdd(&g_mtrace[3], tr_horiz);
+        atomicAdd(&g_mtrace[4], tr_bar2);
+        atomicAdd(&g_mtrace[5], 1ull);
+        atomicAdd(&g_mtrace[6], tr_pro);
+        atomicAdd(&g_mtrace[7], (unsigned long long)__builtin_readcyclecounter() - t_begin);
+    }
+#endif
 }
+
+template <int M, bool kOvf>
+__global__ void __launch_bounds__(kThreads)
+    __attribute__((amdgpu_waves_per_eu(MKernelShape<M, kOvf>::kWaves, MKernelShape<M, kOvf>::kWaves)))
+ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
+                   int *tile_state, int gen, int hrow, int hgroups) {
+    ScaleStreamMBody<M, kOvf>(plan, tab, mt, blend, batch, tile_state, gen, hrow, hgroups);
+}
+#ifdef TIMG_M_VRING
+// The instantiation whose ring lives in registers reserved from the compiler: amdgpu_num_vgpr (which wants a literal,
+// hence the specialisation) caps the compiler's own registers below the ring's.
+template <>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+    __attribute__((amdgpu_num_vgpr(128 - 4 * TIMG_M_VRING)))
+ScaleStreamMKernel<kOpaque, false>(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
+                                   int *tile_state, int gen, int hrow, int hgroups) {
+    static_assert(MKernelShape<kOpaque, false>::kWaves == 4, "the register budget above is four waves per SIMD");
+    ScaleStreamMBody<kOpaque, false>(plan, tab, mt, blend, batch, tile_state, gen, hrow, hgroups);
+}
+#endif
 
 // ===================================================================================
 // Horizontal-first plans (what stb picks e.g. for 8K -> 800x450 and 640x480 -> 67x50):
@@ -1999,3 +2120,15 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
 }
 
 }  // namespace timg_amd
+
+#ifdef TIMG_M_TRACE
+extern "C" int timg_hip_debug_mtrace(unsigned long long *out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(timg_amd::g_mtrace), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(timg_amd::g_mtrace), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -51,16 +51,32 @@ HipSixelCanvas::~HipSixelCanvas() {
     DeviceFrameConsumerDestroyed();
 }
 
+// Frames per device call, at most.  A held batch is ONE chain of kernels, one read-back and one hand-over of its
+// buffers, all of it behind the batch's LAST Send: with a queue long enough for a whole 8x8 grid (129) the twins used
+// to hold all 64 images back -- nothing was encoded while the sources were still being scaled, two of the three
+// encode workers never ran, and the run took 2.5x as long as with rows of 8 (17.4 against 45.1 Gpx/s, BENCH_r04).
+// Beyond ~16 frames a batch buys nothing on the device either (the chain's length is the diffusion's W + 2(H - 1)
+// dependent steps whatever the batch), so longer queues now mean MORE batches in flight, not longer ones.
+// (TIMG_HIP_TWIN_BATCH_CAP: tuning / the old behaviour for comparison.)
+static int BatchCap() {
+    static const int cap = []() {
+        const char *e = getenv("TIMG_HIP_TWIN_BATCH_CAP");
+        const int v   = e ? atoi(e) : 0;
+        return v > 0 ? v : 16;
+    }();
+    return cap;
+}
+
 void HipSixelCanvas::SetGridColumns(int columns) {
     Flush();
-    hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
+    hold_limit_ = std::min(HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len()), BatchCap());
     if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *c) { EncodeBatch(b, c); }, kEncodeWorkers));
 }
 
 void HipSixelCanvas::SetStreamHold(int frames) {
     Flush();
     const int by_queue = (int)write_sequencer_->max_queue_len();  // the writer's future + a full queue behind it
-    stream_hold_       = std::max(1, std::min(frames, by_queue));
+    stream_hold_       = std::max(1, std::min(std::min(frames, by_queue), BatchCap()));
     if (stream_hold_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *c) { EncodeBatch(b, c); }, kEncodeWorkers));
 }
 

@@ -542,6 +542,23 @@ struct RowRec {  // 48 bytes through the scalar cache per source row, from a poi
     float keep[kMSlots];  // 0 on the source row that STARTS an output row in the slot, else 1 (see the sums)
     RowCtl ctl;
 };
+// The opaque matrix kernel's decode, ONE instruction per colour byte.  stb's sample is d = RN(float(u8) * RN(1/255))
+// (stb_image_resize2.h:8300-8321), so far a v_cvt_f32_ubyteN and half a v_pk_mul_f32 per byte.  A multiply with an SDWA
+// byte select reads the byte AS THE BITS of a float: the denormal u * 2^-149, exact (the kernels run with fp32 denormals
+// on: .amdhsa_float_denorm_mode_32 3).  Times K = RN(1/255) * 2^127 (exact, 2^149 would overflow) the exact product is
+// u * RN(1/255) * 2^-22, rounded once in the normal range: RN(u * RN(1/255)) * 2^-22 = d * 2^-22 bit for bit.  The vertical
+// product then takes the weight as w * 2^22 (MTables::rec22: the same records with scaled weights, exact): (d * 2^-22) * (w * 2^22) IS d * w as a real number, and
+// the matrix pipe rounds that real number once -- the same fp32 product, whatever its magnitude (denormal results
+// included: same value, same rounding).  scratch/ubench/vmix.hip checks the identity for all 256 bytes on the device.
+constexpr float kDecodeScaled = 0x1.010102p+119f;  // RN(1.0f / 255.0f) * 2^127
+constexpr float kWeightScale  = 4194304.0f;        // 2^22
+template <int BYTE>
+__device__ __forceinline__ float DecodeScaled(uint32_t word, float k) {
+    // (plain C++: the compiler's SDWA peephole folds the byte extraction into the multiply's operand select --
+    // v_mul_f32_sdwa ... src0_sel:BYTE_n -- and schedules it like any other instruction; check_ring_isa.py counts them)
+    return __uint_as_float((word >> (8 * BYTE)) & 0xffu) * k;
+}
+
 // kOpaque: what the horizontal pass would compute in its alpha channel.  Every staged column of an all-opaque
 // tile carries the SAME alpha (the vertical weight sum of the row, a host constant), so the filtered alpha of
 // output column x is a function of (x, that constant) alone -- the host evaluates stb's even/odd chain for it
@@ -555,6 +572,7 @@ struct AlphaCell {
 struct MTables {
     const RowRec *rec;  // indexed like StreamTables::sched (BandInfo::sched + row - r0)
     const AlphaCell *alpha_tab;  // [distinct vertical alpha sums][out_w]
+    const RowRec *rec22;  // rec with every weight times 2^22 (exact): for samples decoded as d * 2^-22 (DecodeScaled)
 };
 
 // Horizontal pass of a completed row, every lane its own output column(s): weights as
@@ -859,13 +877,19 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
     bool ok       = true;
     int ev        = 0;
     int wa        = 0;  // A operand: lanes 0..3 hold the four slot weights (rewritten every row)
+    float kdec    = kDecodeScaled;
+    asm volatile("" : "+v"(kdec));  // (in a register for the whole tile: the SDWA form of DecodeScaled takes no literal)
 #ifdef TIMG_M_TRACE
     unsigned long long tr_wait = 0, tr_vert = 0, tr_stage = 0, tr_horiz = 0, tr_bar2 = 0, tr_pro = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
     unsigned long long t_last = t_begin;
 #endif
 
+#ifdef TIMG_M_SDWA
+    const RowRec *rec_ptr = ((M == kOpaque && !kOvf) ? mt.rec22 : mt.rec) + bi.sched;
+#else
     const RowRec *rec_ptr = mt.rec + bi.sched;
+#endif
     RowRec rec_next       = LoadConstant(rec_ptr);
     auto row_step = [&](const uint4 &q_in, int r) __attribute__((always_inline)) -> bool {
         uint4 q = q_in;
@@ -875,6 +899,11 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
             q.y = shift == 0 ? b2 : shift == 1 ? c : d2;
             q.z = shift == 0 ? c : d2;
         }
+#ifdef TIMG_M_SDWA
+        constexpr bool kScaledDecode = M == kOpaque && !kOvf;  // (the overflow row multiplies d on the VALU: it keeps d itself)
+#else
+        constexpr bool kScaledDecode = false;
+#endif
         const RowW rw    = rec_next.w;
         const RowCtl ctl = rec_next.ctl;
         // (keep0, keep1) (keep2, keep3) as scalar register pairs
@@ -910,7 +939,14 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
         for (int p0 = 0; p0 < kPix; p0 += kBatch) {
             if (p0) __builtin_amdgcn_sched_barrier(0);
             float d[kBatch][kCh];
-            if (M == kOpaque) {
+            if (kScaledDecode) {
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b) {
+                    d[b][0]               = DecodeScaled<0>(qs[p0 + b], kdec);
+                    d[b][1]               = DecodeScaled<1>(qs[p0 + b], kdec);
+                    d[b][kCh > 2 ? 2 : 0] = DecodeScaled<2>(qs[p0 + b], kdec);
+                }
+            } else if (M == kOpaque) {
                 // u8 * (1/255) for the six colour bytes of two pixels as three packed multiplies
                 static_assert(M != kOpaque || kBatch <= 2, "one or two pixels");
                 const uint32_t pa = qs[p0], pb = qs[p0 + (kBatch > 1 ? 1 : 0)];
@@ -1779,13 +1815,18 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
             }
         }
     }
-    const size_t o_atab   = align(o_recs + recs.size() * sizeof(RowRec));
+    std::vector<RowRec> recs22 = recs;
+    for (RowRec &r : recs22)
+        for (int k = 0; k < kMSlots; ++k) r.w.w[k] = r.w.w[k] * kWeightScale;
+    const size_t o_recs22 = align(o_recs + recs.size() * sizeof(RowRec));
+    const size_t o_atab   = align(o_recs22 + recs22.size() * sizeof(RowRec));
     const size_t total    = align(o_atab + atab.size() * sizeof(AlphaCell) + 16);
     std::vector<char> host(total, 0);
     memcpy(&host[o_strips], strips.data(), strips.size() * sizeof(StripInfo));
     memcpy(&host[o_bands], bands.data(), bands.size() * sizeof(BandInfo));
     memcpy(&host[o_sched], sched.data(), sched.size() * sizeof(RowSched));
     memcpy(&host[o_recs], recs.data(), recs.size() * sizeof(RowRec));
+    memcpy(&host[o_recs22], recs22.data(), recs22.size() * sizeof(RowRec));
     if (!atab.empty()) memcpy(&host[o_atab], atab.data(), atab.size() * sizeof(AlphaCell));
     void *dev = nullptr;
     if (DevMalloc(&dev, total) != hipSuccess) return false;
@@ -1801,6 +1842,7 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     out->t.n_bands  = (int)bands.size();
     out->m.rec      = (const RowRec *)((char *)dev + o_recs);
     out->m.alpha_tab = (const AlphaCell *)((char *)dev + o_atab);
+    out->m.rec22    = (const RowRec *)((char *)dev + o_recs22);
     out->m_ok       = m_ok && wrows.size() == sched.size();
     out->m_ovf      = uses_ovf;
     out->band_rows  = band_rows;

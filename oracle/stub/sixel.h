@@ -18,6 +18,8 @@ extern "C" {
 #endif
 
 typedef int SIXELSTATUS;
+/* (src/timg-print-version.cc:121 prints it: a build of timg itself against this stub says what it is) */
+#define LIBSIXEL_VERSION "none: oracle/stub/sixel.h over the restatement"
 #define SIXEL_OK 0x0000
 #define SIXEL_FALSE 0x1000
 

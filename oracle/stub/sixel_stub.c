@@ -14,8 +14,18 @@ struct sixel_dither {
     int initialised_w, initialised_h;
 };
 
-static int g_lookup_mode = 0;
+/* lookup rule of the restatement behind sixel_encode: 0 libsixel's own first-hit cache (default), 1 the cell-centre
+ * table the device implements.  Set by the test drivers, or -- for a whole timg built over this stub
+ * (integration/Makefile), which has no call for it -- by TIMG_STUB_SIXEL_LOOKUP in the environment. */
+static int g_lookup_mode = -1;
 void timg_stub_sixel_set_lookup_mode(int mode) { g_lookup_mode = mode; }
+static int lookup_mode(void) {
+    if (g_lookup_mode < 0) {
+        const char *e = getenv("TIMG_STUB_SIXEL_LOOKUP");
+        g_lookup_mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_lookup_mode;
+}
 
 SIXELSTATUS sixel_output_new(sixel_output_t **output, sixel_write_function fn_write, void *priv,
                              sixel_allocator_t *allocator) {
@@ -60,7 +70,7 @@ SIXELSTATUS sixel_encode(unsigned char *pixels, int width, int height, int depth
     const long cap = 4096 + (long)width * height * 8;
     char *buf      = (char *)malloc((size_t)cap);
     if (!buf) return SIXEL_FALSE;
-    const long n = oracle_libsixel_encode(pixels, width, height, g_lookup_mode, buf, cap);
+    const long n = oracle_libsixel_encode(pixels, width, height, lookup_mode(), buf, cap);
     if (n < 0) {
         free(buf);
         return SIXEL_FALSE;

@@ -17,6 +17,11 @@ bool HipTwinsEnabled() {
     return !(v && v[0] == '0');
 }
 
+bool HipTwinTrace() {
+    static const bool on = getenv("TIMG_HIP_TWIN_TRACE") != nullptr;
+    return on;
+}
+
 timg_hip_ctx *SharedHipContext() {
     static std::once_flag once;
     static timg_hip_ctx *ctx = nullptr;
@@ -24,6 +29,9 @@ timg_hip_ctx *SharedHipContext() {
         if (!HipTwinsEnabled()) return;
         const char *d = getenv("TIMG_HIP_DEVICE");
         if (timg_hip_init(d ? atoi(d) : 0, &ctx) != TIMG_HIP_OK) ctx = nullptr;
+        if (HipTwinTrace())
+            fprintf(stderr, "timg_hip twins: device context %s%s\n", ctx ? "created" : "unavailable: ",
+                    ctx ? "" : timg_hip_last_error(nullptr));
     });
     return ctx;
 }

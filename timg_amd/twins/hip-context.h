@@ -27,6 +27,9 @@ timg_hip_ctx *LoaderHipContext();
 
 // GPU selection: TIMG_HIP_DEVICE=<n> (default 0), TIMG_HIP=0 disables.
 bool HipTwinsEnabled();
+// TIMG_HIP_TWIN_TRACE in the environment: the twins say on stderr what they do (the context, every scaler and canvas
+// they create, every held batch) -- how tests/test_timg_binary.py knows that a patched timg really ran on the device.
+bool HipTwinTrace();
 
 // Which resampling filter the twins ask the device for (timg_hip_scaler_create's `filter`).  A timg build
 // scales with ONE back-end, chosen at build time (src/image-scaler.cc:24-35: libswscale's SWS_BILINEAR when

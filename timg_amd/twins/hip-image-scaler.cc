@@ -1,5 +1,6 @@
 #include "hip-image-scaler.h"
 
+#include <cstdio>
 #include <cstring>
 
 #include "hip-context.h"
@@ -22,6 +23,7 @@ std::unique_ptr<ImageScaler> HipImageScaler::Create(int in_width, int in_height,
     // (recycled by geometry: the images of a grid share their plan, hip-context.h)
     timg_hip_scaler *s = HipScalerAcquire(ctx, in_width, in_height, fmt, out_width, out_height, HipScalerFilter());
     if (!s) return nullptr;
+    if (HipTwinTrace()) fprintf(stderr, "HipImageScaler: %dx%d -> %dx%d\n", in_width, in_height, out_width, out_height);
     return std::unique_ptr<ImageScaler>(new HipImageScaler(
         ctx, s, in_width, in_height, in_color_format, out_width, out_height));
 }
@@ -41,24 +43,39 @@ void HipImageScaler::Scale(Framebuffer &in, Framebuffer *out) {
 void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
                                      const Framebuffer::bgcolor_query &get_bg,
                                      rgba_t pattern, int pattern_width, int pattern_height) {
+    // Two phases ON THE DEVICE, one trip over PCIe each way: the frame is uploaded and scaled into device memory with
+    // the "is any pixel not opaque" flag (the laziness condition of src/framebuffer.cc:113-117: the getter may block
+    // on a terminal query, src/timg.cc:924-928, so it must not be called for nothing); only when the flag is up is
+    // the getter consulted and the scaled frame composed where it lies; then ONE download.  (Until round 5 the scaled
+    // frame went to the host, and a frame with a transparent pixel was uploaded and downloaded a second time by
+    // timg_hip_alpha_compose.)
+    if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ || out->height() != out_h_)
+        HipFatal(ctx_, "HipImageScaler::ScaleAndCompose: geometry");
+    const size_t bytes = (size_t)out_w_ * out_h_ * 4;
+    uint8_t *scaled    = (uint8_t *)HipPoolMalloc(ctx_, bytes);
+    if (!scaled) HipFatal(ctx_, "HipImageScaler::ScaleAndCompose: device memory");
     int transparent = 0;
     if (HipCall(ctx_, [&]() {
-            return timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0, (uint8_t *)out->begin(), 0, 0, 0,
-                                        1, nullptr, &transparent, nullptr);
+            return timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0, scaled, 0, 0, 1, 1, nullptr,
+                                        &transparent, nullptr);
         }) != TIMG_HIP_OK)
         HipFatal(ctx_, "HipImageScaler::ScaleAndCompose");
-    if (!get_bg || !transparent) return;  // src/framebuffer.cc:111,117: getter not consulted
-    timg_hip_blend b;
-    b.enabled   = 1;
-    b.bg        = PackColor(get_bg());
-    b.pattern   = PackColor(pattern);
-    b.pattern_w = pattern_width;
-    b.pattern_h = pattern_height;
-    b.start_row = 0;
-    if (HipCall(ctx_, [&]() {
-            return timg_hip_alpha_compose(ctx_, (uint8_t *)out->begin(), out_w_, out_h_, 0, 0, 0, 1, &b, nullptr, nullptr);
-        }) != TIMG_HIP_OK)
-        HipFatal(ctx_, "timg_hip_alpha_compose");
+    if (get_bg && transparent) {  // src/framebuffer.cc:111,117: otherwise the getter is not consulted
+        timg_hip_blend b;
+        b.enabled   = 1;
+        b.bg        = PackColor(get_bg());
+        b.pattern   = PackColor(pattern);
+        b.pattern_w = pattern_width;
+        b.pattern_h = pattern_height;
+        b.start_row = 0;
+        if (HipCall(ctx_, [&]() {
+                return timg_hip_alpha_compose(ctx_, scaled, out_w_, out_h_, 0, 0, 1, 1, &b, nullptr, nullptr);
+            }) != TIMG_HIP_OK)
+            HipFatal(ctx_, "timg_hip_alpha_compose");
+    }
+    if (timg_hip_memcpy_d2h(ctx_, out->begin(), scaled, bytes, nullptr) != TIMG_HIP_OK)
+        HipFatal(ctx_, "HipImageScaler::ScaleAndCompose: download");
+    HipPoolFree(ctx_, scaled);
 }
 
 }  // namespace timg

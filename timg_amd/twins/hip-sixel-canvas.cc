@@ -30,6 +30,7 @@ HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_po
       executor_(thread_pool),
       ctx_(SharedHipContext()) {
     if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
+    if (HipTwinTrace()) fprintf(stderr, "HipSixelCanvas: created\n");
     DeviceFrameConsumerCreated();
 }
 
@@ -92,7 +93,7 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     std::unique_ptr<char[]> bytes(new char[slot * n]);
     std::vector<size_t> lens(n);
     const int flags = EncodeFlags();
-    static const bool trace = getenv("TIMG_HIP_TWIN_TRACE") != nullptr;
+    const bool trace = HipTwinTrace();
     const auto t0 = std::chrono::steady_clock::now();
     // (HipCall: out of device memory -- the encoder's scratch grows with the batch -- is retried once after the twins'
     // caches have been given back)

@@ -21,6 +21,7 @@ HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool us
              (use_256_color ? TIMG_HIP_BLOCK_COLOR256 : 0)) {
     if (!ctx_ || timg_hip_block_canvas_create(ctx_, flags_, &canvas_) != TIMG_HIP_OK)
         HipFatal(ctx_, "HipUnicodeBlockCanvas");
+    if (HipTwinTrace()) fprintf(stderr, "HipUnicodeBlockCanvas: created (flags %d)\n", flags_);
     DeviceFrameConsumerCreated();
 }
 

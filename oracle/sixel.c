@@ -47,7 +47,13 @@ static unsigned int hash555(const unsigned char *p) {
 }
 
 /* Stable merge sorts: libsixel calls qsort(), whose order among equal keys is
- * unspecified; we pin it to "stable" (what glibc's merge-sort qsort gives). */
+ * unspecified; we pin it to "stable" (what glibc's merge-sort qsort gives).
+ * How much hangs on that choice is MEASURED, not assumed: oracle_sixel_set_tie_order() turns the order among equal
+ * keys around -- bit 0 for the colours of a box (equal in the split plane), bit 1 for boxes of equal weight -- i.e. the
+ * other extreme an unstable qsort could produce; tests/test_sixel_oracle.py bounds what that does to the palette and
+ * to the decoded picture.  0 (default) is the pinned order every other test and the device implement. */
+static int g_tie_order = 0;
+void oracle_sixel_set_tie_order(int mode) { g_tie_order = mode; }
 static void sort_colors_by_plane(hcolor_t *a, unsigned int n, int plane,
                                  hcolor_t *tmp) {
     if (n < 2) return;
@@ -56,7 +62,7 @@ static void sort_colors_by_plane(hcolor_t *a, unsigned int n, int plane,
     sort_colors_by_plane(a + h, n - h, plane, tmp);
     unsigned int i = 0, j = h, k = 0;
     while (i < h && j < n)
-        tmp[k++] = (a[j].c[plane] < a[i].c[plane]) ? a[j++] : a[i++];
+        tmp[k++] = ((g_tie_order & 1) ? a[j].c[plane] <= a[i].c[plane] : a[j].c[plane] < a[i].c[plane]) ? a[j++] : a[i++];
     while (i < h) tmp[k++] = a[i++];
     while (j < n) tmp[k++] = a[j++];
     memcpy(a, tmp, (size_t)n * sizeof(hcolor_t));
@@ -66,7 +72,7 @@ static void sort_boxes_by_sum_desc(box_t *b, unsigned int n) {
     for (unsigned int i = 1; i < n; i++) { /* stable insertion sort */
         box_t v        = b[i];
         unsigned int j = i;
-        while (j > 0 && b[j - 1].sum < v.sum) {
+        while (j > 0 && ((g_tie_order & 2) ? b[j - 1].sum <= v.sum : b[j - 1].sum < v.sum)) {
             b[j] = b[j - 1];
             j--;
         }

@@ -94,6 +94,10 @@ int oracle_sixel_quantize_trace(const uint8_t *rgba, int w, int h, int lookup_mo
  * the image had <= 256 distinct 15-bit colours. */
 int oracle_sixel_palette(const uint8_t *rgba, int w, int h, uint8_t *pal_rgb,
                          int *dither_off);
+/* libsixel sorts with qsort(): the order among equal keys is the C library's.  The restatement pins it (stable,
+ * mode 0); mode bits turn the order among equal keys around -- 1: colours equal in the split plane, 2: boxes of equal
+ * weight -- so that a test can MEASURE what the pin is worth (process-wide, not thread safe). */
+void oracle_sixel_set_tie_order(int mode);
 /* Independent sixel decoder: parses DCS q ... ST into RGBA (undrawn pixels
  * stay 0,0,0,0).  Returns 0 on success; w/h are the raster size found. */
 int oracle_sixel_decode(const char *data, long len, uint8_t *rgba_out,

@@ -191,6 +191,12 @@ class Oracle:
         assert rc == 0, rc
         return img[:h.value, :w.value].copy(), nc.value
 
+    def sixel_set_tie_order(self, mode: int):
+        """0: the pinned (stable) order among equal sort keys; bits 1 / 2 reverse it for colours / boxes."""
+        self.L.oracle_sixel_set_tie_order.argtypes = [c_int]
+        self.L.oracle_sixel_set_tie_order.restype = None
+        self.L.oracle_sixel_set_tie_order(mode)
+
     def sixel_palette(self, fb):
         fb = np.ascontiguousarray(fb)
         h, w = fb.shape[:2]

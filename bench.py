@@ -246,6 +246,9 @@ def main():
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip tests/twins/build/twin_bench (the C++ drop-in path as src/timg.cc drives it)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_alpha / d2h / batched_streams")
+    ap.add_argument("--sync-encode", action="store_true",
+                    help="sixel on one GPU: every step ends with timg_hip_sixel_encode's blocking read-back of the byte counts "
+                         "(rounds 1-4) instead of timg_hip_sixel_encode_async (two jobs alternate, counts read one step late)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the CPU sample")
     args = ap.parse_args()
@@ -404,7 +407,8 @@ def main():
         """n_steps passes of the hot path; with several ranks the outputs are gathered to rank 0
         in step order by this (the main) thread."""
         if not strong:
-            run_batched_streams(pipes, src, n_steps, n_pipes, 2 if force_gather else world, timed_gather, timed_events, record)
+            run_batched_streams(pipes, src, n_steps, n_pipes, 2 if force_gather else world, timed_gather, timed_events, record,
+                                async_encode=not args.sync_encode)
             return
         for _ in range(n_steps):  # a step = the whole sharded stream, chunk by chunk
             for k in range(n_launches_max):
@@ -547,6 +551,10 @@ def main():
                             + f"; {n_pipes} batch(es) in flight per GPU"),
             "pipelines": n_pipes,
             "pieces": pipe.pieces,
+            "encode_call": ("timg_hip_sixel_encode_async: a step is enqueued, its byte counts are read after the next step's "
+                            "launches (two jobs alternate)"
+                            if (pipe.can_async() and world == 1 and not force_gather and not strong and not args.sync_encode)
+                            else "blocking (the call returns the frames' byte counts)"),
             "scale_kernel": "streaming" if (info["streaming_ok"] and args.kernel != 1) else "generic",
             "pass_order": "vertical-first" if info["vertical_first"] else "horizontal-first",
         },

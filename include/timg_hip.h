@@ -245,6 +245,24 @@ void timg_hip_block_canvas_forget(timg_hip_block_canvas *c);
 
 size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
 
+
+/* The asynchronous form of timg_hip_sixel_encode (device-resident frames and output only).  SixelCanvas::Send hands
+ * the sequencer a FUTURE and returns (src/sixel-canvas.cc:128-154); a host that keeps a device busy wants the same
+ * from the library: timg_hip_sixel_encode returns the frames' byte counts, so every call ends with a blocking
+ * read-back, and the next batch's first kernel cannot be enqueued before it (measured: ~70 us of idle device per
+ * 1.5 ms step).  Here the call only ENQUEUES -- kernels, then a copy of the byte counts into the job's pinned words,
+ * then an event, all on `stream` -- and returns; timg_hip_sixel_encode_wait blocks until THAT call's counts have
+ * arrived and reports them (or the call's error) exactly as the synchronous form would.  The caller may enqueue
+ * further work -- the next batch's scale and encode included, with another job -- before it waits; one job holds one
+ * call at a time.  `out` must stay untouched until the wait returns; bytes are those of timg_hip_sixel_encode. */
+typedef struct timg_hip_sixel_job timg_hip_sixel_job;
+int timg_hip_sixel_job_create(timg_hip_ctx *ctx, int max_frames, timg_hip_sixel_job **out);
+void timg_hip_sixel_job_destroy(timg_hip_sixel_job *job);
+int timg_hip_sixel_encode_async(timg_hip_ctx *ctx, const uint8_t *fb_device, int w, int h, int stride,
+                                size_t frame_stride, int n_frames, int flags,
+                                const timg_hip_blend *pad_blend_or_null, char *out_device, size_t out_cap,
+                                void *stream, timg_hip_sixel_job *job);
+int timg_hip_sixel_encode_wait(timg_hip_sixel_job *job, size_t *out_len /* n_frames of the call */);
 /* ---- scale + compose + sixel encode in ONE call (device-resident batches) ------------------
  * What an ImageSource and a SixelCanvas do to a batch of frames back to back -- ImageScaler::Scale +
  * AlphaComposeBackground (src/qoi-image-source.cc:63-74), then SixelCanvas::Send (src/sixel-canvas.cc:

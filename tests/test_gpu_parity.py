@@ -311,6 +311,49 @@ def test_sixel_batch_device_resident(hip, oracle):
     hip.free(d)
 
 
+def test_sixel_async_encode_is_the_blocking_call_read_late(hip, oracle):
+    """timg_hip_sixel_encode_async / _wait (round 5): three batches of different sizes are ENQUEUED on one stream, on two
+    alternating jobs, before any byte count is looked at -- the scratch of call k is reused by call k + 1 in stream
+    order, the counts travel in the job's own pinned words -- and every frame is then byte for byte what the blocking
+    call and the restatement produce.  The reference contract kept: SixelCanvas::Send hands over a future and returns
+    (src/sixel-canvas.cc:128-154)."""
+    import torch
+    w, h = 200, 112
+    cap = hip.sixel_max_bytes(w, h)
+    batches = [np.stack([synth.make(kind, w, h, 60 + 7 * b + i) for i in range(n)])
+               for b, (kind, n) in enumerate([("photo", 5), ("noise", 2), ("alpha", 7)])]
+    blend = timg_amd.Blend.make(BG, PAT, 5, 3)
+    devs = [hip.upload(b) for b in batches]
+    outs = [torch.empty((len(b), cap), dtype=torch.uint8, device="cuda") for b in batches]
+    st = torch.cuda.Stream()
+    jobs = [hip.sixel_job(8), hip.sixel_job(8)]
+    # job 0 <- batch 0, job 1 <- batch 1: both in flight; batch 2 needs job 0 back first
+    hip.sixel_encode_async(jobs[0], devs[0], w, h, outs[0].data_ptr(), cap, n_frames=5, pad_blend=blend, stream=st.cuda_stream)
+    hip.sixel_encode_async(jobs[1], devs[1], w, h, outs[1].data_ptr(), cap, n_frames=2, pad_blend=blend, stream=st.cuda_stream)
+    with pytest.raises(timg_amd.TimgHipError):  # a job holds ONE call
+        hip.sixel_encode_async(jobs[0], devs[2], w, h, outs[2].data_ptr(), cap, n_frames=7, pad_blend=blend, stream=st.cuda_stream)
+    lens0 = hip.sixel_encode_wait(jobs[0], 5)
+    hip.sixel_encode_async(jobs[0], devs[2], w, h, outs[2].data_ptr(), cap, n_frames=7, pad_blend=blend, stream=st.cuda_stream)
+    lens1 = hip.sixel_encode_wait(jobs[1], 2)
+    lens2 = hip.sixel_encode_wait(jobs[0], 7)
+    with pytest.raises(timg_amd.TimgHipError):  # nothing in flight any more
+        hip.sixel_encode_wait(jobs[0], 7)
+    with pytest.raises(timg_amd.TimgHipError):  # more frames than the job was created for
+        hip.sixel_encode_async(jobs[1], devs[2], w, h, outs[2].data_ptr(), cap, n_frames=9, pad_blend=blend, stream=st.cuda_stream)
+    st.synchronize()
+    for b, (frames, lens, out) in enumerate(zip(batches, (lens0, lens1, lens2), outs)):
+        host = out.cpu().numpy()
+        blocking = hip.sixel_encode(devs[b], w, h, pad_blend=blend, n_frames=len(frames))
+        for i in range(len(frames)):
+            got = host[i, :lens[i]].tobytes()
+            assert got == blocking[i], (b, i)
+            assert got == oracle.sixel_encode(frames[i], BG, PAT, 5, 3, lookup_mode=1), (b, i)
+    for j in jobs:
+        hip.sixel_job_destroy(j)
+    for d in devs:
+        hip.free(d)
+
+
 @pytest.mark.parametrize("kind,w,h", [
     ("noise", 800, 450),   # > 8192 distinct colours: median cut runs on the global-memory table
     ("photo", 64, 1100),   # 1104 padded rows: the diffusion pipeline goes round three times (16 waves x 32 rows)

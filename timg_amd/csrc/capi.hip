@@ -22,7 +22,8 @@ int StreamShapeBits(const timg_hip_scaler *s);
 int SixelEncodeImpl(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride, size_t frame_stride,
                     int fb_on_device, int n_frames, int flags, const timg_hip_blend *pad_blend, char *out,
                     size_t out_cap, int out_on_device, size_t *out_len, void *stream, int pieces_req,
-                    const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms);
+                    const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms,
+                    timg_hip_sixel_job *job);
 }  // namespace timg_amd
 
 DevBlend MakeDevBlend(const timg_hip_blend *b) {
@@ -412,7 +413,7 @@ int timg_hip_scale_sixel_encode(timg_hip_ctx *ctx, timg_hip_scaler *s, const uin
                            : timg_amd::LaunchScaleGeneric(s->dev, db, batch, st);
     };
     return timg_amd::SixelEncodeImpl(ctx, scaled, p.out_w, p.out_h, 0, 0, 1, n_frames, sixel_flags, blend, out, out_cap,
-                                     out_on_device, out_len, stream, pieces, &scale_piece, scale_ms);
+                                     out_on_device, out_len, stream, pieces, &scale_piece, scale_ms, nullptr);
 }
 
 int timg_hip_alpha_compose(timg_hip_ctx *ctx, uint8_t *fb, int w, int h, int stride,

@@ -115,6 +115,18 @@ struct timg_hip_ctx {
     hipStream_t Stream(void *s) { return s ? (hipStream_t)s : stream; }
 };
 
+// One call of timg_hip_sixel_encode_async in flight: where its frames' byte counts land (pinned, + the device's error
+// word) and the event behind them.
+struct timg_hip_sixel_job {
+    timg_hip_ctx *ctx          = nullptr;
+    hipEvent_t done            = nullptr;
+    unsigned long long *len_h  = nullptr;  // max_frames + 1 words of pinned host memory
+    int max_frames             = 0;
+    int n                      = 0;        // frames of the call in flight
+    size_t out_cap             = 0;
+    bool pending               = false;
+};
+
 struct timg_hip_scaler {
     timg_hip_ctx *ctx = nullptr;
     timg_amd::ResamplePlan plan;

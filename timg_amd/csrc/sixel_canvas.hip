@@ -2976,8 +2976,9 @@ namespace timg_amd {
 int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride, size_t frame_stride,
                     int fb_on_device, int n_frames, int flags, const timg_hip_blend *pad_blend, char *out,
                     size_t out_cap, int out_on_device, size_t *out_len, void *stream, int pieces_req,
-                    const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms) {
-    if (!ctx || !fb || !out || !out_len || w <= 0 || h <= 0 || n_frames <= 0)
+                    const std::function<hipError_t(int, int, int, hipStream_t)> *before_piece, float *hook_ms,
+                    timg_hip_sixel_job *job) {
+    if (!ctx || !fb || !out || (!out_len && !job) || w <= 0 || h <= 0 || n_frames <= 0)
         return TIMG_HIP_ERR_ARG;
     if (flags & ~TIMG_HIP_SIXEL_BROKEN_CURSOR) return ctx->Fail(TIMG_HIP_ERR_ARG, "unknown sixel flags 0x%x", flags);
     if (w > kMaxSixelWidth)
@@ -3076,6 +3077,8 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_prow  = carve(nf * (size_t)w * 5 * sizeof(uint32_t));
     const size_t o_xwg   = carve(nf * (kDitherMaxParts - 1) * (size_t)XwgStride(w) * sizeof(uint32_t));
     const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
+    // (growing the scratch frees the old block: kernels of an earlier ASYNCHRONOUS call on this stream may still use it)
+    if (off > ctx->dev[5].bytes) TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
     char *base = (char *)ctx->dev[5].ptr;
     SixelBatch b;
@@ -3261,6 +3264,18 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     }
     TIMG_HIP_TRY(ctx, hipGetLastError());
 
+    if (job) {
+        // the asynchronous form: the frames' byte counts (and the device's error word) go to the JOB's pinned words
+        // behind an event on the caller's stream; nothing is waited for -- the caller may enqueue its next batch (the
+        // scratch is reused in stream order; the counts above were copied out before the next call's kernels run)
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(job->len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
+        TIMG_HIP_TRY(ctx, hipEventRecord(job->done, st));
+        job->n       = n_frames;
+        job->out_cap = out_cap;
+        job->pending = true;
+        return TIMG_HIP_OK;
+    }
+
     TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * (nf + 1)));
     unsigned long long *len_h = (unsigned long long *)ctx->pin[0].ptr;
     TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * (nf + 1),
@@ -3296,7 +3311,59 @@ extern "C" int timg_hip_sixel_encode(timg_hip_ctx *ctx, const uint8_t *fb, int w
                                      char *out, size_t out_cap, int out_on_device,
                                      size_t *out_len, void *stream) {
     return timg_amd::SixelEncodeImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, pad_blend, out,
-                                     out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr);
+                                     out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr, nullptr);
+}
+
+// ---- the asynchronous form (round 5): a step of a pipeline must not end with a blocking read-back ----
+extern "C" int timg_hip_sixel_job_create(timg_hip_ctx *ctx, int max_frames, timg_hip_sixel_job **out) {
+    if (!ctx || !out || max_frames <= 0) return TIMG_HIP_ERR_ARG;
+    TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    timg_hip_sixel_job *j = new timg_hip_sixel_job();
+    j->ctx        = ctx;
+    j->max_frames = max_frames;
+    hipError_t e  = hipHostMalloc((void **)&j->len_h, sizeof(unsigned long long) * ((size_t)max_frames + 1), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (j->len_h) (void)hipHostFree(j->len_h);
+        delete j;
+        return ctx->FailHip(e, "timg_hip_sixel_job_create");
+    }
+    *out = j;
+    return TIMG_HIP_OK;
+}
+extern "C" void timg_hip_sixel_job_destroy(timg_hip_sixel_job *j) {
+    if (!j) return;
+    if (j->pending) (void)hipEventSynchronize(j->done);  // (the copy into len_h must not land in freed memory)
+    if (j->done) (void)hipEventDestroy(j->done);
+    if (j->len_h) (void)hipHostFree(j->len_h);
+    delete j;
+}
+extern "C" int timg_hip_sixel_encode_async(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stride,
+                                           size_t frame_stride, int n_frames, int flags,
+                                           const timg_hip_blend *pad_blend, char *out, size_t out_cap, void *stream,
+                                           timg_hip_sixel_job *job) {
+    if (!ctx || !job || job->ctx != ctx) return TIMG_HIP_ERR_ARG;
+    if (job->pending) return ctx->Fail(TIMG_HIP_ERR_ARG, "timg_hip_sixel_encode_async: the job still holds a call that was not waited for");
+    if (n_frames > job->max_frames) return ctx->Fail(TIMG_HIP_ERR_ARG, "timg_hip_sixel_encode_async: %d frames, the job was created for %d", n_frames, job->max_frames);
+    return timg_amd::SixelEncodeImpl(ctx, fb, w, h, stride, frame_stride, 1, n_frames, flags, pad_blend, out, out_cap, 1,
+                                     nullptr, stream, 0, nullptr, nullptr, job);
+}
+extern "C" int timg_hip_sixel_encode_wait(timg_hip_sixel_job *job, size_t *out_len) {
+    if (!job || !out_len) return TIMG_HIP_ERR_ARG;
+    timg_hip_ctx *ctx = job->ctx;
+    if (!job->pending) return ctx->Fail(TIMG_HIP_ERR_ARG, "timg_hip_sixel_encode_wait: nothing to wait for");
+    TIMG_HIP_TRY(ctx, hipEventSynchronize(job->done));
+    job->pending = false;
+    if ((int)job->len_h[job->n] != 0)
+        return ctx->Fail(TIMG_HIP_ERR_DEVICE, "sixel diffusion: a workgroup gave up waiting for its neighbour");
+    size_t worst = 0;
+    for (int i = 0; i < job->n; ++i) {
+        out_len[i] = (size_t)job->len_h[i];
+        if (out_len[i] > worst) worst = out_len[i];
+    }
+    if (worst > job->out_cap)
+        return ctx->Fail(TIMG_HIP_ERR_SMALL, "frame needs %zu bytes, out_cap is %zu", worst, job->out_cap);
+    return TIMG_HIP_OK;
 }
 #else
 // TEST-ONLY (libtimg_hip_debug.so): timg_hip_sixel_encode with libsixel's own lookup rule -- a 15-bit cell answers with
@@ -3309,6 +3376,6 @@ extern "C" int timg_hip_debug_sixel_encode_first_hit(timg_hip_ctx *ctx, const ui
                                                      const timg_hip_blend *pad_blend, char *out, size_t out_cap,
                                                      int out_on_device, size_t *out_len, void *stream) {
     return timg_amd::SixelEncodeFirstHitImpl(ctx, fb, w, h, stride, frame_stride, fb_on_device, n_frames, flags, pad_blend,
-                                             out, out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr);
+                                             out, out_cap, out_on_device, out_len, stream, 0, nullptr, nullptr, nullptr);
 }
 #endif

@@ -104,6 +104,12 @@ def load_library():
     L.timg_hip_sixel_encode.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int,
                                         c_int, POINTER(Blend), vp, c_size_t, c_int,
                                         POINTER(c_size_t), vp]
+    L.timg_hip_sixel_job_create.argtypes = [vp, c_int, POINTER(vp)]
+    L.timg_hip_sixel_job_destroy.argtypes = [vp]
+    L.timg_hip_sixel_job_destroy.restype = None
+    L.timg_hip_sixel_encode_async.argtypes = [vp, vp, c_int, c_int, c_int, c_size_t, c_int, c_int, POINTER(Blend), vp,
+                                              c_size_t, vp, vp]
+    L.timg_hip_sixel_encode_wait.argtypes = [vp, POINTER(c_size_t)]
     L.timg_hip_scale_sixel_encode.argtypes = [vp, vp, vp, c_int, c_size_t, vp, c_int, POINTER(Blend), c_int, vp, c_size_t,
                                               c_int, POINTER(c_size_t), c_int, POINTER(ctypes.c_float), vp]
     L.timg_hip_png_bytes.argtypes = [c_int, c_int, c_int]
@@ -389,6 +395,27 @@ class TimgHip:
             byref(pad_blend) if pad_blend is not None else None, c_void_p(out.ctypes.data), c_size_t(out_cap), c_int(0),
             lens, None))
         return [out[i * out_cap:i * out_cap + lens[i]].tobytes() for i in range(n_frames)]
+
+    # -- the asynchronous form: enqueue now, read the byte counts later (timg_hip_sixel_encode_async) --
+    def sixel_job(self, max_frames: int):
+        j = c_void_p()
+        self._check(self.L.timg_hip_sixel_job_create(self.ctx, max_frames, byref(j)))
+        return j
+
+    def sixel_job_destroy(self, job):
+        self.L.timg_hip_sixel_job_destroy(job)
+
+    def sixel_encode_async(self, job, fb_dev: int, w, h, out_dev: int, out_cap, n_frames=1, flags=0,
+                           pad_blend: Blend | None = None, stride=0, frame_stride=0, stream=None):
+        self._check(self.L.timg_hip_sixel_encode_async(self.ctx, c_void_p(int(fb_dev)), w, h, stride, frame_stride, n_frames,
+                                                       flags, byref(pad_blend) if pad_blend is not None else None,
+                                                       c_void_p(int(out_dev)), out_cap,
+                                                       c_void_p(stream) if stream else None, job))
+
+    def sixel_encode_wait(self, job, n_frames: int):
+        lens = (c_size_t * n_frames)()
+        self._check(self.L.timg_hip_sixel_encode_wait(job, lens))
+        return list(lens)
 
     def sixel_encode(self, fb, w, h, flags=0, pad_blend: Blend | None = None, n_frames=1,
                      out=None, out_cap=None, stride=0, frame_stride=0, stream=None):

@@ -72,6 +72,30 @@ class GridPipeline:
         self.lengths = lens
         return lens
 
+    # -- sixel, asynchronous: a step is ENQUEUED (scale + encode + the byte counts' copy behind an event), its counts
+    # are read when the caller asks for them -- usually after the next step has been enqueued, so that the device
+    # never waits for the host between steps (timg_hip_sixel_encode_async; include/timg_hip.h)
+    def can_async(self):
+        return self.mode == "sixel" and not self.fused
+
+    def encode_begin(self, slot: int = 0):
+        assert self.can_async()
+        if not hasattr(self, "_jobs"):
+            self._jobs = {}
+        if slot not in self._jobs:
+            self._jobs[slot] = self.hip.sixel_job(self.n)
+        self.hip.sixel_encode_async(self._jobs[slot], self.scaled.data_ptr(), self.out_w, self.out_h,
+                                    self.out.data_ptr(), self.cap, n_frames=self.n, pad_blend=self.blend,
+                                    stream=self.stream_ptr())
+
+    def begin(self, src: torch.Tensor, slot: int = 0):
+        self.scale(src)
+        self.encode_begin(slot)
+
+    def finish(self, slot: int = 0):
+        self.lengths = self.hip.sixel_encode_wait(self._jobs[slot], self.n)
+        return self.lengths
+
     def step(self, src: torch.Tensor):
         if not self.fused:
             self.scale(src)
@@ -95,11 +119,14 @@ class GridPipeline:
         return self.out[i, :self.lengths[i]].cpu().numpy().tobytes()
 
     def close(self):
+        for j in getattr(self, "_jobs", {}).values():
+            self.hip.sixel_job_destroy(j)
+        self._jobs = {}
         self.scaler.close()
 
 
 def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, timed_events=None,
-                        record_event=None):
+                        record_event=None, async_encode=True):
     """n_steps passes of the hot path over `src`, step k on pipeline k % n_pipes, every pipeline
     driven by its own host thread (one batch in flight per pipeline).  With several ranks the
     variable-length outputs are handed to `gather(payload, lengths)` by the CALLING thread in
@@ -118,6 +145,8 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
     def worker(i):
         try:
             p = pipes[i]
+            # (with several ranks the gather needs a step's byte counts before the next step starts: synchronous there)
+            use_async = async_encode and world == 1 and getattr(p, "can_async", lambda: False)()
             for k in range(i, n_steps, n_pipes):
                 if world > 1 and k >= n_pipes:
                     consumed[k - n_pipes].wait()
@@ -125,6 +154,12 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
                 if getattr(p, "fused", False):  # one call; the library times its scale kernels itself
                     p.step(src)
                     e1 = None
+                elif use_async:
+                    # the step is only ENQUEUED: its byte counts are read after the NEXT step of this pipeline has been
+                    # enqueued behind it (two jobs alternate), so the stream never runs dry between steps
+                    p.scale(src)
+                    e1 = record_event(p.stream) if record_event else None
+                    p.encode_begin(slot=(k // n_pipes) & 1)
                 else:
                     p.scale(src)
                     e1 = record_event(p.stream) if record_event else None
@@ -132,6 +167,11 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
                 e2 = record_event(p.stream) if record_event else None
                 if timed_events is not None and record_event:
                     timed_events.append((e0, e1, e2, getattr(p, "last_scale_ms", None)))
+                if use_async:
+                    if k - n_pipes >= i:
+                        p.finish(slot=((k - n_pipes) // n_pipes) & 1)
+                    if k + n_pipes >= n_steps:  # this pipeline's last step
+                        p.finish(slot=(k // n_pipes) & 1)
                 done[k].set()
         except Exception as exc:  # surface worker failures instead of hanging the gather loop
             errors.append(exc)

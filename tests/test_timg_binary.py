@@ -189,3 +189,17 @@ def test_patched_timg_sixel_is_the_reference_sixel_canvas_over_the_same_encoder(
         assert "HipSixelCanvas: created" in err and "timg_hip twins: device context created" in err, err[-1500:]
         assert b"\x1bPq" in want and len(want) > 20000
         assert got == want, (name, len(got), len(want))
+
+
+@pytest.mark.gpu
+@needs_binaries
+@pytest.mark.parametrize("fail_at", [1, 3, 6])
+def test_patched_timg_survives_a_device_failure(fail_at, files, tmp_path):
+    """TIMG_HIP_FAIL_CALL=k: the k-th device call of the run fails.  The patched timg says once that it continues on the
+    CPU and still writes the reference's bytes (still images: no frame differences in the stream)."""
+    args, names = CASES["grid_2x2_titles"]
+    paths = [files[n] for n in names]
+    want, _ = run(REF_BIN, args + paths, str(tmp_path / "ref.txt"))
+    got, err = run(HIP_BIN, args + paths, str(tmp_path / "hip.txt"), {"TIMG_HIP_FAIL_CALL": str(fail_at)})
+    assert err.count("continuing on the CPU") == 1, err[-1500:]
+    assert got == want

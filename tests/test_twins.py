@@ -110,3 +110,23 @@ def test_twin_bench_runs_the_drop_in_path_like_timg_cc():
     # files take); cpu: the reference's own classes
     assert seen == {(c, p) for c in ("c2", "c3", "c4", "metric") for p in ("gpu", "host", "cpu")}, seen
     assert all(x["mpx_per_s"] > 0 and x["bytes_written"] > 1000 for x in rows), rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_at", [1, 2, 3, 5, 9, 14, 22])
+def test_a_device_failure_after_creation_degrades_to_the_cpu_classes(oracle, fail_at):
+    """"C++ twins fall back to the CPU base implementation on non-zero".  Nothing in Scale() / Send() can
+    fail in the reference, so until round 5 a failing device call ended the process.  TIMG_HIP_FAIL_CALL=k makes the k-th
+    device call of the process fail (in HipCall, before the library is reached): wherever k lands -- a block canvas'
+    Send, a held grid row, a sixel batch, a scaler on a loader thread -- the twin says ONCE on stderr that the run
+    continues on the CPU, produces that frame with the reference's own class (timg_amd/twins/cpu-sibling.h:
+    UnicodeBlockCanvas / SixelCanvas on a private write sequencer; HipImageScaler: the reference's scaler) and every
+    later factory call builds the reference's classes.  The grid as src/timg.cc drives it (no animation: a frame
+    DIFFERENCE becomes a full frame after the switch) and the host-frames path stay byte-identical."""
+    if not os.path.exists(BIN):
+        pytest.skip("tests/twins/build/twin_check not built (needs /root/reference at build time)")
+    env = dict(os.environ, TIMG_HIP_FAIL_CALL=str(fail_at))
+    r = subprocess.run([BIN, "degrade"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "streams identical to the reference classes" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "degraded=1" in r.stdout, r.stdout[-500:]
+    assert r.stderr.count("continuing on the CPU") == 1, r.stderr[-1500:]

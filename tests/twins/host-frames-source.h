@@ -64,9 +64,12 @@ public:
             // memory, HipImageScaler::Create stands where ImageScaler::Create stood (src/stb-image-source.cc:44-61,
             // src/qoi-image-source.cc:42-77): upload, scale and compose on the device, the result back in a Framebuffer
             std::unique_ptr<timg::Framebuffer> out(new timg::Framebuffer(tw, th));
-            if (hip_scaler_) {
-                auto scaler = HipImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
-                if (!scaler) return false;
+            // (nullptr from the twin's factory -- no device, or the back-end switched off after a failure -- means the next
+            // back-end, as in the patched ImageScaler::Create: integration/timg-hip.patch)
+            std::unique_ptr<ImageScaler> hip_made;
+            if (hip_scaler_) hip_made = HipImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
+            if (hip_made) {
+                auto &scaler = hip_made;
                 static_cast<HipImageScaler *>(scaler.get())->ScaleAndCompose(
                     in, out.get(), options_.bgcolor_getter, options_.bg_pattern_color,
                     options_.pattern_size * options_.cell_x_px, options_.pattern_size * options_.cell_y_px / 2);

@@ -298,6 +298,9 @@ static void CheckSixelCanvas(const char *dump_path) {
 // sequencer->Flush() while the canvas is still alive, then renderer, canvas and the encoder pool
 // destroyed in that order.  The reference canvas encodes every Send on its own; the twin holds
 // grid rows back (SetGridColumns) -- the two terminal streams must not differ in a byte.
+// (the "degrade" mode runs the grid without its animation: after a device failure the block twin sends FULL frames where
+// the device would have sent differences -- valid, but other bytes; every other Send must not differ in a byte)
+static bool g_grid_animation = true;
 template <class MakeCanvas>
 static std::string RunGridLikeTimg(int fd, size_t queue_len, int columns, bool sixel, MakeCanvas make) {
     rng_state = 777;
@@ -324,7 +327,7 @@ static std::string RunGridLikeTimg(int fd, size_t queue_len, int columns, bool s
                 Fill(&fb, i % 3);
                 canvas->CursorOff();  // before_image_show
                 auto cb = renderer->render_cb("image " + std::to_string(i));
-                const bool animation = i == 2;
+                const bool animation = g_grid_animation && i == 2;
                 cb(0, 0, fb, animation ? SeqType::StartOfAnimation : SeqType::FrameImmediate, {});
                 if (animation) {
                     for (int f = 0; f < 2; ++f) {
@@ -361,8 +364,11 @@ static void CheckGridLikeTimg() {
                     fd, queue_len, columns, kind == 1,
                     [&](BufferedWriteSequencer *seq, ThreadPool *pool, const DisplayOptions &opts) -> TerminalCanvas * {
                         static SixelOptions so;
-                        if (kind == 0 && !twin) return new UnicodeBlockCanvas(seq, true, false, false);
-                        if (kind == 1 && !twin) return new SixelCanvas(seq, pool, so, opts);
+                        // (as the patched PresentImages does, integration/timg-hip.patch: no usable device -- or a back-end
+                        // that has been switched off after a failure -- means the reference's class)
+                        const bool use_twin = twin && SharedHipContext() != nullptr;
+                        if (kind == 0 && !use_twin) return new UnicodeBlockCanvas(seq, true, false, false);
+                        if (kind == 1 && !use_twin) return new SixelCanvas(seq, pool, so, opts);
                         if (kind == 0) {
                             auto *c = new HipUnicodeBlockCanvas(seq, true, false, false);
                             c->SetGridColumns(columns);
@@ -868,10 +874,13 @@ static void CheckHostFramesPath() {
                 ThreadPool pool(5);
                 static SixelOptions so;
                 std::unique_ptr<TerminalCanvas> canvas;
-                if (canvas_kind == 0 && hip) canvas.reset(new HipUnicodeBlockCanvas(&seq, true, false, false));
-                if (canvas_kind == 0 && !hip) canvas.reset(new UnicodeBlockCanvas(&seq, true, false, false));
-                if (canvas_kind == 1 && hip) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
-                if (canvas_kind == 1 && !hip) canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
+                // (a back-end switched off after a failure -- the "degrade" mode -- means the reference's class, as in the
+                // patched PresentImages)
+                const bool hip_canvas = hip && SharedHipContext() != nullptr;
+                if (canvas_kind == 0 && hip_canvas) canvas.reset(new HipUnicodeBlockCanvas(&seq, true, false, false));
+                if (canvas_kind == 0 && !hip_canvas) canvas.reset(new UnicodeBlockCanvas(&seq, true, false, false));
+                if (canvas_kind == 1 && hip_canvas) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
+                if (canvas_kind == 1 && !hip_canvas) canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
                 {
                     auto renderer = Renderer::Create(canvas.get(), opts, 4, 3, Duration(), Duration());
                     for (auto &fut : loaded) {
@@ -934,7 +943,7 @@ static void CheckPools() {
 }
 
 int main(int argc, char **argv) {
-    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|hostpath|pools|bilinear] [sixel-dump-path]
+    // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|hostpath|pools|bilinear|degrade] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
     if (!SharedHipContext()) {
         fprintf(stderr, "twin_check: no usable HIP device (%s)\n", timg_hip_last_error(nullptr));
@@ -956,6 +965,16 @@ int main(int argc, char **argv) {
     if (what == "all" || what == "source" || what == "autocrop") CheckAutoCropSource();
     if (what == "all" || what == "gather") CheckGatherWriter();
     if (what == "all" || what == "hostpath") CheckHostFramesPath();
+    if (what == "degrade") {
+        // run with TIMG_HIP_FAIL_CALL=k: the k-th device call of the process fails; the twins say so once on stderr and go
+        // on with the reference's classes (cpu-sibling.h, HipImageScaler::ScaleOnCpu) -- same terminal streams
+        g_grid_animation = false;
+        CheckGridLikeTimg();
+        CheckHostFramesPath();
+        printf("degrade: device failure injected (TIMG_HIP_FAIL_CALL=%s), degraded=%d: streams identical to the reference classes\n",
+               getenv("TIMG_HIP_FAIL_CALL") ? getenv("TIMG_HIP_FAIL_CALL") : "-", (int)HipDegraded());
+        fflush(stdout);
+    }
     if (what == "all" || what == "pools") CheckPools();
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);

@@ -22,7 +22,27 @@ bool HipTwinTrace() {
     return on;
 }
 
-timg_hip_ctx *SharedHipContext() {
+namespace {
+std::atomic<bool> g_degraded{false};
+}
+
+bool HipDegraded() { return g_degraded.load(); }
+
+void HipDegrade(timg_hip_ctx *ctx, const char *what) {
+    if (!g_degraded.exchange(true))
+        fprintf(stderr, "timg: HIP back-end failed in %s: %s -- continuing on the CPU\n", what, timg_hip_last_error(ctx));
+}
+
+bool HipFailInjected() {
+    static const long fail_at = []() {
+        const char *e = getenv("TIMG_HIP_FAIL_CALL");
+        return e ? atol(e) : 0L;
+    }();
+    static std::atomic<long> calls{0};
+    return fail_at > 0 && calls.fetch_add(1) + 1 == fail_at;
+}
+
+static timg_hip_ctx *SharedHipContextEvenIfDegraded() {
     static std::once_flag once;
     static timg_hip_ctx *ctx = nullptr;
     std::call_once(once, []() {
@@ -34,6 +54,11 @@ timg_hip_ctx *SharedHipContext() {
                     ctx ? "" : timg_hip_last_error(nullptr));
     });
     return ctx;
+}
+
+timg_hip_ctx *SharedHipContext() {
+    timg_hip_ctx *ctx = SharedHipContextEvenIfDegraded();
+    return g_degraded.load() ? nullptr : ctx;
 }
 
 timg_hip_ctx *ExtraHipContext(int k) {

@@ -53,8 +53,12 @@ size_t HipPoolTrim(timg_hip_ctx *ctx);
 // grow, a staging copy could not be allocated) is made ONCE more after HipPoolTrim: a transient shortage in the
 // middle of a 600-frame stream must not end the process while gigabytes sit in the pool.  Any other failure, and a
 // second one, is the caller's (HipFatal).
+// (TIMG_HIP_FAIL_CALL=k in the environment: the k-th HipCall of the process fails with TIMG_HIP_ERR_DEVICE without reaching
+// the library -- fault injection for the degrade paths, tests/test_twins.py)
+bool HipFailInjected();
 template <class Call>
 int HipCall(timg_hip_ctx *ctx, Call &&call) {
+    if (HipFailInjected()) return TIMG_HIP_ERR_DEVICE;
     int rc = call();
     if (rc == TIMG_HIP_ERR_NOMEM) {
         HipPoolTrim(ctx);
@@ -72,7 +76,14 @@ timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_
 void HipScalerRelease(timg_hip_scaler *s);
 size_t HipIdleScalers();  // (for the tests)
 
-// A device call failed after the GPU back-end had been selected: print
+// A device call failed after the GPU back-end had been selected and the twin has a CPU implementation to go on with
+// (cpu-sibling.h; HipImageScaler: the reference's own scaler): says so ONCE on stderr and switches the back-end off for
+// the rest of the process -- SharedHipContext() returns nullptr from now on, so every later factory call builds the
+// reference's classes.  Objects that exist keep their context (they check HipDegraded() themselves).
+void HipDegrade(timg_hip_ctx *ctx, const char *what);
+bool HipDegraded();
+
+// A device call failed after the GPU back-end had been selected and there is nothing to fall back to: print
 // timg_hip_last_error() and terminate.  The twins never substitute CPU results
 // for a failed device call -- nothing in Scale()/Send() can fail in the
 // reference either, so there is no error path to return through.

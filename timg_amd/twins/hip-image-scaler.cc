@@ -30,14 +30,25 @@ std::unique_ptr<ImageScaler> HipImageScaler::Create(int in_width, int in_height,
 
 HipImageScaler::~HipImageScaler() { HipScalerRelease(scaler_); }
 
+// The device failed (or failed earlier: HipDegraded) after this scaler had been created: the reference's own scaler for
+// the same geometry does the work -- ImageScaler::Create builds it, because HipImageScaler::Create now returns nullptr.
+// Same bytes when the timg build scales with stb (src/image-scaler.cc:75-98), the build's own filter otherwise.
+void HipImageScaler::ScaleOnCpu(Framebuffer &in, Framebuffer *out, const char *what) {
+    HipDegrade(ctx_, what);
+    std::unique_ptr<ImageScaler> cpu = ImageScaler::Create(in_w_, in_h_, fmt_, out_w_, out_h_);
+    if (!cpu) HipFatal(ctx_, what);  // (no CPU back-end either: the reference's loaders would have failed the load)
+    cpu->Scale(in, out);
+}
+
 void HipImageScaler::Scale(Framebuffer &in, Framebuffer *out) {
-    if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ ||
-        out->height() != out_h_ ||
+    if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ || out->height() != out_h_)
+        HipFatal(ctx_, "HipImageScaler::Scale: geometry");
+    if (HipDegraded() ||
         HipCall(ctx_, [&]() {
             return timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0, (uint8_t *)out->begin(), 0, 0, 0,
                                         1, nullptr, nullptr, nullptr);
         }) != TIMG_HIP_OK)
-        HipFatal(ctx_, "HipImageScaler::Scale");
+        ScaleOnCpu(in, out, "HipImageScaler::Scale");
 }
 
 void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
@@ -51,15 +62,22 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
     // timg_hip_alpha_compose.)
     if (in.width() != in_w_ || in.height() != in_h_ || out->width() != out_w_ || out->height() != out_h_)
         HipFatal(ctx_, "HipImageScaler::ScaleAndCompose: geometry");
+    auto on_cpu = [&](const char *what) {  // (src/qoi-image-source.cc:63-74: the pair of calls this one replaces)
+        ScaleOnCpu(in, out, what);
+        out->AlphaComposeBackground(get_bg, pattern, pattern_width, pattern_height);
+    };
+    if (HipDegraded()) return on_cpu("HipImageScaler::ScaleAndCompose");
     const size_t bytes = (size_t)out_w_ * out_h_ * 4;
     uint8_t *scaled    = (uint8_t *)HipPoolMalloc(ctx_, bytes);
-    if (!scaled) HipFatal(ctx_, "HipImageScaler::ScaleAndCompose: device memory");
+    if (!scaled) return on_cpu("HipImageScaler::ScaleAndCompose: device memory");
     int transparent = 0;
     if (HipCall(ctx_, [&]() {
             return timg_hip_scale_blend(ctx_, scaler_, (const uint8_t *)in.begin(), 0, 0, 0, scaled, 0, 0, 1, 1, nullptr,
                                         &transparent, nullptr);
-        }) != TIMG_HIP_OK)
-        HipFatal(ctx_, "HipImageScaler::ScaleAndCompose");
+        }) != TIMG_HIP_OK) {
+        HipPoolFree(ctx_, scaled);
+        return on_cpu("HipImageScaler::ScaleAndCompose");
+    }
     if (get_bg && transparent) {  // src/framebuffer.cc:111,117: otherwise the getter is not consulted
         timg_hip_blend b;
         b.enabled   = 1;
@@ -70,11 +88,15 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
         b.start_row = 0;
         if (HipCall(ctx_, [&]() {
                 return timg_hip_alpha_compose(ctx_, scaled, out_w_, out_h_, 0, 0, 1, 1, &b, nullptr, nullptr);
-            }) != TIMG_HIP_OK)
-            HipFatal(ctx_, "timg_hip_alpha_compose");
+            }) != TIMG_HIP_OK) {
+            HipPoolFree(ctx_, scaled);
+            return on_cpu("timg_hip_alpha_compose");  // (the getter is asked a second time: it caches, src/timg.cc:924-928)
+        }
     }
-    if (timg_hip_memcpy_d2h(ctx_, out->begin(), scaled, bytes, nullptr) != TIMG_HIP_OK)
-        HipFatal(ctx_, "HipImageScaler::ScaleAndCompose: download");
+    if (timg_hip_memcpy_d2h(ctx_, out->begin(), scaled, bytes, nullptr) != TIMG_HIP_OK) {
+        HipPoolFree(ctx_, scaled);
+        return on_cpu("HipImageScaler::ScaleAndCompose: download");
+    }
     HipPoolFree(ctx_, scaled);
 }
 

@@ -34,6 +34,7 @@ public:
                          rgba_t pattern, int pattern_width, int pattern_height);
 
 private:
+    void ScaleOnCpu(Framebuffer &in, Framebuffer *out, const char *what);
     HipImageScaler(timg_hip_ctx *ctx, timg_hip_scaler *scaler, int in_w,
                    int in_h, ColorFmt fmt, int out_w, int out_h)
         : ctx_(ctx), scaler_(scaler), in_w_(in_w), in_h_(in_h), fmt_(fmt),

@@ -10,10 +10,14 @@
 #include <functional>
 #include <future>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "hip-context.h"
 #include "hip-device-frames.h"
+#ifdef WITH_TIMG_SIXEL
+#include "sixel-canvas.h"
+#endif
 
 namespace timg {
 
@@ -27,11 +31,40 @@ HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_po
                                const DisplayOptions &display_opts)
     : TerminalCanvas(ws), options_(display_opts), full_cell_jump_(sixel_options.full_cell_jump),
       broken_cursor_(sixel_options.known_broken_cursor_placement),
+      sixel_options_(sixel_options),
       executor_(thread_pool),
       ctx_(SharedHipContext()) {
     if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
     if (HipTwinTrace()) fprintf(stderr, "HipSixelCanvas: created\n");
+#ifdef WITH_TIMG_SIXEL
+    cpu_.reset(new CpuSibling([this](BufferedWriteSequencer *seq, ThreadPool *pool) -> TerminalCanvas * {
+        return new SixelCanvas(seq, pool, sixel_options_, options_);  // (constructed on first use only)
+    }));
+#endif
     DeviceFrameConsumerCreated();
+}
+
+size_t HipSixelCanvas::EncodeOnCpu(timg_hip_ctx *ctx, char *&buffer, size_t prefix, size_t &cap, const uint8_t *pixels,
+                                   bool on_device, int w, int h, const char *what) {
+    if (!cpu_) HipFatal(ctx, what);  // (a timg build without libsixel has no CPU sixel canvas to go on with)
+    HipDegrade(ctx, what);
+    std::vector<uint8_t> host;
+    if (on_device) {
+        host.resize((size_t)w * h * 4);
+        if (timg_hip_memcpy_d2h(ctx, host.data(), pixels, host.size(), nullptr) != TIMG_HIP_OK) HipFatal(ctx, what);
+        pixels = host.data();
+    }
+    // (x = 0, dy = 0: the cursor moves of this Send are in the twin's prefix already)
+    const std::string bytes = cpu_->Encode(0, pixels, w, h);
+    if (prefix + bytes.size() > cap) {
+        char *bigger = new char[prefix + bytes.size()];
+        memcpy(bigger, buffer, prefix);
+        delete[] buffer;
+        buffer = bigger;
+        cap    = prefix + bytes.size();
+    }
+    memcpy(buffer + prefix, bytes.data(), bytes.size());
+    return bytes.size();
 }
 
 int HipSixelCanvas::EncodeFlags() const { return broken_cursor_ ? TIMG_HIP_SIXEL_BROKEN_CURSOR : 0; }
@@ -97,16 +130,22 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     const auto t0 = std::chrono::steady_clock::now();
     // (HipCall: out of device memory -- the encoder's scratch grows with the batch -- is retried once after the twins'
     // caches have been given back)
-    if (HipCall(ctx, [&]() {
+    const bool on_device = !HipDegraded() &&
+        HipCall(ctx, [&]() {
             return timg_hip_sixel_encode(ctx, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
                                          bytes.get(), slot, 0, lens.data(), nullptr);
-        }) != TIMG_HIP_OK)
-        HipFatal(ctx, "timg_hip_sixel_encode");
+        }) == TIMG_HIP_OK;
     const auto t1 = std::chrono::steady_clock::now();
+    const size_t frame_bytes = (size_t)batch.w * batch.h * 4;
     for (size_t i = 0; i < n; ++i) {
         HeldFrame &f = batch.frames[i];
-        if (f.prefix + lens[i] > f.cap) HipFatal(ctx_, "sixel frame larger than its buffer");
-        memcpy(f.buffer + f.prefix, bytes.get() + i * slot, lens[i]);
+        if (on_device) {
+            if (f.prefix + lens[i] > f.cap) HipFatal(ctx_, "sixel frame larger than its buffer");
+            memcpy(f.buffer + f.prefix, bytes.get() + i * slot, lens[i]);
+        } else {
+            lens[i] = EncodeOnCpu(ctx, f.buffer, f.prefix, f.cap, batch.data() + i * frame_bytes, batch.on_device, batch.w,
+                                  batch.h, "timg_hip_sixel_encode");
+        }
         f.promise.set_value(OutBuffer(f.buffer, f.prefix + lens[i]));
     }
     if (trace)
@@ -173,17 +212,20 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         memcpy(pixels->data(), fb_orig.begin(), frame_bytes);
     }
     const int flags = EncodeFlags();
+    const size_t prefix_len = (size_t)(offset - buffer);
     const std::function<OutBuffer()> encode_fun = [=]() {
-        OutBuffer out(buffer, offset - buffer);
         size_t len = 0;
-        if (HipCall(ctx, [&]() {
+        char *buf  = buffer;
+        size_t room = cap;
+        if (HipDegraded() ||
+            HipCall(ctx, [&]() {
                 return timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr,
-                                             1, flags, &pad, offset, cap - (size_t)(offset - buffer), 0, &len, nullptr);
+                                             1, flags, &pad, buf + prefix_len, room - prefix_len, 0, &len, nullptr);
             }) != TIMG_HIP_OK)
-            HipFatal(ctx, "timg_hip_sixel_encode");
+            len = EncodeOnCpu(ctx, buf, prefix_len, room, device_copy ? device_copy : pixels->data(), device_copy != nullptr, w, h,
+                              "timg_hip_sixel_encode");
         if (device_copy) HipPoolFree(ctx, device_copy);
-        out.size += len;
-        return out;
+        return OutBuffer(buf, prefix_len + len);
     };
     write_sequencer_->WriteBuffer(executor_->ExecAsync(encode_fun), seq_type, end_of_frame);
 }

@@ -3,8 +3,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "hip-context.h"
+#include "unicode-block-canvas.h"
 #include "hip-device-frames.h"
 
 namespace timg {
@@ -22,7 +25,32 @@ HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool us
     if (!ctx_ || timg_hip_block_canvas_create(ctx_, flags_, &canvas_) != TIMG_HIP_OK)
         HipFatal(ctx_, "HipUnicodeBlockCanvas");
     if (HipTwinTrace()) fprintf(stderr, "HipUnicodeBlockCanvas: created (flags %d)\n", flags_);
+    const bool quarter = use_quarter, upper = use_upper_half_block, c256 = use_256_color;
+    cpu_.reset(new CpuSibling([quarter, upper, c256](BufferedWriteSequencer *seq, ThreadPool *) -> TerminalCanvas * {
+        return new UnicodeBlockCanvas(seq, quarter, upper, c256);  // (constructed on first use only)
+    }));
     DeviceFrameConsumerCreated();
+}
+
+size_t HipUnicodeBlockCanvas::EncodeOnCpu(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height,
+                                          const char *what) {
+    HipDegrade(ctx_, what);
+    std::vector<uint8_t> host;
+    if (on_device) {  // (a frame of a device-resident source: its pixels have to come back first -- if the device still answers)
+        host.resize((size_t)width * height * 4);
+        if (timg_hip_memcpy_d2h(ctx_, host.data(), pixels, host.size(), nullptr) != TIMG_HIP_OK) HipFatal(ctx_, what);
+        pixels = host.data();
+    }
+    const std::string bytes = cpu_->Encode(p.x, pixels, width, height);
+    if (p.prefix + bytes.size() > p.cap) {
+        char *bigger = new char[p.prefix + bytes.size()];
+        memcpy(bigger, p.buffer, p.prefix);
+        delete[] p.buffer;
+        p.buffer = bigger;
+        p.cap    = p.prefix + bytes.size();
+    }
+    memcpy(p.buffer + p.prefix, bytes.data(), bytes.size());
+    return bytes.size();
 }
 
 HipUnicodeBlockCanvas::~HipUnicodeBlockCanvas() {
@@ -46,11 +74,12 @@ void HipUnicodeBlockCanvas::Flush() {
 void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height,
                                     SeqType seq_type, Duration end_of_frame) {
     size_t len = 0;
-    if (HipCall(ctx_, [&]() {
+    if (HipDegraded() ||
+        HipCall(ctx_, [&]() {
             return timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, on_device, p.buffer + p.prefix,
                                               p.cap - p.prefix, &len, nullptr);
         }) != TIMG_HIP_OK)
-        HipFatal(ctx_, "timg_hip_block_canvas_send");
+        len = EncodeOnCpu(p, pixels, on_device, width, height, "timg_hip_block_canvas_send");
     // nothing emitted: the reference keeps the buffer size zero, dropping the
     // cursor jump as well (:390-395)
     write_sequencer_->WriteBuffer(OutBuffer(p.buffer, len ? p.prefix + len : 0), seq_type, end_of_frame);
@@ -68,14 +97,17 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
         std::vector<size_t> lens(n - 1);
         std::vector<int> xs(n - 1);
         for (size_t i = 0; i + 1 < n; ++i) xs[i] = batch.frames[i].x;
-        if (HipCall(ctx_, [&]() {
+        const bool on_device = !HipDegraded() &&
+            HipCall(ctx_, [&]() {
                 return timg_hip_block_encode_grid(ctx_, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)(n - 1),
                                                   flags_, xs.data(), bytes.get(), slot, 0, lens.data(), nullptr);
-            }) != TIMG_HIP_OK)
-            HipFatal(ctx_, "timg_hip_block_encode_grid");
+            }) == TIMG_HIP_OK;
         for (size_t i = 0; i + 1 < n; ++i) {
             HeldFrame &p = batch.frames[i];
-            memcpy(p.buffer + p.prefix, bytes.get() + i * slot, lens[i]);
+            if (on_device)
+                memcpy(p.buffer + p.prefix, bytes.get() + i * slot, lens[i]);
+            else
+                lens[i] = EncodeOnCpu(p, batch.data() + i * frame_bytes, batch.on_device, batch.w, batch.h, "timg_hip_block_encode_grid");
             p.promise.set_value(OutBuffer(p.buffer, lens[i] ? p.prefix + lens[i] : 0));
         }
     }
@@ -85,11 +117,12 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
     timg_hip_block_canvas_forget(canvas_);
     HeldFrame &p = batch.frames[n - 1];
     size_t len   = 0;
-    if (HipCall(ctx_, [&]() {
+    if (HipDegraded() ||
+        HipCall(ctx_, [&]() {
             return timg_hip_block_canvas_send(canvas_, p.x, p.dy, batch.data() + (n - 1) * frame_bytes, batch.w, batch.h, 0,
                                               batch.on_device, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr);
         }) != TIMG_HIP_OK)
-        HipFatal(ctx_, "timg_hip_block_canvas_send");
+        len = EncodeOnCpu(p, batch.data() + (n - 1) * frame_bytes, batch.on_device, batch.w, batch.h, "timg_hip_block_canvas_send");
     p.promise.set_value(OutBuffer(p.buffer, len ? p.prefix + len : 0));
 }
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "buffered-write-sequencer.h"
+#include "cpu-sibling.h"
 #include "held-rows.h"
 #include "terminal-canvas.h"
 #include "timg_hip.h"
@@ -46,6 +47,9 @@ private:
     void SendNow(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height, SeqType seq_type,
                  Duration end_of_frame);
     void EncodeBatch(HeldBatch &batch);
+    // the device failed: the frame's bytes from the reference's own UnicodeBlockCanvas (cpu-sibling.h); returns their
+    // length, written behind p's prefix (the buffer grows if it has to)
+    size_t EncodeOnCpu(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height, const char *what);
 
     timg_hip_ctx *const ctx_;
     const int flags_;
@@ -53,6 +57,7 @@ private:
     int hold_limit_   = 1;
     bool have_last_x_ = false;
     int last_x_       = 0;  // x of the previous Send
+    std::unique_ptr<CpuSibling> cpu_;
     std::unique_ptr<HeldRows> rows_;  // (last member: its thread uses the ones above)
 };
 

@@ -325,7 +325,10 @@ def main():
             if recv_buf[0] is None or recv_buf[0].numel() < total:
                 recv_buf[0] = torch.empty(max(total + total // 4, 1 << 20), dtype=torch.uint8, device="cuda")
             recv_ptr, recv_cap = recv_buf[0].data_ptr(), recv_buf[0].numel()
-        got = cabi.gather_payload(payload.data_ptr() if payload.numel() else 0, all_len, recv_ptr, recv_cap)
+        # (packed_output() handed over a snapshot it has synchronised: PAYLOAD_READY -- the exchange runs on the communicator's
+        # stream beside the next step's kernels instead of waiting for the whole device)
+        got = cabi.gather_payload(payload.data_ptr() if payload.numel() else 0, all_len, recv_ptr, recv_cap,
+                                  stream=tcomm.PAYLOAD_READY)
         if rank == 0:
             exchange["gathers"] += 1
             exchange["bytes_at_root"] = got

@@ -70,8 +70,13 @@ int timg_hip_gather_lengths(timg_hip_comm *comm, const uint64_t *lengths, int n_
  * total.  Other ranks pass recv = NULL, recv_cap = 0.  The root's recv_cap travels with a one-word
  * all-gather first: when it is too small EVERY rank returns TIMG_HIP_COMM_ERR_CAP and no payload
  * moves.  `stream`: the hipStream_t the payload was produced on -- the exchange is enqueued behind it;
- * NULL: the communicator's own stream, after the whole device has gone idle (the payload is complete
- * whatever stream produced it). */
+ * TIMG_HIP_COMM_PAYLOAD_READY: the caller has already waited for whatever produced the payload (a snapshot it
+ * synchronised, bench.py's packed_output) -- the exchange runs on the communicator's own stream BESIDE whatever the
+ * caller's other streams are doing (the next step's kernels), no device-wide wait;
+ * NULL: the last resort for a caller that knows nothing about its producer -- the communicator's own stream, after
+ * the whole device has gone idle (the payload is complete whatever stream produced it; everything else the device
+ * was doing is waited for too). */
+#define TIMG_HIP_COMM_PAYLOAD_READY ((void *)(uintptr_t)1)
 int timg_hip_gather_payload(timg_hip_comm *comm, int root, const uint8_t *payload, const uint64_t *all_lengths,
                             int n_frames_max, uint8_t *recv, size_t recv_cap, size_t *recv_bytes, void *stream);
 

@@ -424,6 +424,41 @@ def test_sixel_pixel_pairs_equal_single_pixels(hip, oracle, monkeypatch, kind, w
         assert got == want, f"pixel requests of {pix}: {len(got)} vs {len(want)} bytes"
 
 
+@pytest.mark.parametrize("trips", [1, 2])
+@pytest.mark.parametrize("pix", [1, 2])
+@pytest.mark.parametrize("kind,w,h,parts,view", [
+    ("photo", 800, 450, 2, False),    # two parts a frame
+    ("photo", 800, 450, 16, False),   # the most parts the placement takes (one row group each where it can)
+    ("alpha", 801, 77, -1, False),    # odd width: never pixel pairs, whatever TIMG_HIP_DITHER_PIX says
+    ("noise", 402, 130, -1, True),    # rows 4-byte but not 8-byte aligned (a view into a wider image): one-pixel form
+    ("photo", 2600, 100, -1, False),  # one wave going round four times on ONE boundary row
+    ("photo", 64, 1100, 3, False),    # three rounds of a sixteen-wave workgroup per part
+])
+def test_sixel_every_diffusion_instantiation(hip, oracle, monkeypatch, kind, w, h, parts, view, pix, trips):
+    """the diffusion's hand-counted s_waitcnt rings (two-trip / one-trip lookup x pixel pairs / single
+    pixels) are chosen by geometry and alignment, so a parity run may only ever exercise one of them; a wrong count
+    corrupts pixels silently.  The cross product, forced through TIMG_HIP_DITHER_TRIPS x TIMG_HIP_DITHER_PIX, on the
+    geometries that pick different placements (parts 2 and 16, odd widths, misaligned rows, a single wave that follows
+    itself, several rounds): the oracle's bytes every time."""
+    monkeypatch.setenv("TIMG_HIP_DITHER_TRIPS", str(trips))
+    monkeypatch.setenv("TIMG_HIP_DITHER_PIX", str(pix))
+    if parts >= 0:
+        monkeypatch.setenv("TIMG_HIP_DITHER_PARTS", str(parts))
+    if view:
+        wide = synth.make(kind, w + 7, h, seed=31)
+        fb = np.ascontiguousarray(wide[:, 3:3 + w])
+        d = hip.upload(wide)
+        got = hip.sixel_encode(d + 3 * 4, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3), stride=(w + 7) * 4,
+                               frame_stride=(w + 7) * 4 * h)[0]
+        hip.free(d)
+    else:
+        fb = synth.make(kind, w, h, seed=31)
+        got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3),
+                               out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 5, 3, lookup_mode=1)
+    assert got == want, f"trips {trips} pix {pix}: {len(got)} vs {len(want)} bytes"
+
+
 @pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])
 def test_sixel_diffusion_spread_over_several_cus(hip, oracle, monkeypatch, parts):
     """Frames of eight row groups and more are diffused by several workgroups (CUs) per frame, the boundary row

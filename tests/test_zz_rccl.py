@@ -42,6 +42,12 @@ assert (al == all_len).all()
 hip.upload(np.zeros(int(lens.sum()), np.uint8), dst)
 assert c.gather_payload(src, al, dst, int(lens.sum())) == lens.sum()
 assert np.array_equal(hip.download(dst, total), data)
+# ... and with TIMG_HIP_COMM_PAYLOAD_READY: "I have waited for the payload's producer" -- the exchange runs on the
+# communicator's stream without idling the device first (what bench.py's gather passes: ADVICE r4)
+hip.upload(np.zeros(int(lens.sum()), np.uint8), dst)
+hip.sync()
+assert c.gather_payload(src, al, dst, int(lens.sum()), stream=comm.PAYLOAD_READY) == lens.sum()
+assert np.array_equal(hip.download(dst, total), data)
 # a short receive buffer is an error on every rank (here: the only one), not a hang, and moves nothing
 hip.upload(np.full(int(lens.sum()), 7, np.uint8), dst)
 try:

@@ -73,6 +73,11 @@ def shard_count(n_total, world, round_robin, rank):
     return load_comm_library().timg_hip_shard_count(n_total, world, int(round_robin), rank)
 
 
+# include/timg_hip_comm.h TIMG_HIP_COMM_PAYLOAD_READY: "the caller has waited for the payload's producer itself" -- the exchange
+# then runs on the communicator's stream beside the caller's other streams (pass as `stream`)
+PAYLOAD_READY = 1
+
+
 class Comm:
     """One communicator per process (one process per GPU)."""
 

@@ -243,7 +243,7 @@ int timg_hip_gather_lengths(timg_hip_comm *c, const uint64_t *lengths, int n_fra
     if (n_frames < 0 || n_frames_max < 1 || n_frames > n_frames_max || (n_frames && !lengths) || !all_lengths)
         return c->Fail(TIMG_HIP_COMM_ERR, "bad argument");
     COMM_HIP(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = (stream && stream != TIMG_HIP_COMM_PAYLOAD_READY) ? (hipStream_t)stream : c->stream;
     std::vector<uint64_t> mine((size_t)n_frames_max, 0);
     for (int i = 0; i < n_frames; ++i) mine[i] = lengths[i];
     return c->AllGatherWords(mine.data(), mine.size(), all_lengths, st);
@@ -265,11 +265,13 @@ int timg_hip_gather_payload(timg_hip_comm *c, int root, const uint8_t *payload, 
     const size_t my_bytes = total[c->rank];
     if (my_bytes && !payload) return c->Fail(TIMG_HIP_COMM_ERR, "payload is NULL");
     COMM_HIP(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const bool ready = stream == TIMG_HIP_COMM_PAYLOAD_READY;
+    hipStream_t st   = (stream && !ready) ? (hipStream_t)stream : c->stream;
     // stream == NULL: the exchange runs on the communicator's own stream, which knows nothing of the stream(s) the
     // caller produced `payload` on -- the device is made idle first, so that the payload is complete whatever the
     // caller did or did not synchronise (the call ends with a synchronisation anyway).  A caller that passes its
-    // producing stream gets stream order instead and pays no device-wide wait.
+    // producing stream gets stream order instead, and one that says TIMG_HIP_COMM_PAYLOAD_READY (it has waited for its
+    // producer itself) runs beside the kernels of its other streams: neither pays a device-wide wait.
     if (!stream) COMM_HIP(c, hipDeviceSynchronize());
     // every rank learns the root's capacity: a short buffer fails everywhere, nobody waits in a send
     const uint64_t my_cap = (c->rank == root && recv) ? (uint64_t)recv_cap : 0;

@@ -2105,6 +2105,10 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
                 StreamVariant nv;
                 if (BuildVariant(s->plan, ss->strips_host, ss->first_host, ss->last_host, rows, &nv))
                     it = ss->more.emplace(rows, nv).first;
+                else
+                    (void)hipGetLastError();  // (a failed allocation of the EXTRA variant is not this launch's error: the
+                                              // launch goes on with a variant that exists, and LaunchMode* below read
+                                              // hipGetLastError() right behind their kernel -- ADVICE r4)
             }
             if (it != ss->more.end()) {
                 pick = &it->second;

@@ -1278,6 +1278,11 @@ __global__ void __launch_bounds__(kLutWaves * 64) BuildLutKernel(SixelGeom g, Si
 //    which the LDS executes in order: no fence (a workgroup fence would drain the wave's
 //    global prefetches), only relaxed atomics and compiler barriers.
 constexpr int kDitherAhead    = 8;  // source pixels are requested this many steps early
+// How far past the end of the row above a step reads (unclamped -- the lanes that receive those records are outside
+// their own rows by then): the skew of the wave's last row pair (2 columns a row), the request lead, one unrolled body
+// of 8 steps, the record look-ahead (t + 3) and the pair's second half -- 62 + 8 + 8 + 7 + 5 = 90 slots with today's
+// constants.  Changing any of them must move kDitherOverrun (sixel_launch.h) with it: ADVICE r4.
+static_assert(kDitherOverrun >= 2 * (kPairRows - 1) + kDitherAhead + 8 + 7 + 5, "record reads past a row's end must stay inside the slack");
 
 // wave_shr:1 -- every lane receives the value of the lane below it in index
 __device__ __forceinline__ uint32_t FromLaneAbove(uint32_t v) {

@@ -47,7 +47,16 @@ inline size_t DitherLdsBytes(int w, int rows, bool one_trip) {
     return kDitherLdsHead +
            (DitherTabWords(one_trip) + (size_t)(rows > 1 ? rows + 1 : 1) * 3 * (size_t)(w + 3) + 3 * kDitherOverrun) * sizeof(uint32_t);
 }
-constexpr size_t kDitherStaticLds = 512;  // (kept free of a workgroup's LDS: nothing static is left in the kernel)
+// The slack behind the last boundary row (3 * kDitherOverrun words) has two tenants (DitherKernel, "handing down WITHOUT
+// touching exec"): the unclamped record reads past a row's end, and every lane's DUMMY stores -- an 8-byte record at
+// 8 * lane and a progress word at 512 + 4 * lane.  Both must fit, and the waves' real progress counters must fit the head:
+static_assert(3 * kDitherOverrun * sizeof(uint32_t) >= 512 + 4 * 64, "the lanes' dummy record and progress stores must fit the slack");
+static_assert(8 * 64 <= 512, "the dummy records (8 bytes a lane) must end where the dummy progress words begin");
+static_assert(kDitherLdsHead >= 4 * kDitherMaxWaves, "one progress counter per wave in front of the tables");
+// (Kept free of a workgroup's LDS budget although the kernel has had no static LDS since round 4: the placement
+// decisions -- waves per workgroup, parts per frame -- at geometries that fill the LDS to the byte are the ones the
+// parity tests pin (widths 766, 825, 1200...); giving the 512 bytes back would move them for nothing.)
+constexpr size_t kDitherStaticLds = 512;
 
 // LDS layout of BandNodesKernel for frames whose bands sort in LDS (words)
 __host__ __device__ inline int BandBitmapWords(int w) { return ((w + 31) >> 5) | 1; }

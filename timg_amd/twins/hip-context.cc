@@ -79,13 +79,23 @@ timg_hip_ctx *LoaderHipContext() {
     // Loader threads (src/timg.cc:948-968 runs 3/4 of the cores as loaders) scale frames that live in HOST memory: a
     // call uploads the frame, scales and downloads the result under its context's lock -- on ONE context every loader
     // waits for the others' uploads (64 frames of 4K: 1.02 ms a frame, 8.1 Gpx/s at sixteen loaders).  Each thread is
-    // given one of kLoaderContexts contexts of its own stream and staging memory instead, so that one image's upload
-    // runs beside another's kernels; contexts kLoaderFirst.. leave the first ones to the canvases' encoders.
-    constexpr int kLoaderContexts = 8, kLoaderFirst = 5;
+    // given one of up to kLoaderContexts contexts of its own stream and staging memory instead, so that one image's
+    // upload runs beside another's kernels.  They are the loaders' OWN contexts, created on demand, one per loader
+    // thread that actually shows up (a single-image run creates one, not the five encoder contexts in front of it and
+    // itself: ADVICE r4) -- the encoders' contexts (ExtraHipContext) are not touched.
+    constexpr int kLoaderContexts = 8;
+    static std::mutex mu;
+    static timg_hip_ctx *loaders[kLoaderContexts] = {};
     static std::atomic<int> next{0};
-    thread_local int mine = next.fetch_add(1);
-    timg_hip_ctx *c = ExtraHipContext(kLoaderFirst + mine % kLoaderContexts);
-    return c ? c : SharedHipContext();
+    thread_local int mine = next.fetch_add(1) % kLoaderContexts;
+    timg_hip_ctx *shared = SharedHipContext();
+    if (!shared) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    if (!loaders[mine]) {
+        const char *d = getenv("TIMG_HIP_DEVICE");
+        if (timg_hip_init(d ? atoi(d) : 0, &loaders[mine]) != TIMG_HIP_OK) loaders[mine] = nullptr;
+    }
+    return loaders[mine] ? loaders[mine] : shared;
 }
 
 int HipScalerFilter() {

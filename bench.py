@@ -603,10 +603,21 @@ def main():
                 result["roofline"]["traffic"] = t["hbm_bytes_per_launch"] // launches_per_batch
                 result["roofline"]["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / launches_per_batch / alg_bytes, 3)
                 result["roofline"]["traffic_measured_in_this_run"] = False
+                # the counters belong to ONE binary: the file names the library it was collected with (collect_pmc.sh)
+                import hashlib
+                with open(os.path.join(ROOT, "timg_amd", "libtimg_hip.so"), "rb") as lib_f:
+                    lib_sha = hashlib.sha256(lib_f.read()).hexdigest()
+                stale = t.get("library_sha256") != lib_sha
+                result["roofline"]["traffic_stale"] = stale
+                if stale:
+                    result["roofline"]["traffic_stale_why"] = (
+                        "profiles/%s was collected with another build of libtimg_hip.so (%s; this one %s): the ratio is that "
+                        "build's, the limiter text is withheld" % (os.path.basename(traffic_file),
+                                                                  (t.get("library_sha256") or "unrecorded")[:12], lib_sha[:12]))
                 result["roofline"]["traffic_source"] = ("NOT measured in this run: profiles/%s, rocprofv3 --pmc FETCH_SIZE / "
                                                         "WRITE_SIZE passes of this same command (profiles/collect_pmc.sh)"
                                                         % os.path.basename(traffic_file))
-                if t.get("limiter"):
+                if t.get("limiter") and not stale:
                     result["roofline"]["limiter"] = t["limiter"]
                 break
         except Exception:

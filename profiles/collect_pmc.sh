@@ -1,5 +1,5 @@
 #!/bin/bash
-# profiles/collect_pmc.sh <round-tag> [config[:kind] ...]   (run on the GPU box: gpurun -- 'bash profiles/collect_pmc.sh r4')
+# profiles/collect_pmc.sh <round-tag> [config[:kind] ...]   (run on the GPU box: gpurun -- 'bash profiles/collect_pmc.sh r5')
 #
 # Counter evidence for the scale kernel of every bench configuration, as the kernels are NOW: for each configuration
 # (default: metric, metric:alpha, c3, c5) the same `python bench.py --config C [--kind K]` command under
@@ -10,6 +10,8 @@
 #   gpurun_out/<tag>/hbm_traffic_<config>[_<kind>].json   (copy to profiles/: bench.py fills roofline.traffic and
 #                                                          roofline.limiter of `--config C [--kind K]` from it)
 #   gpurun_out/<tag>/sq_counters_<config>[_<kind>].txt
+# Every hbm_traffic_*.json carries the SHA-256 of the timg_amd/libtimg_hip.so it was collected with: bench.py compares it with
+# the library it is timing and says `traffic_stale: true` (and drops `limiter`) when a kernel change has left the file behind.
 set -e
 tag=${1:-r4}; shift || true
 specs=("$@"); [ ${#specs[@]} -eq 0 ] && specs=(metric metric:alpha c3 c5)
@@ -51,7 +53,10 @@ with open("%s/sq_counters_%s.txt" % (out, name), "w") as f:
     for k in sorted(set(sq1) | set(sq2)):
         f.write("%s%s\n  sq1 %s\n  sq2 %s\n" % (k, "   <- dominant" if k == dom else "", {c: round(v, 1) for c, v in sq1.get(k, {}).items()},
                                               {c: round(v, 1) for c, v in sq2.get(k, {}).items()}))
-res = {"config": cfg, "kind": kind or None, "workload_frames": line["config"]["frames_per_launch"], "kernel": line["config"]["scale_kernel"],
+import hashlib, os
+lib = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "timg_amd", "libtimg_hip.so")
+res = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),  # (bench.py: a counter file of another binary is stale)
+       "config": cfg, "kind": kind or None, "workload_frames": line["config"]["frames_per_launch"], "kernel": line["config"]["scale_kernel"],
        "dominant_kernel": dom, "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
        "avg_launch_ms_unprofiled": line["roofline"]["avg_launch_ms"], "frac_unprofiled": line["roofline"]["frac"]}
 if dom and dom in fetch and dom in write:

@@ -19,6 +19,7 @@
 
 #include "context.h"
 #include "pixel_math.h"
+#include "wave_ops.h"
 
 namespace timg_amd {
 namespace {
@@ -296,17 +297,11 @@ ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
         const bool present = live && !(rec.meta & 0x400u);
         const bool nonbg   = present && (rec.meta & 0xffu) != kBackground;
 
-        int sp = present ? lane : -1, sn = nonbg ? lane : -1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int op = __shfl_up(sp, d), on = __shfl_up(sn, d);
-            if (lane >= d) {
-                sp = sp > op ? sp : op;
-                sn = sn > on ? sn : on;
-            }
-        }
-        int prev_p = __shfl_up(sp, 1), prev_n = __shfl_up(sn, 1);
-        if (lane == 0) prev_p = prev_n = -1;
+        // "the nearest present / non-background cell at or below this lane": a prefix maximum of lane + 1 (0: none) on
+        // the DPP data path (wave_ops.h) -- as __shfl_up loops these were six dependent ds_bpermute round trips each
+        const uint32_t ip = WaveInclusiveMaxU32(present ? (uint32_t)lane + 1u : 0u);
+        const uint32_t in = WaveInclusiveMaxU32(nonbg ? (uint32_t)lane + 1u : 0u);
+        const int prev_p = (int)WaveShr1(ip) - 1, prev_n = (int)WaveShr1(in) - 1;  // (lane 0: -1)
 
         // cursor-right in front of an emitted cell: cells skipped since the last
         // emitted one; the row starts with x_skip = indent (:240)
@@ -331,12 +326,7 @@ ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
             if (emit_bg) len += Transparent(rec.bg) ? 3u : 5u + ColorLen(rec.bg, g.color256);
             len += (rec.meta & 0xffu) == kBackground ? 1u : 3u;
         }
-        uint32_t incl = len;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
+        const uint32_t incl = WaveInclusiveAdd(len);
         if (live) {
             rec.off  = base_off + incl - len;
             rec.meta = (rec.meta & 0x4ffu) | (emit_fg ? 0x100u : 0u) | (emit_bg ? 0x200u : 0u) |
@@ -344,10 +334,10 @@ ScanRowsKernel(BlockGeom g, CellRec *cells, uint32_t *row_len) {
             row[i] = rec;
         }
         // carry
-        base_off += __shfl(incl, 63);
-        const int chunk_p = __shfl(sp, 63), chunk_n = __shfl(sn, 63);
-        const uint32_t cbg = __shfl(rec.bg, chunk_p < 0 ? 0 : chunk_p);
-        const uint32_t cfg = __shfl(rec.fg, chunk_n < 0 ? 0 : chunk_n);
+        base_off += ReadLane(incl, 63);
+        const int chunk_p = (int)ReadLane(ip, 63) - 1, chunk_n = (int)ReadLane(in, 63) - 1;  // (wave-uniform)
+        const uint32_t cbg = ReadLane(rec.bg, chunk_p < 0 ? 0 : chunk_p);
+        const uint32_t cfg = ReadLane(rec.fg, chunk_n < 0 ? 0 : chunk_n);
         if (chunk_p >= 0) {
             last_present = c0 + chunk_p;
             prev_bg      = cbg;
@@ -409,12 +399,7 @@ ScanFramesKernel(BlockGeom g, uint32_t *row_len, uint32_t *row_yskip,
             // up to four '\n', else ESC [ k B (:249-258)
             v = rl[r] + (k == 0 ? 0u : (k <= 4 ? k : 3u + DecLen(k)));
         }
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
+        const uint32_t incl = WaveInclusiveAdd(v);
         if (lane == 63) wave_tot[wv] = incl;
         __syncthreads();
         uint32_t before = carry;

@@ -1578,7 +1578,6 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         const int prog_lo = round * n_pub, prog_hi = round * n_pub + n_pub;
         // (a wave with no row above it finds every column "published": its own counter, against a base far below)
         const int in_base        = follows ? producer_round * n_pub : -(1 << 30);
-        const int out_base       = round * n_pub;
 
         // terms of this row's own recent errors (pairs of q << 8):
         //   own7 = 7/16 of e(x-1)  -> this row's next pixel

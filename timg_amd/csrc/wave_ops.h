@@ -49,6 +49,20 @@ __device__ __forceinline__ uint32_t WaveMaxU32(uint32_t v) {
     return ReadLane(v, 63);
 }
 
+// inclusive prefix maximum over the 64 lanes
+__device__ __forceinline__ uint32_t WaveInclusiveMaxU32(uint32_t v) {
+    v = max(v, TIMG_DPP0(v, 0x111, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x112, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x114, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x118, 0xf));
+    v = max(v, TIMG_DPP0(v, 0x142, 0xa));
+    v = max(v, TIMG_DPP0(v, 0x143, 0xc));
+    return v;
+}
+
+// the value of the lane below (lane 0: 0)
+__device__ __forceinline__ uint32_t WaveShr1(uint32_t v) { return TIMG_DPP0(v, 0x138, 0xf); }  // wave_shr:1
+
 // exclusive prefix maximum over the 64 lanes (lane 0: 0)
 __device__ __forceinline__ uint32_t WaveExclusiveMaxU32(uint32_t v) {
     v = max(v, TIMG_DPP0(v, 0x111, 0xf));

@@ -1932,7 +1932,11 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     ss->hfirst = !p.vertical_first;
     ss->hwin   = hwin;
     for (const StripInfo &si : strips) ss->hrow = std::max(ss->hrow, si.ox1 - si.ox0);
-    int tall = 45;
+    // Tall bands: 45 output rows for vertical-first plans (flat between 45 and 150: profiles/r5/band_rows.txt).  A
+    // horizontal-first plan pays every band's vertical halo with a full horizontal pass over the halo's source rows (39
+    // rows of 8K per band at 9.6:1): 90 rows -- 4.20 ms per 64 8K frames against 4.44 at 45 (profiles/r5/band_rows_c5.txt;
+    // 113 and more leave the 768 workgroup slots of that kernel half empty in the last round).
+    int tall = p.vertical_first ? 45 : 90;
     if (const char *e = getenv("TIMG_HIP_BAND_ROWS")) tall = atoi(e) > 0 ? atoi(e) : tall;  // tuning
     tall = std::max(1, std::min(p.out_h, tall));
     tall = (p.out_h + (p.out_h + tall - 1) / tall - 1) / ((p.out_h + tall - 1) / tall);  // (equally tall bands)

@@ -304,10 +304,46 @@ def main():
         if box[0][0] == "error":
             exchange = {"ranks": world, "via": "torch.distributed (C-ABI communicator unavailable: %s)" % box[0][1]}
         else:
-            # (every rank enters ncclCommInitRank together; a failure here is fatal for the job, as it should be)
-            cabi = tcomm.Comm(local_rank, world, rank, box[0][0])
-            exchange = {"ranks": world, "via": "timg_hip_gather_lengths + timg_hip_gather_payload (libtimg_hip_comm.so, C-ABI)",
-                        "lib": box[0][1][0], "rccl_version": box[0][1][1], "gathers": 0, "bytes_at_root": 0}
+            # Every rank enters ncclCommInitRank together.  Then ONE small exchange is made and checked before any timing --
+            # this path has never run on more than one GPU (only one is reachable from the build container): if the
+            # communicator cannot be created or the self-test does not deliver every rank's bytes to the root in rank
+            # order, ALL ranks agree (an all-reduce over torch.distributed) to exchange through torch.distributed
+            # instead, and the JSON line says so -- a scaling run then still produces its numbers.
+            import numpy as np
+            ok, why = 1, ""
+            try:
+                cabi = tcomm.Comm(local_rank, world, rank, box[0][0])
+                probe = torch.full((16,), 0x40 + rank, dtype=torch.uint8, device="cuda")
+                back = torch.zeros(16 * world, dtype=torch.uint8, device="cuda") if rank == 0 else None
+                torch.cuda.synchronize()
+                al = cabi.gather_lengths(np.array([16], np.uint64), 1)
+                got = cabi.gather_payload(probe.data_ptr(), al, back.data_ptr() if rank == 0 else 0,
+                                          16 * world if rank == 0 else 0, stream=tcomm.PAYLOAD_READY)
+                if rank == 0:
+                    want = torch.arange(world, dtype=torch.uint8).repeat_interleave(16) + 0x40
+                    if got != 16 * world or not torch.equal(back.cpu(), want):
+                        ok, why = 0, "self-test: the root received %d bytes, not every rank's 16 in rank order" % got
+            except Exception as exc:
+                ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                agreed = int(flag.item())
+            else:
+                agreed = ok
+            if agreed:
+                exchange = {"ranks": world, "via": "timg_hip_gather_lengths + timg_hip_gather_payload (libtimg_hip_comm.so, C-ABI)",
+                            "lib": box[0][1][0], "rccl_version": box[0][1][1], "gathers": 0, "bytes_at_root": 0,
+                            "self_test": "16 bytes per rank delivered to the root in rank order before the timed region"}
+            else:
+                if cabi is not None:
+                    try:
+                        cabi.close()
+                    except Exception:
+                        pass
+                cabi = None
+                exchange = {"ranks": world, "via": "torch.distributed (the C-ABI communicator failed its start-up self-test on "
+                                                   "some rank%s)" % (": " + why if why else "")}
     elif world > 1:
         exchange = {"ranks": world, "via": "torch.distributed over %s (testing configuration)" % backend}
     recv_buf = [None]

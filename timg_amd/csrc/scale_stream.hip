@@ -1054,7 +1054,9 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
             // No overflow row: the completed slot is only READ here (it restarts through keep == 0), and it
             // is read through selects on the uniform slot number -- one code path.  (Four specialised
             // paths that only read get merged by the compiler into ONE path indexing a copy of the
-            // accumulators in scratch memory, with a store behind every update in the hot loop.)
+            // accumulators in scratch memory, with a store behind every update in the hot loop.  Round 5 tried
+            // TWO paths by slot pair with one select per value, the stores inside the branches: 12 selects
+            // instead of 36 -- and 4.55 ms instead of 0.67: the same demotion.  profiles/r5/scale_variants.txt.)
             const bool s0 = code == 1, s1 = code == 2, s2 = code == 3;
             auto pick = [&](const float a[kMSlots]) { return s0 ? a[0] : s1 ? a[1] : s2 ? a[2] : a[3]; };
 #pragma unroll

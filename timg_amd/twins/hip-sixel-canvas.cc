@@ -89,14 +89,17 @@ HipSixelCanvas::~HipSixelCanvas() {
 // buffers, all of it behind the batch's LAST Send: with a queue long enough for a whole 8x8 grid (129) the twins used
 // to hold all 64 images back -- nothing was encoded while the sources were still being scaled, two of the three
 // encode workers never ran, and the run took 2.5x as long as with rows of 8 (17.4 against 45.1 Gpx/s, BENCH_r04).
-// Beyond ~16 frames a batch buys nothing on the device either (the chain's length is the diffusion's W + 2(H - 1)
-// dependent steps whatever the batch), so longer queues now mean MORE batches in flight, not longer ones.
+// Beyond a grid row's worth a batch buys nothing on the device either (the chain's length is the diffusion's
+// W + 2(H - 1) dependent steps whatever the batch), so longer queues now mean MORE batches in flight, not longer ones.
+// Measured (profiles/r5/twin_batch_cap.txt, metric configuration / the 600-frame stream, Gpx/s by queue length
+// 4 / 17 / 33 / 64 / 129): cap 8: 22 / 47 / 64 / 48 / 46 and 38 / 86 / 108 / 103 / 97; cap 16: 20 / 51 / 59 / 33 / 34
+// and 39 / 53 / 84 / 88 / 88; cap 64 (round 4): 17-23 at queue 129.
 // (TIMG_HIP_TWIN_BATCH_CAP: tuning / the old behaviour for comparison.)
 static int BatchCap() {
     static const int cap = []() {
         const char *e = getenv("TIMG_HIP_TWIN_BATCH_CAP");
         const int v   = e ? atoi(e) : 0;
-        return v > 0 ? v : 16;
+        return v > 0 ? v : 8;
     }();
     return cap;
 }

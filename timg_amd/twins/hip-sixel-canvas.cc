@@ -125,8 +125,16 @@ void HipSixelCanvas::Flush() {
 void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     const size_t n    = batch.frames.size();
     const size_t slot = timg_hip_sixel_max_bytes(batch.w, batch.h) * 2;
-    // (uninitialised on purpose: a std::vector would zero 3.6 MB per frame; only the bytes a frame produced are touched)
-    std::unique_ptr<char[]> bytes(new char[slot * n]);
+    // The batch's staging buffer: one per worker thread, kept (a fresh 29 MB mapping per batch cost its page faults
+    // every time); uninitialised on purpose -- only the bytes a frame produced are touched.
+    thread_local std::unique_ptr<char[]> staging;
+    thread_local size_t staging_cap = 0;
+    if (staging_cap < slot * n) {
+        staging.reset(new char[slot * n]);
+        staging_cap = slot * n;
+    }
+    char *const bytes_ptr = staging.get();
+    struct { char *p; char *get() const { return p; } } bytes{bytes_ptr};
     std::vector<size_t> lens(n);
     const int flags = EncodeFlags();
     const bool trace = HipTwinTrace();
@@ -143,8 +151,14 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     for (size_t i = 0; i < n; ++i) {
         HeldFrame &f = batch.frames[i];
         if (on_device) {
-            if (f.prefix + lens[i] > f.cap) HipFatal(ctx_, "sixel frame larger than its buffer");
-            memcpy(f.buffer + f.prefix, bytes.get() + i * slot, lens[i]);
+            // the buffer the sequencer gets (freed with delete[] by the writer thread): the prefix kept at Send time +
+            // the frame, exactly
+            char *final = new char[f.prefix + lens[i]];
+            memcpy(final, f.buffer, f.prefix);
+            memcpy(final + f.prefix, bytes.get() + i * slot, lens[i]);
+            delete[] f.buffer;
+            f.buffer = final;
+            f.cap    = f.prefix + lens[i];
         } else {
             lens[i] = EncodeOnCpu(ctx, f.buffer, f.prefix, f.cap, batch.data() + i * frame_bytes, batch.on_device, batch.w,
                                   batch.h, "timg_hip_sixel_encode");
@@ -183,16 +197,20 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         pad.pattern_h = options_.pattern_size * options_.cell_y_px / 2;
         pad.start_row = h;
     }
-    const size_t cap     = kPrefixBudget + timg_hip_sixel_max_bytes(w, h) * 2;
-    char *const buffer   = new char[cap];
-    char *const offset   = AppendPrefixToBuffer(buffer);  // must happen on this thread
     // a frame of a device-resident source is encoded where it is (hip-device-frames.h)
     const uint8_t *const device = DevicePixels(fb_orig);
     if (may_hold) {
+        // A held frame's bytes arrive in the batch's staging buffer and are copied into the buffer the sequencer gets:
+        // that buffer is allocated THEN, with the size the frame has (a few hundred KB).  Here only the prefix is kept.
+        // (Round 4 allocated the worst case -- 16 KB + 2 x 1.8 MB -- per Send: with a long queue the main thread ran
+        // far ahead of the writer and every one of those was a fresh mapping.)
+        char prefix[kPrefixBudget];
+        const size_t prefix_len = (size_t)(AppendPrefixToBuffer(prefix) - prefix);  // must happen on this thread
         HeldFrame f;
-        f.buffer = buffer;
-        f.prefix = (size_t)(offset - buffer);
-        f.cap    = cap;
+        f.buffer = new char[prefix_len ? prefix_len : 1];
+        memcpy(f.buffer, prefix, prefix_len);
+        f.prefix = prefix_len;
+        f.cap    = prefix_len;
         f.x      = x;
         f.dy     = dy;
         write_sequencer_->WriteBuffer(rows_->Hold(w, h, device ? device : (const uint8_t *)fb_orig.begin(), device != nullptr,
@@ -201,6 +219,9 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         return;
     }
     if (rows_) rows_->Seal();  // (a row in progress ends here; its futures are already queued in front of this one)
+    const size_t cap     = kPrefixBudget + timg_hip_sixel_max_bytes(w, h) * 2;
+    char *const buffer   = new char[cap];
+    char *const offset   = AppendPrefixToBuffer(buffer);  // must happen on this thread
     // The framebuffer is only valid during this call: copy before going async (device frames:
     // a device-to-device copy on the context's stream, ordered before whatever the source does next).
     const size_t frame_bytes = (size_t)w * h * 4;

@@ -449,15 +449,28 @@ def main():
             run_batched_streams(pipes, src, n_steps, n_pipes, 2 if force_gather else world, timed_gather, timed_events, record,
                                 async_encode=not args.sync_encode)
             return
+        # (one rank, sixel: a chunk is enqueued -- timg_hip_sixel_encode_async -- and its byte counts are read after the
+        # next chunk's launches; with several ranks the gather needs a chunk's counts at once: the blocking form)
+        use_async = (world == 1 and not force_gather and not args.sync_encode and pipe.can_async())
         for _ in range(n_steps):  # a step = the whole sharded stream, chunk by chunk
+            pending = None  # (pipeline, job slot) whose byte counts have not been read yet
             for k in range(n_launches_max):
                 c = chunks[k] if k < len(chunks) else None
                 if c is not None:
                     p = tail_pipe if (tail_pipe is not None and c.shape[0] != chunk) else pipe
+                    if pending is not None and pending[0] is not p:
+                        # (the ragged tail has a pipeline -- a stream -- of its own on the SAME context: the scratch the two
+                        # share is only safe in stream order, so the chunk in flight is waited for before the switch)
+                        pending[0].finish(slot=pending[1])
+                        pending = None
                     e0 = record(p.stream)
                     if p.fused:
                         p.step(c)
                         e1 = None
+                    elif use_async:
+                        p.scale(c)
+                        e1 = record(p.stream)
+                        p.encode_begin(slot=k & 1)
                     else:
                         p.scale(c)
                         e1 = record(p.stream)
@@ -465,6 +478,10 @@ def main():
                     e2 = record(p.stream)
                     if timed_events is not None:
                         timed_events.append((e0, e1, e2, p.last_scale_ms))
+                    if use_async:
+                        if pending is not None:
+                            pending[0].finish(slot=pending[1])
+                        pending = (p, k & 1)
                 if world > 1 or force_gather:
                     # every rank takes part in every gather; ranks that own fewer frames pad their
                     # lengths with zeros (the gather wants the same frame count everywhere)
@@ -477,6 +494,8 @@ def main():
                     if lens.numel() < want:
                         lens = torch.cat([lens, torch.zeros(want - lens.numel(), dtype=torch.int64, device="cuda")])
                     timed_gather(payload, lens)
+            if pending is not None:
+                pending[0].finish(slot=pending[1])
 
     def timed(n_steps, n_pipes, timed_events=None):
         torch.cuda.synchronize()
@@ -592,7 +611,7 @@ def main():
             "pieces": pipe.pieces,
             "encode_call": ("timg_hip_sixel_encode_async: a step is enqueued, its byte counts are read after the next step's "
                             "launches (two jobs alternate)"
-                            if (pipe.can_async() and world == 1 and not force_gather and not strong and not args.sync_encode)
+                            if (pipe.can_async() and world == 1 and not force_gather and not args.sync_encode)
                             else "blocking (the call returns the frames' byte counts)"),
             "scale_kernel": "streaming" if (info["streaming_ok"] and args.kernel != 1) else "generic",
             "pass_order": "vertical-first" if info["vertical_first"] else "horizontal-first",

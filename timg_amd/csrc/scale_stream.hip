@@ -575,6 +575,26 @@ struct MTables {
     const RowRec *rec22;  // rec with every weight times 2^22 (exact): for samples decoded as d * 2^-22 (DecodeScaled)
 };
 
+// one correctly rounded fp32 multiplication / addition as ONE instruction (never contracted, never regrouped)
+__device__ __forceinline__ float MulRn(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a float4 slot of LDS as ONE 16-byte read: the value passes through an (empty) asm as a whole register tuple, so
+// that the compiler cannot split the read by its uses (a ds_read_b96, or two 8-byte halves, cost the LDS twice
+// the cycles of a ds_read_b128)
+__device__ __forceinline__ f4v LdsSlot(const void *p) {
+    f4v v = *reinterpret_cast<const f4v *>(p);
+    asm("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float AddRn(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Horizontal pass of a completed row, every lane its own output column(s): weights as
 // float4 groups in LDS (taps beyond a column's count have weight 0 and read staged or
 // zeroed data: acc + v * 0 leaves the sum as it is), tap k of the pair (k, k+1) feeds the
@@ -605,31 +625,32 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
                 }
             }
         } else {
+            // Channel PAIRS (x, y) and (z, w) of a staged column as the operands of packed multiplies and adds -- said
+            // as two-float vectors: left to pair the scalar form itself, the vectoriser paired channels of different
+            // taps and paid ten register moves and four unpacked multiplies per four taps (28 instructions where 16 do;
+            // round 5, read off the premultiplied kernel's assembly).  Same operations in the same order per channel.
+            f2v e01 = {0.0f, 0.0f}, e23 = {0.0f, 0.0f}, o01 = {0.0f, 0.0f}, o23 = {0.0f, 0.0f};
             for (int g = 0; g < hgroups; ++g) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(wbase + (size_t)g * hrow * 4);
-                const float4 t0 = *reinterpret_cast<const float4 *>(base + (g * 4 + 0) * 16);
-                const float4 t1 = *reinterpret_cast<const float4 *>(base + (g * 4 + 1) * 16);
-                const float4 t2 = *reinterpret_cast<const float4 *>(base + (g * 4 + 2) * 16);
-                const float4 t3 = *reinterpret_cast<const float4 *>(base + (g * 4 + 3) * 16);
-                even[0] = even[0] + t0.x * w4.x;
-                even[1] = even[1] + t0.y * w4.x;
-                even[2] = even[2] + t0.z * w4.x;
-                even[3] = even[3] + t0.w * w4.x;
-                odd[0]  = odd[0] + t1.x * w4.y;
-                odd[1]  = odd[1] + t1.y * w4.y;
-                odd[2]  = odd[2] + t1.z * w4.y;
-                odd[3]  = odd[3] + t1.w * w4.y;
-                even[0] = even[0] + t2.x * w4.z;
-                even[1] = even[1] + t2.y * w4.z;
-                even[2] = even[2] + t2.z * w4.z;
-                even[3] = even[3] + t2.w * w4.z;
-                odd[0]  = odd[0] + t3.x * w4.w;
-                odd[1]  = odd[1] + t3.y * w4.w;
-                odd[2]  = odd[2] + t3.z * w4.w;
-                odd[3]  = odd[3] + t3.w * w4.w;
+                const f4v w4 = LdsSlot(wbase + (size_t)g * hrow * 4);
+                const f4v t0 = LdsSlot(base + (g * 4 + 0) * 16);
+                const f4v t1 = LdsSlot(base + (g * 4 + 1) * 16);
+                const f4v t2 = LdsSlot(base + (g * 4 + 2) * 16);
+                const f4v t3 = LdsSlot(base + (g * 4 + 3) * 16);
+                e01 = e01 + f2v{t0.x, t0.y} * f2v{w4.x, w4.x};
+                e23 = e23 + f2v{t0.z, t0.w} * f2v{w4.x, w4.x};
+                o01 = o01 + f2v{t1.x, t1.y} * f2v{w4.y, w4.y};
+                o23 = o23 + f2v{t1.z, t1.w} * f2v{w4.y, w4.y};
+                e01 = e01 + f2v{t2.x, t2.y} * f2v{w4.z, w4.z};
+                e23 = e23 + f2v{t2.z, t2.w} * f2v{w4.z, w4.z};
+                o01 = o01 + f2v{t3.x, t3.y} * f2v{w4.w, w4.w};
+                o23 = o23 + f2v{t3.z, t3.w} * f2v{w4.w, w4.w};
             }
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) even[ch] = even[ch] + odd[ch];
+            e01     = e01 + o01;
+            e23     = e23 + o23;
+            even[0] = e01.x;
+            even[1] = e01.y;
+            even[2] = e23.x;
+            even[3] = e23.y;
         }
         Px7 px;
         if (M == kOpaque) {  // with alpha == 1 the straight and the weighted sums coincide
@@ -654,26 +675,6 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
         const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, blend, flag);
         *reinterpret_cast<uint32_t *>(dst_row + (size_t)ox * 4) = out;
     }
-}
-
-// one correctly rounded fp32 multiplication / addition as ONE instruction (never contracted, never regrouped)
-__device__ __forceinline__ float MulRn(float a, float b) {
-    float r;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a float4 slot of LDS as ONE 16-byte read: the value passes through an (empty) asm as a whole register tuple, so
-// that the compiler cannot split the read by its uses (a ds_read_b96, or two 8-byte halves, cost the LDS twice
-// the cycles of a ds_read_b128)
-__device__ __forceinline__ f4v LdsSlot(const void *p) {
-    f4v v = *reinterpret_cast<const f4v *>(p);
-    asm("" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ float AddRn(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
 }
 
 // The same pass for all-opaque tiles: three channels in the chains, alpha and its reciprocal from the host's
@@ -766,7 +767,11 @@ template <int M, bool kOvf> struct MKernelShape {
     // premultiplied one fits 125 with THREE source rows in flight instead of four (at four it needs 129 and spilled ring
     // registers behind their loads: check_ring_isa.py refused it) -- 0.893 -> 0.868 ms per 64 S-alpha frames.
     static constexpr int kWaves = !kOvf ? 4 : (M == kPremult) ? 2 : 3;
+#ifdef TIMG_M_PREMULT_DEPTH
+    static constexpr int kDepth = (M == kPremult && !kOvf) ? TIMG_M_PREMULT_DEPTH : 4;  // source rows in flight per lane
+#else
     static constexpr int kDepth = (M == kPremult && !kOvf) ? 3 : 4;  // source rows in flight per lane
+#endif
     static constexpr int kStage = kWaves == 4 ? 1 : 2;              // staging rows
     // rows in flight in registers reserved from the compiler (see the kernel's main loop); 0: named variables
 #ifdef TIMG_M_VRING

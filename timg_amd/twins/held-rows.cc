@@ -40,6 +40,15 @@ HeldRows::~HeldRows() {
     for (auto &w : workers_) w.join();  // (the workers empty sealed_ before they leave)
 }
 
+int HeldRows::BatchCap() {
+    static const int cap = []() {
+        const char *e = getenv("TIMG_HIP_TWIN_BATCH_CAP");
+        const int v   = e ? atoi(e) : 0;
+        return v > 0 ? v : 8;
+    }();
+    return cap;
+}
+
 int HeldRows::HoldLimit(int grid_columns, size_t sequencer_queue_len) {
     // the writer holds the first future; behind it the queue must take the other futures of the
     // batch and one control write (CursorOn) per image

@@ -72,6 +72,8 @@ public:
 
     // Largest number of Sends one device call may cover.
     static int HoldLimit(int grid_columns, size_t sequencer_queue_len);
+    // ... and the twins' own bound on it (hip-sixel-canvas.cc has the measurements): 8, or TIMG_HIP_TWIN_BATCH_CAP.
+    static int BatchCap();
 
     // Adds a frame to the open batch (sealing an open batch of another size first) and returns
     // the future the caller hands to the sequencer.  Seals the batch when it reaches `limit`.

@@ -95,25 +95,16 @@ HipSixelCanvas::~HipSixelCanvas() {
 // 4 / 17 / 33 / 64 / 129): cap 8: 22 / 47 / 64 / 48 / 46 and 38 / 86 / 108 / 103 / 97; cap 16: 20 / 51 / 59 / 33 / 34
 // and 39 / 53 / 84 / 88 / 88; cap 64 (round 4): 17-23 at queue 129.
 // (TIMG_HIP_TWIN_BATCH_CAP: tuning / the old behaviour for comparison.)
-static int BatchCap() {
-    static const int cap = []() {
-        const char *e = getenv("TIMG_HIP_TWIN_BATCH_CAP");
-        const int v   = e ? atoi(e) : 0;
-        return v > 0 ? v : 8;
-    }();
-    return cap;
-}
-
 void HipSixelCanvas::SetGridColumns(int columns) {
     Flush();
-    hold_limit_ = std::min(HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len()), BatchCap());
+    hold_limit_ = std::min(HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len()), HeldRows::BatchCap());
     if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *c) { EncodeBatch(b, c); }, kEncodeWorkers));
 }
 
 void HipSixelCanvas::SetStreamHold(int frames) {
     Flush();
     const int by_queue = (int)write_sequencer_->max_queue_len();  // the writer's future + a full queue behind it
-    stream_hold_       = std::max(1, std::min(std::min(frames, by_queue), BatchCap()));
+    stream_hold_       = std::max(1, std::min(std::min(frames, by_queue), HeldRows::BatchCap()));
     if (stream_hold_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *c) { EncodeBatch(b, c); }, kEncodeWorkers));
 }
 

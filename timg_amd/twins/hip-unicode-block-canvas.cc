@@ -1,5 +1,6 @@
 #include "hip-unicode-block-canvas.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +62,9 @@ HipUnicodeBlockCanvas::~HipUnicodeBlockCanvas() {
 
 void HipUnicodeBlockCanvas::SetGridColumns(int columns) {
     Flush();
-    hold_limit_ = HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len());
+    // (capped like the sixel twin's batches: with a queue long enough for a whole 8x8 grid one 64-frame batch held every
+    // Send back until the last source was scaled -- 31 Gpx/s at queue 129 against 40 at queue 17, profiles/r5/twin_bench.txt)
+    hold_limit_ = std::min(HeldRows::HoldLimit(columns, write_sequencer_->max_queue_len()), HeldRows::BatchCap());
     if (hold_limit_ > 1 && !rows_) rows_.reset(new HeldRows(ctx_, [this](HeldBatch &b, timg_hip_ctx *) { EncodeBatch(b); }));  // (one worker: the canvas has state)
 }
 

@@ -26,12 +26,31 @@ def test_twin_sources_bind_only_the_c_abi():
             assert "CpuFallback" not in body, f
 
 
+def _page_in(path):
+    """twin_check is a process without PyTorch: its gather stage maps ROCm's own librccl.so.1 (570 MB), and on a GPU box
+    whose image is still paging in, the first process to do that waited 320-480 s for it, one small random read per page
+    fault (`profiles/r5/twin_times.txt`; the stage itself takes seconds, a sequential read of the file 90 s).  Read the
+    file ahead of it, in parallel pieces: test plumbing for a slow disk, nothing of the product."""
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        fd = os.open(os.path.realpath(path), os.O_RDONLY)
+    except OSError:
+        return
+    try:
+        size, piece = os.fstat(fd).st_size, 4 << 20
+        with ThreadPoolExecutor(16) as pool:
+            list(pool.map(lambda at: len(os.pread(fd, piece, at)), range(0, size, piece)))
+    finally:
+        os.close(fd)
+
+
 @pytest.mark.gpu
 def test_twins_match_reference_classes(oracle, tmp_path):
     if not os.path.exists(BIN):
         pytest.skip("tests/twins/build/twin_check not built (needs /root/reference at build time)")
     dump = tmp_path / "sixel.bin"
-    r = subprocess.run([BIN, "all", str(dump)], capture_output=True, text=True, timeout=600)
+    _page_in("/opt/rocm/lib/librccl.so.1")
+    r = subprocess.run([BIN, "all", str(dump)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all twins match" in r.stdout
     # (includes MultiColumnRenderer from the reference driving the block canvas twin in its

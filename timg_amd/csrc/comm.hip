@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -55,7 +56,14 @@ void BindRccl() {
             break;
         }
     }
-    // 2. none: the loader's search path, then ROCm's default prefix
+    // 2. the file the deployment names (TIMG_HIP_RCCL_LIB=/path/to/librccl.so): a process that maps no RCCL yet can be
+    //    pointed at the copy its neighbours already use -- ROCm's own librccl.so.1 is 570 MB, and the first process to
+    //    map it on a box whose image is still paging in waits minutes for it (tests/test_twins.py names PyTorch's)
+    if (!h) {
+        const char *named = getenv("TIMG_HIP_RCCL_LIB");
+        if (named && *named && (h = dlopen(named, RTLD_NOW | RTLD_LOCAL))) g_rccl.how = std::string("loaded as ") + named;
+    }
+    // 3. none: the loader's search path, then ROCm's default prefix
     if (!h) {
         static const char *kLoad[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char *n : kLoad) {

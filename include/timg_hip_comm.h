@@ -14,8 +14,9 @@
  * It is a separate shared object (libtimg_hip_comm.so) so that the single-GPU library carries no
  * RCCL dependency.  RCCL itself is NOT linked: the library binds the RCCL the process already
  * maps (a host program that brings its own -- e.g. one that also holds PyTorch -- gets exactly
- * that one, never a second copy), and only when none is mapped loads librccl.so.1 by the usual
- * search path, then /opt/rocm/lib.  timg_hip_comm_rccl_info says which library answered.
+ * that one, never a second copy), and only when none is mapped loads the file TIMG_HIP_RCCL_LIB
+ * names, else librccl.so.1 by the usual search path, then /opt/rocm/lib.  timg_hip_comm_rccl_info
+ * says which library answered.
  * The communicator is bootstrapped like every NCCL/RCCL program: rank 0 creates a unique id, the
  * host program hands those 128 bytes to the other ranks by whatever means it has (environment,
  * file, MPI, torch.distributed), every rank calls timg_hip_comm_create.  Plain C types only; every

@@ -99,6 +99,32 @@ def test_rccl_gather_through_the_c_abi_world_1():
     print("RCCL:", path, version)
 
 
+@pytest.mark.gpu
+def test_rccl_library_named_by_the_environment(tmp_path):
+    """A process that maps no RCCL yet (no PyTorch: plain ctypes) binds the file TIMG_HIP_RCCL_LIB names before it
+    searches the loader's path: `timg_hip_comm_rccl_info` says so.  A name that cannot be loaded is not an error: the
+    search goes on."""
+    rocm = os.path.realpath("/opt/rocm/lib/librccl.so.1")
+    if not os.path.exists(rocm):
+        pytest.skip("no /opt/rocm/lib/librccl.so.1")
+    named = tmp_path / "the_rccl_of_this_deployment.so"
+    os.symlink(rocm, named)
+    child = (
+        "import ctypes, sys\n"
+        "L = ctypes.CDLL(%r)\n"
+        "buf, ver = ctypes.create_string_buffer(512), ctypes.c_int(0)\n"
+        "rc = L.timg_hip_comm_rccl_info(buf, ctypes.c_size_t(512), ctypes.byref(ver))\n"
+        "print(rc, ver.value, buf.value.decode())\n"
+    ) % os.path.join(ROOT, "timg_amd", "libtimg_hip_comm.so")
+    for value, expect in ((str(named), "loaded as " + str(named)), (str(tmp_path / "absent.so"), "loaded as librccl")):
+        r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, TIMG_HIP_RCCL_LIB=value))
+        assert r.returncode == 0, r.stdout + r.stderr
+        rc, version, how = r.stdout.strip().splitlines()[-1].split(" ", 2)
+        assert int(rc) == 0 and int(version) > 0, r.stdout
+        assert expect in how or (expect == "loaded as librccl" and "loaded as /opt/rocm" in how), how
+
+
 def test_comm_library_does_not_link_rccl():
     """libtimg_hip_comm.so binds RCCL at run time (dlopen, RTLD_NOLOAD first): no DT_NEEDED on librccl, so
     the host program's RCCL is never shadowed by a second one."""

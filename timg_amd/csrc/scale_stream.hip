@@ -824,6 +824,12 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
         }
     }
     if (tid == 0) fail = 0;
+#ifdef TIMG_M_STAGGER  // (experiment: the workgroups of a CU start together and complete their output rows in phase)
+    {
+        const unsigned ph = ((unsigned)tile * 2654435761u) >> 30;  // 0..3, by the tile
+        for (unsigned i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(TIMG_M_STAGGER);
+    }
+#endif
     BlockSync();
 
     const int col0 = si.cx0 + tid * kPix;

@@ -2,7 +2,7 @@
 """check_ring_isa.py <device assembly of scale_stream.hip or sixel_canvas.hip>
 
 ScaleStreamMKernel keeps source rows in flight in a ring of register sets that are loaded by inline
-asm (`global_load_dwordx4`) and released by an inline-asm `s_waitcnt vmcnt(n) ; ring v[a:b]`; the sixel
+asm (`global_load_dwordx4`; round 6: four typed `buffer_load_format_xyzw` a row) and released by an inline-asm `s_waitcnt vmcnt(n) ; ring v[a:b]`; the sixel
 DitherKernel does the same with source pixels (`global_load_dword`, `; ring vN`).  The
 compiler does not know that such a load completes later: this script proves, on the generated code,
 that on no path between a set's load and its wait an instruction outside the asm statements names one
@@ -28,7 +28,7 @@ REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 # tracked in the same sets as the vector registers, numbered from AGPR_BASE.
 AGPR_BASE = 1000
 AREG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
-LOAD = re.compile(r"global_load_dwordx[24] v\[(\d+):(\d+)\]")  # (x2: the sixel diffusion's pixel pairs)
+LOAD = re.compile(r"(?:global_load_dwordx[24]|buffer_load_dwordx4|buffer_load_format_xyzw?) v\[(\d+):(\d+)\]")  # (x2: the sixel diffusion's pixel pairs; buffer_load_format: the typed rows of the matrix scale kernel, round 6)
 LOAD_A = re.compile(r"global_load_dwordx4 a\[(\d+):(\d+)\]")
 LOAD1 = re.compile(r"global_load_(?:dword|ubyte) v(\d+),")  # (the sixel diffusion's one-pixel ring)
 WAIT = re.compile(r"s_waitcnt vmcnt\(\d+\) ; ring (.*)")

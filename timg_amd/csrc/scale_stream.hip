@@ -542,23 +542,6 @@ struct RowRec {  // 48 bytes through the scalar cache per source row, from a poi
     float keep[kMSlots];  // 0 on the source row that STARTS an output row in the slot, else 1 (see the sums)
     RowCtl ctl;
 };
-// The opaque matrix kernel's decode, ONE instruction per colour byte.  stb's sample is d = RN(float(u8) * RN(1/255))
-// (stb_image_resize2.h:8300-8321), so far a v_cvt_f32_ubyteN and half a v_pk_mul_f32 per byte.  A multiply with an SDWA
-// byte select reads the byte AS THE BITS of a float: the denormal u * 2^-149, exact (the kernels run with fp32 denormals
-// on: .amdhsa_float_denorm_mode_32 3).  Times K = RN(1/255) * 2^127 (exact, 2^149 would overflow) the exact product is
-// u * RN(1/255) * 2^-22, rounded once in the normal range: RN(u * RN(1/255)) * 2^-22 = d * 2^-22 bit for bit.  The vertical
-// product then takes the weight as w * 2^22 (MTables::rec22: the same records with scaled weights, exact): (d * 2^-22) * (w * 2^22) IS d * w as a real number, and
-// the matrix pipe rounds that real number once -- the same fp32 product, whatever its magnitude (denormal results
-// included: same value, same rounding).  scratch/ubench/vmix.hip checks the identity for all 256 bytes on the device.
-constexpr float kDecodeScaled = 0x1.010102p+119f;  // RN(1.0f / 255.0f) * 2^127
-constexpr float kWeightScale  = 4194304.0f;        // 2^22
-template <int BYTE>
-__device__ __forceinline__ float DecodeScaled(uint32_t word, float k) {
-    // (plain C++: the compiler's SDWA peephole folds the byte extraction into the multiply's operand select --
-    // v_mul_f32_sdwa ... src0_sel:BYTE_n -- and schedules it like any other instruction; check_ring_isa.py counts them)
-    return __uint_as_float((word >> (8 * BYTE)) & 0xffu) * k;
-}
-
 // kOpaque: what the horizontal pass would compute in its alpha channel.  Every staged column of an all-opaque
 // tile carries the SAME alpha (the vertical weight sum of the row, a host constant), so the filtered alpha of
 // output column x is a function of (x, that constant) alone -- the host evaluates stb's even/odd chain for it
@@ -572,7 +555,6 @@ struct AlphaCell {
 struct MTables {
     const RowRec *rec;  // indexed like StreamTables::sched (BandInfo::sched + row - r0)
     const AlphaCell *alpha_tab;  // [distinct vertical alpha sums][out_w]
-    const RowRec *rec22;  // rec with every weight times 2^22 (exact): for samples decoded as d * 2^-22 (DecodeScaled)
 };
 
 // one correctly rounded fp32 multiplication / addition as ONE instruction (never contracted, never regrouped)
@@ -610,7 +592,7 @@ __device__ __forceinline__ void HorizontalRowM(const DevPlan &plan, const DevBle
         const int ox          = si.ox0 + o;
         const char *base      = reinterpret_cast<const char *>(stage_row) + hbase[o];
         const float *wbase    = hw + (size_t)o * 4;
-        float even[4] = {0.0f, 0.0f, 0.0f, 0.0f}, odd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float even[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (plan.h_sequential) {
             for (int g = 0; g < hgroups; ++g) {
                 const float4 w4 = *reinterpret_cast<const float4 *>(wbase + (size_t)g * hrow * 4);
@@ -688,11 +670,7 @@ __device__ __forceinline__ void HorizontalRowOpaque(const DevPlan &plan, const D
     uint8_t *dst_row = batch.dst + (size_t)f * batch.dst_frame_stride + (size_t)y * batch.dst_stride;
     for (int o = threadIdx.x; o < n_out; o += kThreads) {
         const int ox       = si.ox0 + o;
-#ifdef TIMG_HABL_NOAC  // (timing experiment, wrong bytes: no global load -- and no vmcnt(0) -- in the pass)
-        const AlphaCell ac = {1.0f, 0xff000000u};
-#else
         const AlphaCell ac = alpha_row[ox];  // (requested first: the tap loop hides it)
-#endif
         // (staged columns and weight groups are float4 slots: said out loud, or the 16-byte reads are split)
         const char *base   = reinterpret_cast<const char *>(
             __builtin_assume_aligned(reinterpret_cast<const char *>(stage_row) + hbase[o], 16));
@@ -773,13 +751,6 @@ template <int M, bool kOvf> struct MKernelShape {
     static constexpr int kDepth = (M == kPremult && !kOvf) ? 3 : 4;  // source rows in flight per lane
 #endif
     static constexpr int kStage = kWaves == 4 ? 1 : 2;              // staging rows
-    // rows in flight in registers reserved from the compiler (see the kernel's main loop); 0: named variables
-#ifdef TIMG_M_VRING
-    static constexpr int kRing = (M == kOpaque && !kOvf) ? TIMG_M_VRING : 0;
-#else
-    static constexpr int kRing = 0;
-#endif
-    static constexpr int kVgprCap = kRing ? 128 - 4 * kRing : 0;  // (0: no cap of its own)
 };
 template <int M, bool kOvf>
 __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const StreamTables &tab, const MTables &mt,
@@ -824,12 +795,6 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
         }
     }
     if (tid == 0) fail = 0;
-#ifdef TIMG_M_STAGGER  // (experiment: the workgroups of a CU start together and complete their output rows in phase)
-    {
-        const unsigned ph = ((unsigned)tile * 2654435761u) >> 30;  // 0..3, by the tile
-        for (unsigned i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(TIMG_M_STAGGER);
-    }
-#endif
     BlockSync();
 
     const int col0 = si.cx0 + tid * kPix;
@@ -888,19 +853,13 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
     bool ok       = true;
     int ev        = 0;
     int wa        = 0;  // A operand: lanes 0..3 hold the four slot weights (rewritten every row)
-    float kdec    = kDecodeScaled;
-    asm volatile("" : "+v"(kdec));  // (in a register for the whole tile: the SDWA form of DecodeScaled takes no literal)
 #ifdef TIMG_M_TRACE
     unsigned long long tr_wait = 0, tr_vert = 0, tr_stage = 0, tr_horiz = 0, tr_bar2 = 0, tr_pro = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
     unsigned long long t_last = t_begin;
 #endif
 
-#ifdef TIMG_M_SDWA
-    const RowRec *rec_ptr = ((M == kOpaque && !kOvf) ? mt.rec22 : mt.rec) + bi.sched;
-#else
     const RowRec *rec_ptr = mt.rec + bi.sched;
-#endif
     RowRec rec_next       = LoadConstant(rec_ptr);
     auto row_step = [&](const uint4 &q_in, int r) __attribute__((always_inline)) -> bool {
         uint4 q = q_in;
@@ -910,11 +869,6 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
             q.y = shift == 0 ? b2 : shift == 1 ? c : d2;
             q.z = shift == 0 ? c : d2;
         }
-#ifdef TIMG_M_SDWA
-        constexpr bool kScaledDecode = M == kOpaque && !kOvf;  // (the overflow row multiplies d on the VALU: it keeps d itself)
-#else
-        constexpr bool kScaledDecode = false;
-#endif
         const RowW rw    = rec_next.w;
         const RowCtl ctl = rec_next.ctl;
         // (keep0, keep1) (keep2, keep3) as scalar register pairs
@@ -950,14 +904,7 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
         for (int p0 = 0; p0 < kPix; p0 += kBatch) {
             if (p0) __builtin_amdgcn_sched_barrier(0);
             float d[kBatch][kCh];
-            if (kScaledDecode) {
-#pragma unroll
-                for (int b = 0; b < kBatch; ++b) {
-                    d[b][0]               = DecodeScaled<0>(qs[p0 + b], kdec);
-                    d[b][1]               = DecodeScaled<1>(qs[p0 + b], kdec);
-                    d[b][kCh > 2 ? 2 : 0] = DecodeScaled<2>(qs[p0 + b], kdec);
-                }
-            } else if (M == kOpaque) {
+            if (M == kOpaque) {
                 // u8 * (1/255) for the six colour bytes of two pixels as three packed multiplies
                 static_assert(M != kOpaque || kBatch <= 2, "one or two pixels");
                 const uint32_t pa = qs[p0], pb = qs[p0 + (kBatch > 1 ? 1 : 0)];
@@ -1003,19 +950,12 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
                 for (int ch = 0; ch < kCh; ++ch) {
                     const f2v lo = {prod[b][ch].x, prod[b][ch].y}, hi = {prod[b][ch].z, prod[b][ch].w};
                     float *a      = acc[p0 + b][ch];
-#ifdef TIMG_M_PLAINFMA  // (experiment: the sums as four v_fma_f32 instead of two v_pk_fma_f32)
-                    a[0] = __builtin_fmaf(a[0], keep_lo.x, lo.x);
-                    a[1] = __builtin_fmaf(a[1], keep_lo.y, lo.y);
-                    a[2] = __builtin_fmaf(a[2], keep_hi.x, hi.x);
-                    a[3] = __builtin_fmaf(a[3], keep_hi.y, hi.y);
-#else
                     const f2v n01 = __builtin_elementwise_fma(f2v{a[0], a[1]}, keep_lo, lo);
                     const f2v n23 = __builtin_elementwise_fma(f2v{a[2], a[3]}, keep_hi, hi);
                     a[0] = n01.x;
                     a[1] = n01.y;
                     a[2] = n23.x;
                     a[3] = n23.y;
-#endif
                 }
             if (kOvf && (ctl.flags & 1)) {  // wave-uniform: the overflow row
 #pragma unroll
@@ -1129,59 +1069,6 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
     static_assert(kDepth == 3 || kDepth == 4 || kDepth == 8, "ring written out for 3, 4 or 8 rows");
     u4v q0, q1, q2, q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = q4, q6 = q4, q7 = q4;
     TIMG_M_MARK(tr_pro)
-    constexpr int kRingA = MKernelShape<M, kOvf>::kRing;  // rows in flight in RESERVED registers (0: the ring of named variables below)
-    static_assert(kRingA == 0 || kRingA == 4 || kRingA == 6, "written out for 4 or 6 rows in flight");
-    if constexpr (kRingA != 0) {
-        // The ring in vector registers the compiler does not allocate (amdgpu_num_vgpr caps ITS registers below them):
-        // a set is named only inside the asm statements here (load, wait, read-out), so no compiler-placed copy can
-        // touch a set in flight -- and a set is free the moment its four words are read out, so the request for the row
-        // kRingA steps ahead goes out BEFORE this row's arithmetic and before a completed row's horizontal pass: kRingA
-        // rows stay in flight through the whole step (the ring of named variables has kDepth - 1 while a row is worked on).
-#define TIMG_M_ISSUE_R(R0, R1, R2, R3)                                                                    \
-    {                                                                                                     \
-        const uint8_t *p = frame_lane + next_off;                                                         \
-        asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off ; reserved" : : "v"(p)                     \
-                     : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);                                     \
-        next_off = min(next_off + row_step_b, last_off);                                                  \
-    }
-#define TIMG_M_STEP_R(R0, R1, R2, R3, K)                                                                  \
-    if (left < K + 1) break;                                                                              \
-    {                                                                                                     \
-        uint4 qv;                                                                                         \
-        const uint8_t *p = frame_lane + next_off;                                                         \
-        asm volatile("s_waitcnt vmcnt(%5) ; ring v[" #R0 ":" #R3 "]\n\t"                                  \
-                     "v_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\t"                              \
-                     "v_mov_b32 %2, v" #R2 "\n\tv_mov_b32 %3, v" #R3 "\n\t"                              \
-                     "global_load_dwordx4 v[" #R0 ":" #R3 "], %4, off ; reserved"                          \
-                     : "=&v"(qv.x), "=&v"(qv.y), "=&v"(qv.z), "=&v"(qv.w)                                  \
-                     : "v"(p), "n"(kRingA - 1)                                                            \
-                     : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);                                     \
-        next_off = min(next_off + row_step_b, last_off);                                                  \
-        TIMG_M_MARK(tr_wait)                                                                              \
-        if (!row_step(qv, 0)) return;                                                                     \
-    }
-        TIMG_M_ISSUE_R(124, 125, 126, 127)
-        TIMG_M_ISSUE_R(120, 121, 122, 123)
-        TIMG_M_ISSUE_R(116, 117, 118, 119)
-        TIMG_M_ISSUE_R(112, 113, 114, 115)
-        if (kRingA == 6) {
-            TIMG_M_ISSUE_R(108, 109, 110, 111)
-            TIMG_M_ISSUE_R(104, 105, 106, 107)
-        }
-        for (int left = r1 - bi.r0 + 1; left > 0; left -= kRingA) {  // (rows still to do)
-            TIMG_M_STEP_R(124, 125, 126, 127, 0)
-            TIMG_M_STEP_R(120, 121, 122, 123, 1)
-            TIMG_M_STEP_R(116, 117, 118, 119, 2)
-            TIMG_M_STEP_R(112, 113, 114, 115, 3)
-            if (kRingA == 6) {
-                TIMG_M_STEP_R(108, 109, 110, 111, 4)
-                TIMG_M_STEP_R(104, 105, 106, 107, 5)
-            }
-        }
-#undef TIMG_M_STEP_R
-#undef TIMG_M_ISSUE_R
-        asm volatile("s_waitcnt vmcnt(0) ; ring all" : : : "memory");
-    } else {
     issue_next_row(q0);
     issue_next_row(q1);
     issue_next_row(q2);
@@ -1214,7 +1101,6 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
     }
     // (loads still in flight must land before their registers mean anything else)
     asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : : "memory");
-    }
 #undef TIMG_M_STEP
     if (M == kOpaque) ok = ok && (amin >> 24) == 0xffu;
     if (__any(!ok) && (tid & 63) == 0) fail = 1;
@@ -1241,18 +1127,6 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
                    int *tile_state, int gen, int hrow, int hgroups) {
     ScaleStreamMBody<M, kOvf>(plan, tab, mt, blend, batch, tile_state, gen, hrow, hgroups);
 }
-#ifdef TIMG_M_VRING
-// The instantiation whose ring lives in registers reserved from the compiler: amdgpu_num_vgpr (which wants a literal,
-// hence the specialisation) caps the compiler's own registers below the ring's.
-template <>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-    __attribute__((amdgpu_num_vgpr(128 - 4 * TIMG_M_VRING)))
-ScaleStreamMKernel<kOpaque, false>(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, FrameBatch batch,
-                                   int *tile_state, int gen, int hrow, int hgroups) {
-    static_assert(MKernelShape<kOpaque, false>::kWaves == 4, "the register budget above is four waves per SIMD");
-    ScaleStreamMBody<kOpaque, false>(plan, tab, mt, blend, batch, tile_state, gen, hrow, hgroups);
-}
-#endif
 
 // ===================================================================================
 // Horizontal-first plans (what stb picks e.g. for 8K -> 800x450 and 640x480 -> 67x50):
@@ -1828,18 +1702,13 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
             }
         }
     }
-    std::vector<RowRec> recs22 = recs;
-    for (RowRec &r : recs22)
-        for (int k = 0; k < kMSlots; ++k) r.w.w[k] = r.w.w[k] * kWeightScale;
-    const size_t o_recs22 = align(o_recs + recs.size() * sizeof(RowRec));
-    const size_t o_atab   = align(o_recs22 + recs22.size() * sizeof(RowRec));
+    const size_t o_atab   = align(o_recs + recs.size() * sizeof(RowRec));
     const size_t total    = align(o_atab + atab.size() * sizeof(AlphaCell) + 16);
     std::vector<char> host(total, 0);
     memcpy(&host[o_strips], strips.data(), strips.size() * sizeof(StripInfo));
     memcpy(&host[o_bands], bands.data(), bands.size() * sizeof(BandInfo));
     memcpy(&host[o_sched], sched.data(), sched.size() * sizeof(RowSched));
     memcpy(&host[o_recs], recs.data(), recs.size() * sizeof(RowRec));
-    memcpy(&host[o_recs22], recs22.data(), recs22.size() * sizeof(RowRec));
     if (!atab.empty()) memcpy(&host[o_atab], atab.data(), atab.size() * sizeof(AlphaCell));
     void *dev = nullptr;
     if (DevMalloc(&dev, total) != hipSuccess) return false;
@@ -1855,7 +1724,6 @@ static bool BuildVariant(const ResamplePlan &p, const std::vector<StripInfo> &st
     out->t.n_bands  = (int)bands.size();
     out->m.rec      = (const RowRec *)((char *)dev + o_recs);
     out->m.alpha_tab = (const AlphaCell *)((char *)dev + o_atab);
-    out->m.rec22    = (const RowRec *)((char *)dev + o_recs22);
     out->m_ok       = m_ok && wrows.size() == sched.size();
     out->m_ovf      = uses_ovf;
     out->band_rows  = band_rows;

@@ -251,10 +251,45 @@ def main():
                          "(rounds 1-4) instead of timg_hip_sixel_encode_async (two jobs alternate, counts read one step late)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the CPU sample")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch / rendezvous check only: every rank joins the process group, one all-reduce, rank 0 prints "
+                         '{"launched_ranks": N}; no device is touched (tests/test_gather_gloo.py runs it on the CPU)')
     args = ap.parse_args()
+
+    # --gpus N MEANS N ranks.  The driver starts N > 1 under torch.distributed.run; started as ONE plain process
+    # (`python bench.py --gpus 8`) this script used to read WORLD_SIZE alone and report n_gpus 1 without a word
+    # (VERDICT r5): it now starts the launcher itself -- same command line, one rank per GPU on this node.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd[1:9])))
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s rank(s) (WORLD_SIZE): refusing to report a number for "
+                         "another job than the one asked for" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
 
     import torch
     import torch.distributed as dist
+    if args.dry_launch:
+        import datetime
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("TIMG_DIST_BACKEND", "gloo"), timeout=datetime.timedelta(seconds=120))
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"launched_ranks": seen, "n_gpus": args.gpus}), flush=True)
+        return
     import timg_amd
     from timg_amd.gather import gather_frames_to_root, shard_frames
     from timg_amd.pipeline import GridPipeline, run_batched_streams
@@ -346,6 +381,13 @@ def main():
                                                    "some rank%s)" % (": " + why if why else "")}
     elif world > 1:
         exchange = {"ranks": world, "via": "torch.distributed over %s (testing configuration)" % backend}
+    # (a curve measured on the fallback is a curve of torch.distributed's collectives, not of the product's exchange: said
+    # in the line, and first thing on stderr where a log reader sees it)
+    exchange["exchange_is_product"] = cabi is not None or world == 1
+    if rank == 0:
+        sys.stderr.write("bench.py: %d rank(s); exchange via %s%s\n" % (world, exchange["via"],
+                         "" if exchange["exchange_is_product"] else "  [NOT the product's exchange]"))
+        sys.stderr.flush()
     recv_buf = [None]
 
     def gather(payload, lens):

@@ -254,7 +254,11 @@ size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
  * then an event, all on `stream` -- and returns; timg_hip_sixel_encode_wait blocks until THAT call's counts have
  * arrived and reports them (or the call's error) exactly as the synchronous form would.  The caller may enqueue
  * further work -- the next batch's scale and encode included, with another job -- before it waits; one job holds one
- * call at a time.  `out` must stay untouched until the wait returns; bytes are those of timg_hip_sixel_encode. */
+ * call at a time.  `out` must stay untouched until the wait returns; bytes are those of timg_hip_sixel_encode.
+ * Streams: the encoder's scratch memory belongs to the context, one call at a time.  Calls on ONE stream follow each
+ * other in stream order; a sixel call (blocking or not) on ANOTHER stream of the same context is ordered behind the
+ * call in flight by the library itself (an event wait on the device, nobody blocks) -- correct, not concurrent: callers
+ * that want two encodes to overlap use two contexts. */
 typedef struct timg_hip_sixel_job timg_hip_sixel_job;
 int timg_hip_sixel_job_create(timg_hip_ctx *ctx, int max_frames, timg_hip_sixel_job **out);
 void timg_hip_sixel_job_destroy(timg_hip_sixel_job *job);

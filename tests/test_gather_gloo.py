@@ -153,3 +153,32 @@ def test_batched_streams_single_rank_runs_every_step():
     pipes = [_FakePipe(0, i) for i in range(3)]
     run_batched_streams(pipes, None, 8, 3)
     assert sorted(p.calls for p in pipes) == [2, 3, 3]
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` as ONE plain process (no torchrun around it) used to parse --gpus and never read it:
+    WORLD_SIZE was unset, the line said n_gpus 1.  It now starts torch.distributed.run itself; --dry-launch
+    stops after the rendezvous (no device here): both ranks joined one gloo group."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TIMG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-1500:]
+    assert "without a launcher: starting" in r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"launched_ranks": 2, "n_gpus": 2}
+
+
+def test_bench_refuses_a_world_that_is_not_what_gpus_asked_for():
+    """--gpus 4 under a launcher that started ONE rank: no number for another job than the one asked for."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-launch"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "refusing to report" in r.stderr, r.stdout + r.stderr

@@ -354,6 +354,49 @@ def test_sixel_async_encode_is_the_blocking_call_read_late(hip, oracle):
         hip.free(d)
 
 
+def test_sixel_calls_on_two_streams_of_one_context_are_ordered_by_the_library(hip, oracle):
+    """a call of timg_hip_sixel_encode_async leaves kernels running on the context's scratch after it has
+    returned; nothing but stream order kept the NEXT sixel call off that scratch -- so a call on another stream, a
+    blocking call on the context's own stream, or one that has to GROW the scratch (which frees the old block) raced
+    with it.  The library now orders them itself (context.h: sixel_done).  Here: a large batch in flight on stream A,
+    then at once a small batch on stream B, a blocking call on the default stream, and a batch big enough to grow the
+    scratch on stream B -- every frame must be the restatement's, every time."""
+    import torch
+    w, h = 320, 180
+    cap = hip.sixel_max_bytes(w, h)
+    blend = timg_amd.Blend.make(BG, PAT, 5, 3)
+    big = np.stack([synth.make("photo", w, h, 300 + i) for i in range(24)])
+    small = np.stack([synth.make("noise", w, h, 400 + i) for i in range(3)])
+    bigger = np.stack([synth.make("alpha", w, h, 500 + i) for i in range(40)])
+    want = {name: [oracle.sixel_encode(f, BG, PAT, 5, 3, lookup_mode=1) for f in frames]
+            for name, frames in (("big", big), ("small", small), ("bigger", bigger))}
+    d_big, d_small, d_bigger = hip.upload(big), hip.upload(small), hip.upload(bigger)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        o_big = torch.empty((24, cap), dtype=torch.uint8, device="cuda")
+        o_small = torch.empty((3, cap), dtype=torch.uint8, device="cuda")
+        o_bigger = torch.empty((40, cap), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ja, jb = hip.sixel_job(24), hip.sixel_job(40)
+        hip.sixel_encode_async(ja, d_big, w, h, o_big.data_ptr(), cap, n_frames=24, pad_blend=blend, stream=sa.cuda_stream)
+        hip.sixel_encode_async(jb, d_small, w, h, o_small.data_ptr(), cap, n_frames=3, pad_blend=blend, stream=sb.cuda_stream)
+        blocking = hip.sixel_encode(d_small, w, h, pad_blend=blend, n_frames=3)  # (the context's own stream)
+        l_small = hip.sixel_encode_wait(jb, 3)
+        hip.sixel_encode_async(jb, d_bigger, w, h, o_bigger.data_ptr(), cap, n_frames=40, pad_blend=blend, stream=sb.cuda_stream)
+        l_big = hip.sixel_encode_wait(ja, 24)
+        l_bigger = hip.sixel_encode_wait(jb, 40)
+        torch.cuda.synchronize()
+        for name, out, lens in (("big", o_big, l_big), ("small", o_small, l_small), ("bigger", o_bigger, l_bigger)):
+            host = out.cpu().numpy()
+            for i, ref in enumerate(want[name]):
+                assert host[i, :lens[i]].tobytes() == ref, (rep, name, i)
+        assert list(blocking) == want["small"], rep
+        hip.sixel_job_destroy(ja)
+        hip.sixel_job_destroy(jb)
+    for d in (d_big, d_small, d_bigger):
+        hip.free(d)
+
+
 @pytest.mark.parametrize("kind,w,h", [
     ("noise", 800, 450),   # > 8192 distinct colours: median cut runs on the global-memory table
     ("photo", 64, 1100),   # 1104 padded rows: the diffusion pipeline goes round three times (16 waves x 32 rows)

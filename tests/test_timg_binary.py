@@ -104,6 +104,18 @@ CASES = {
 }
 
 
+def twin_counts(err):
+    """The line the twins print when a traced process ends (timg_amd/twins/hip-context.cc: PrintTwinStats): frames
+    produced by a device call and frames produced by the reference's classes, per twin."""
+    import re
+    m = re.search(r"timg_hip twins: frames on the device: scaler (\d+) block (\d+) sixel (\d+) graphics (\d+); on the CPU: "
+                  r"scaler (\d+) block (\d+) sixel (\d+) graphics (\d+); degraded (\d)", err)
+    assert m, err[-1500:]
+    v = [int(x) for x in m.groups()]
+    return {"device": dict(zip(("scaler", "block", "sixel", "graphics"), v[:4])),
+            "cpu": dict(zip(("scaler", "block", "sixel", "graphics"), v[4:8])), "degraded": v[8]}
+
+
 @needs_binaries
 def test_binaries_run_and_say_what_they_are():
     for b in (REF_BIN, HIP_BIN):
@@ -171,6 +183,13 @@ def test_patched_timg_on_the_device_writes_the_references_bytes(case, files, tmp
     assert "timg_hip twins: device context created" in err, err[-1500:]
     assert err.count("HipImageScaler:") >= len(paths), err[-1500:]
     assert "HipUnicodeBlockCanvas: created" in err, err[-1500:]
+    # ... and KEPT doing it: a device call that fails after creation makes the twins go on with the reference's classes
+    # (cpu-sibling.h) -- the comparison below would then be the reference against itself.  Every image was scaled and
+    # every frame encoded by a device call, none by a CPU sibling.
+    assert "continuing on the CPU" not in err, err[-1500:]
+    counts = twin_counts(err)
+    assert counts["degraded"] == 0 and not any(counts["cpu"].values()), counts
+    assert counts["device"]["scaler"] == len(paths) and counts["device"]["block"] == len(paths), counts
     assert len(want) > 2000
     assert got == want, "first difference at byte %d of %d / %d" % (
         next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want))), len(got), len(want))
@@ -187,6 +206,10 @@ def test_patched_timg_sixel_is_the_reference_sixel_canvas_over_the_same_encoder(
         want, _ = run(REF_BIN, args, str(tmp_path / "ref.txt"), {"TIMG_STUB_SIXEL_LOOKUP": "1"})
         got, err = run(HIP_BIN, args, str(tmp_path / "hip.txt"), {"TIMG_HIP_TWIN_TRACE": "1"})
         assert "HipSixelCanvas: created" in err and "timg_hip twins: device context created" in err, err[-1500:]
+        assert "continuing on the CPU" not in err, err[-1500:]
+        counts = twin_counts(err)
+        assert counts["degraded"] == 0 and not any(counts["cpu"].values()), counts
+        assert counts["device"]["scaler"] == 1 and counts["device"]["sixel"] == 1, counts
         assert b"\x1bPq" in want and len(want) > 20000
         assert got == want, (name, len(got), len(want))
 
@@ -200,6 +223,8 @@ def test_patched_timg_survives_a_device_failure(fail_at, files, tmp_path):
     args, names = CASES["grid_2x2_titles"]
     paths = [files[n] for n in names]
     want, _ = run(REF_BIN, args + paths, str(tmp_path / "ref.txt"))
-    got, err = run(HIP_BIN, args + paths, str(tmp_path / "hip.txt"), {"TIMG_HIP_FAIL_CALL": str(fail_at)})
+    got, err = run(HIP_BIN, args + paths, str(tmp_path / "hip.txt"), {"TIMG_HIP_FAIL_CALL": str(fail_at), "TIMG_HIP_TWIN_TRACE": "1"})
     assert err.count("continuing on the CPU") == 1, err[-1500:]
+    counts = twin_counts(err)  # (what the device tests above must NOT see)
+    assert counts["degraded"] == 1 and sum(counts["cpu"].values()) >= 1, counts
     assert got == want

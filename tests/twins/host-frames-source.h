@@ -68,6 +68,9 @@ public:
             // back-end, as in the patched ImageScaler::Create: integration/timg-hip.patch)
             std::unique_ptr<ImageScaler> hip_made;
             if (hip_scaler_) hip_made = HipImageScaler::Create(sw, sh, ImageScaler::ColorFmt::kRGBA, tw, th);
+            // (a run that asked for the device scaler and did not get one must not pass as "identical": only a back-end
+            // that was switched off after a failure -- the degrade test -- may fall through to the reference's scaler)
+            if (hip_scaler_ && !hip_made && !HipDegraded()) return false;
             if (hip_made) {
                 auto &scaler = hip_made;
                 static_cast<HipImageScaler *>(scaler.get())->ScaleAndCompose(

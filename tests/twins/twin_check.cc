@@ -74,6 +74,8 @@ static std::string Slurp(int fd) {
 }
 
 static int failures = 0;
+// frames the modes below KNOW the device refuses (TIMG_HIP_ERR_UNSUPP): the only ones a CPU sibling may encode
+static unsigned long g_expected_cpu_frames = 0;
 #define CHECK(cond, ...)                   \
     do {                                   \
         if (!(cond)) {                     \
@@ -281,6 +283,48 @@ static void CheckSixelCanvas(const char *dump_path) {
               "sixel canvas variant %d: %zu (reference class) vs %zu bytes", variant, streams[0].size(),
               streams[1].size());
         if (variant == 0) hip_stream = streams[1];
+    }
+    // A frame the device REFUSES (wider than timg_hip_sixel_encode takes: TIMG_HIP_ERR_UNSUPP; the reference sizes its
+    // buffer for any width, src/sixel-canvas.cc:123): that frame alone is the CPU sibling's, the back-end stays selected,
+    // the frames before and after it are the device's.
+    {
+        std::string streams[2];
+        const HipTwinCounts before = HipTwinStats();
+        for (int twin = 0; twin < 2; ++twin) {
+            rng_state = 4242;
+            volatile sig_atomic_t intr = 0;
+            const int fd = memfd_create("sixwide", 0);
+            DisplayOptions opts;  // (outlives the encoder pool, as in src/timg.cc: canvases keep a reference)
+            opts.cell_x_px      = 9;
+            opts.cell_y_px      = 18;
+            opts.bgcolor_getter = []() { rgba_t c; c.r = 30; c.g = 30; c.b = 46; c.a = 255; return c; };
+            {
+                ThreadPool pool(2);
+                BufferedWriteSequencer seq(fd, false, 4, true, intr);
+                SixelOptions so;
+                std::unique_ptr<TerminalCanvas> canvas;
+                if (twin) canvas.reset(new HipSixelCanvas(&seq, &pool, so, opts));
+                else canvas.reset(new SixelCanvas(&seq, &pool, so, opts));
+                const int sizes[][2] = {{120, 30}, {4200, 8}, {96, 24}};
+                for (const auto &wh : sizes) {
+                    Framebuffer fb(wh[0], wh[1]);
+                    Fill(&fb, 2);
+                    canvas->Send(0, 0, fb, SeqType::FrameImmediate, {});
+                }
+                canvas.reset();
+            }
+            streams[twin] = Slurp(fd);
+            close(fd);
+        }
+        const HipTwinCounts after = HipTwinStats();
+        CHECK(streams[0] == streams[1] && streams[0].size() > 1000, "a refused (4200 px wide) sixel frame between two others: %zu vs %zu bytes",
+              streams[0].size(), streams[1].size());
+        CHECK(!HipDegraded(), "a refused frame switched the back-end off");
+        CHECK(after.cpu[kHipTwinSixel] - before.cpu[kHipTwinSixel] == 1 && after.device[kHipTwinSixel] - before.device[kHipTwinSixel] == 2,
+              "refused frame: %lu on the CPU (want 1), %lu on the device (want 2)", after.cpu[kHipTwinSixel] - before.cpu[kHipTwinSixel],
+              after.device[kHipTwinSixel] - before.device[kHipTwinSixel]);
+        g_expected_cpu_frames += 1;
+        printf("sixel canvas twin: a frame the device refuses goes to the CPU sibling alone, the back-end stays on\n");
     }
     if (dump_path) {
         FILE *f = fopen(dump_path, "wb");
@@ -976,6 +1020,23 @@ int main(int argc, char **argv) {
         fflush(stdout);
     }
     if (what == "all" || what == "pools") CheckPools();
+    // What ran where.  Every mode but `degrade` compares DEVICE output with the reference's classes: a twin that quietly
+    // went on with its CPU sibling (hip-context.h: HipDegrade) would compare the reference with itself -- that is a
+    // failure here, whatever the bytes say.  (A frame the device REFUSED -- TIMG_HIP_ERR_UNSUPP -- is counted on the CPU
+    // side without the switch; the modes that send such frames say how many they expect: g_expected_cpu_frames.)
+    const HipTwinCounts counts = HipTwinStats();
+    unsigned long on_device = 0, on_cpu = 0;
+    for (int k = 0; k < kHipTwinKinds; ++k) {
+        on_device += counts.device[k];
+        on_cpu += counts.cpu[k];
+    }
+    printf("twin_check: frames on the device: scaler %lu block %lu sixel %lu graphics %lu; on the CPU: %lu; degraded %d\n",
+           counts.device[0], counts.device[1], counts.device[2], counts.device[3], on_cpu, (int)HipDegraded());
+    if (what != "degrade") {
+        CHECK(!HipDegraded(), "the HIP back-end was switched off during the run: the comparisons above were reference against reference");
+        CHECK(on_cpu == g_expected_cpu_frames, "frames encoded by the CPU sibling although no device call failed");
+        if (what != "pools" && what != "gather") CHECK(on_device > 0, "no frame was produced on the device");
+    }
     if (failures) {
         fprintf(stderr, "twin_check: %d failure(s)\n", failures);
         return 1;

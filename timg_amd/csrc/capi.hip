@@ -158,6 +158,7 @@ void timg_hip_destroy(timg_hip_ctx *ctx) {
     for (auto ev : ctx->hook_event)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    if (ctx->sixel_done) (void)hipEventDestroy(ctx->sixel_done);
     delete ctx;
 }
 

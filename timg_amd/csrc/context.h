@@ -87,6 +87,14 @@ struct timg_hip_ctx {
         return hipEventCreateWithFlags(&fork_event, hipEventDisableTiming);
     }
 
+    // The sixel encoder's scratch (dev[5]) belongs to ONE call at a time.  A blocking call has left it when it returns;
+    // an asynchronous one (timg_hip_sixel_encode_async) has not: `sixel_done` is recorded behind its last kernel on
+    // `sixel_stream`.  The next sixel call on ANOTHER stream waits for it on the device (hipStreamWaitEvent); one that
+    // must grow the scratch waits for it on the host before the old block is freed.
+    hipEvent_t sixel_done   = nullptr;
+    hipStream_t sixel_stream = nullptr;
+    bool sixel_in_flight    = false;
+
     timg_hip_ctx() {
         for (auto &p : pin) p.pinned = true;
     }

@@ -3081,8 +3081,17 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_prow  = carve(nf * (size_t)w * 5 * sizeof(uint32_t));
     const size_t o_xwg   = carve(nf * (kDitherMaxParts - 1) * (size_t)XwgStride(w) * sizeof(uint32_t));
     const size_t o_len   = carve((nf + 1) * sizeof(unsigned long long));  // + 1: device error word
-    // (growing the scratch frees the old block: kernels of an earlier ASYNCHRONOUS call on this stream may still use it)
-    if (off > ctx->dev[5].bytes) TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    // An earlier ASYNCHRONOUS call may still be running on this scratch (context.h: sixel_done).  On the same stream the
+    // kernels below queue behind it; on another stream they are made to (on the device: nobody blocks); and before the
+    // scratch GROWS -- Reserve frees the old block -- the host waits for that call, whatever stream it is on.
+    if (ctx->sixel_in_flight) {
+        if (off > ctx->dev[5].bytes) {
+            TIMG_HIP_TRY(ctx, hipEventSynchronize(ctx->sixel_done));
+            ctx->sixel_in_flight = false;
+        } else if (ctx->sixel_stream != st) {
+            TIMG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->sixel_done, 0));
+        }
+    }
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
     char *base = (char *)ctx->dev[5].ptr;
     SixelBatch b;
@@ -3274,6 +3283,10 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         // scratch is reused in stream order; the counts above were copied out before the next call's kernels run)
         TIMG_HIP_TRY(ctx, hipMemcpyAsync(job->len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
         TIMG_HIP_TRY(ctx, hipEventRecord(job->done, st));
+        if (!ctx->sixel_done) TIMG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->sixel_done, hipEventDisableTiming));
+        TIMG_HIP_TRY(ctx, hipEventRecord(ctx->sixel_done, st));  // (the context's own event: the job may be destroyed first)
+        ctx->sixel_stream    = st;
+        ctx->sixel_in_flight = true;
         job->n       = n_frames;
         job->out_cap = out_cap;
         job->pending = true;
@@ -3285,6 +3298,7 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * (nf + 1),
                                      hipMemcpyDeviceToHost, st));
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->sixel_in_flight = false;  // (this call waited behind whatever was in flight, and has finished itself)
     if ((int)len_h[nf] != 0)
         return ctx->Fail(TIMG_HIP_ERR_DEVICE, "sixel diffusion: a workgroup gave up waiting for its neighbour");
     if (hook_ms) {

@@ -33,6 +33,38 @@ void HipDegrade(timg_hip_ctx *ctx, const char *what) {
         fprintf(stderr, "timg: HIP back-end failed in %s: %s -- continuing on the CPU\n", what, timg_hip_last_error(ctx));
 }
 
+void HipDegradeUnless(int rc, timg_hip_ctx *ctx, const char *what) {
+    if (rc == TIMG_HIP_ERR_UNSUPP) {
+        if (HipTwinTrace()) fprintf(stderr, "timg_hip twins: %s refused this frame (%s): the reference's class encodes it\n", what, timg_hip_last_error(ctx));
+        return;
+    }
+    HipDegrade(ctx, what);
+}
+
+namespace {
+std::atomic<unsigned long> g_frames_device[kHipTwinKinds], g_frames_cpu[kHipTwinKinds];
+void PrintTwinStats() {
+    const HipTwinCounts c = HipTwinStats();
+    fprintf(stderr,
+            "timg_hip twins: frames on the device: scaler %lu block %lu sixel %lu graphics %lu; on the CPU: scaler %lu block %lu sixel %lu "
+            "graphics %lu; degraded %d\n",
+            c.device[0], c.device[1], c.device[2], c.device[3], c.cpu[0], c.cpu[1], c.cpu[2], c.cpu[3], (int)HipDegraded());
+}
+}  // namespace
+
+void HipCountFrames(HipTwinKind kind, bool on_device, size_t frames) {
+    (on_device ? g_frames_device : g_frames_cpu)[kind].fetch_add((unsigned long)frames, std::memory_order_relaxed);
+}
+
+HipTwinCounts HipTwinStats() {
+    HipTwinCounts c;
+    for (int k = 0; k < kHipTwinKinds; ++k) {
+        c.device[k] = g_frames_device[k].load();
+        c.cpu[k]    = g_frames_cpu[k].load();
+    }
+    return c;
+}
+
 bool HipFailInjected() {
     static const long fail_at = []() {
         const char *e = getenv("TIMG_HIP_FAIL_CALL");
@@ -49,9 +81,11 @@ static timg_hip_ctx *SharedHipContextEvenIfDegraded() {
         if (!HipTwinsEnabled()) return;
         const char *d = getenv("TIMG_HIP_DEVICE");
         if (timg_hip_init(d ? atoi(d) : 0, &ctx) != TIMG_HIP_OK) ctx = nullptr;
-        if (HipTwinTrace())
+        if (HipTwinTrace()) {
             fprintf(stderr, "timg_hip twins: device context %s%s\n", ctx ? "created" : "unavailable: ",
                     ctx ? "" : timg_hip_last_error(nullptr));
+            atexit(PrintTwinStats);
+        }
     });
     return ctx;
 }

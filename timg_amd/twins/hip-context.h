@@ -76,11 +76,28 @@ timg_hip_scaler *HipScalerAcquire(timg_hip_ctx *ctx, int in_w, int in_h, int in_
 void HipScalerRelease(timg_hip_scaler *s);
 size_t HipIdleScalers();  // (for the tests)
 
+// What the twins really did, counted per process: frames produced by a device call and frames produced by the reference's
+// own classes (cpu-sibling.h, HipImageScaler::ScaleOnCpu).  A parity test that compares a twin's stream with the
+// reference's proves nothing when the twin quietly took the CPU path: tests/twins/twin_check.cc and
+// tests/test_timg_binary.py read these -- with TIMG_HIP_TWIN_TRACE set the process prints them on stderr when it ends:
+//   "timg_hip twins: frames on the device: scaler N block N sixel N graphics N; on the CPU: scaler N block N sixel N graphics N; degraded D"
+enum HipTwinKind { kHipTwinScaler = 0, kHipTwinBlock = 1, kHipTwinSixel = 2, kHipTwinGraphics = 3, kHipTwinKinds = 4 };
+struct HipTwinCounts {
+    unsigned long device[kHipTwinKinds];
+    unsigned long cpu[kHipTwinKinds];
+};
+void HipCountFrames(HipTwinKind kind, bool on_device, size_t frames = 1);
+HipTwinCounts HipTwinStats();
+
 // A device call failed after the GPU back-end had been selected and the twin has a CPU implementation to go on with
 // (cpu-sibling.h; HipImageScaler: the reference's own scaler): says so ONCE on stderr and switches the back-end off for
 // the rest of the process -- SharedHipContext() returns nullptr from now on, so every later factory call builds the
 // reference's classes.  Objects that exist keep their context (they check HipDegraded() themselves).
 void HipDegrade(timg_hip_ctx *ctx, const char *what);
+// ... unless the call only REFUSED this frame (TIMG_HIP_ERR_UNSUPP: a geometry the kernels do not take): that frame
+// alone goes to the reference's class, the device stays selected for every other one, nothing is printed (with
+// TIMG_HIP_TWIN_TRACE: one line per refused frame).
+void HipDegradeUnless(int rc, timg_hip_ctx *ctx, const char *what);
 bool HipDegraded();
 
 // A device call failed after the GPU back-end had been selected and there is nothing to fall back to: print

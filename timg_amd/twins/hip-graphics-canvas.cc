@@ -44,6 +44,7 @@ void SendAsync(timg_hip_ctx *ctx, ThreadPool *pool, BufferedWriteSequencer *ws, 
         if (HipCall(ctx, [&]() { return encode(pixels->data(), w, h, offset, cap - (size_t)(offset - buffer), &len); }) !=
             TIMG_HIP_OK)
             HipFatal(ctx, what);
+        HipCountFrames(kHipTwinGraphics, true);
         return OutBuffer(buffer, (size_t)(offset - buffer) + len);
     };
     ws->WriteBuffer(pool->ExecAsync(encode_fun), seq_type, end_of_frame);

@@ -35,6 +35,7 @@ HipImageScaler::~HipImageScaler() { HipScalerRelease(scaler_); }
 // Same bytes when the timg build scales with stb (src/image-scaler.cc:75-98), the build's own filter otherwise.
 void HipImageScaler::ScaleOnCpu(Framebuffer &in, Framebuffer *out, const char *what) {
     HipDegrade(ctx_, what);
+    HipCountFrames(kHipTwinScaler, false);
     std::unique_ptr<ImageScaler> cpu = ImageScaler::Create(in_w_, in_h_, fmt_, out_w_, out_h_);
     if (!cpu) HipFatal(ctx_, what);  // (no CPU back-end either: the reference's loaders would have failed the load)
     cpu->Scale(in, out);
@@ -49,6 +50,8 @@ void HipImageScaler::Scale(Framebuffer &in, Framebuffer *out) {
                                         1, nullptr, nullptr, nullptr);
         }) != TIMG_HIP_OK)
         ScaleOnCpu(in, out, "HipImageScaler::Scale");
+    else
+        HipCountFrames(kHipTwinScaler, true);
 }
 
 void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
@@ -98,6 +101,7 @@ void HipImageScaler::ScaleAndCompose(Framebuffer &in, Framebuffer *out,
         return on_cpu("HipImageScaler::ScaleAndCompose: download");
     }
     HipPoolFree(ctx_, scaled);
+    HipCountFrames(kHipTwinScaler, true);
 }
 
 }  // namespace timg

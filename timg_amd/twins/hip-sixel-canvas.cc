@@ -37,17 +37,23 @@ HipSixelCanvas::HipSixelCanvas(BufferedWriteSequencer *ws, ThreadPool *thread_po
     if (!ctx_) HipFatal(ctx_, "HipSixelCanvas");
     if (HipTwinTrace()) fprintf(stderr, "HipSixelCanvas: created\n");
 #ifdef WITH_TIMG_SIXEL
-    cpu_.reset(new CpuSibling([this](BufferedWriteSequencer *seq, ThreadPool *pool) -> TerminalCanvas * {
-        return new SixelCanvas(seq, pool, sixel_options_, options_);  // (constructed on first use only)
+    // (captures what the reference class would be given -- the caller's DisplayOptions by reference, as SixelCanvas
+    // itself keeps them -- and nothing of this object)
+    const SixelOptions so       = sixel_options;
+    const DisplayOptions *dopts = &display_opts;
+    cpu_.reset(new CpuSibling([so, dopts](BufferedWriteSequencer *seq, ThreadPool *pool) -> TerminalCanvas * {
+        return new SixelCanvas(seq, pool, so, *dopts);  // (constructed on first use only)
     }));
 #endif
     DeviceFrameConsumerCreated();
 }
 
-size_t HipSixelCanvas::EncodeOnCpu(timg_hip_ctx *ctx, char *&buffer, size_t prefix, size_t &cap, const uint8_t *pixels,
+size_t HipSixelCanvas::EncodeOnCpu(const std::shared_ptr<CpuSibling> &cpu_, int rc, timg_hip_ctx *ctx, char *&buffer, size_t prefix, size_t &cap, const uint8_t *pixels,
                                    bool on_device, int w, int h, const char *what) {
     if (!cpu_) HipFatal(ctx, what);  // (a timg build without libsixel has no CPU sixel canvas to go on with)
-    HipDegrade(ctx, what);
+    // (rc == TIMG_HIP_ERR_UNSUPP: the device refused THIS frame's geometry; it stays selected for the others)
+    HipDegradeUnless(rc, ctx, what);
+    HipCountFrames(kHipTwinSixel, false);
     std::vector<uint8_t> host;
     if (on_device) {
         host.resize((size_t)w * h * 4);
@@ -132,11 +138,12 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
     const auto t0 = std::chrono::steady_clock::now();
     // (HipCall: out of device memory -- the encoder's scratch grows with the batch -- is retried once after the twins'
     // caches have been given back)
-    const bool on_device = !HipDegraded() &&
-        HipCall(ctx, [&]() {
-            return timg_hip_sixel_encode(ctx, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
-                                         bytes.get(), slot, 0, lens.data(), nullptr);
-        }) == TIMG_HIP_OK;
+    const int rc = HipDegraded() ? TIMG_HIP_ERR_DEVICE : HipCall(ctx, [&]() {
+        return timg_hip_sixel_encode(ctx, batch.data(), batch.w, batch.h, 0, 0, batch.on_device, (int)n, flags, &batch.pad,
+                                     bytes.get(), slot, 0, lens.data(), nullptr);
+    });
+    const bool on_device = rc == TIMG_HIP_OK;
+    if (on_device) HipCountFrames(kHipTwinSixel, true, n);
     const auto t1 = std::chrono::steady_clock::now();
     const size_t frame_bytes = (size_t)batch.w * batch.h * 4;
     for (size_t i = 0; i < n; ++i) {
@@ -151,7 +158,7 @@ void HipSixelCanvas::EncodeBatch(HeldBatch &batch, timg_hip_ctx *ctx) {
             f.buffer = final;
             f.cap    = f.prefix + lens[i];
         } else {
-            lens[i] = EncodeOnCpu(ctx, f.buffer, f.prefix, f.cap, batch.data() + i * frame_bytes, batch.on_device, batch.w,
+            lens[i] = EncodeOnCpu(cpu_, rc, ctx, f.buffer, f.prefix, f.cap, batch.data() + i * frame_bytes, batch.on_device, batch.w,
                                   batch.h, "timg_hip_sixel_encode");
         }
         f.promise.set_value(OutBuffer(f.buffer, f.prefix + lens[i]));
@@ -228,16 +235,19 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     }
     const int flags = EncodeFlags();
     const size_t prefix_len = (size_t)(offset - buffer);
+    const std::shared_ptr<CpuSibling> cpu = cpu_;
     const std::function<OutBuffer()> encode_fun = [=]() {
         size_t len = 0;
         char *buf  = buffer;
         size_t room = cap;
-        if (HipDegraded() ||
-            HipCall(ctx, [&]() {
-                return timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr,
-                                             1, flags, &pad, buf + prefix_len, room - prefix_len, 0, &len, nullptr);
-            }) != TIMG_HIP_OK)
-            len = EncodeOnCpu(ctx, buf, prefix_len, room, device_copy ? device_copy : pixels->data(), device_copy != nullptr, w, h,
+        const int rc = HipDegraded() ? TIMG_HIP_ERR_DEVICE : HipCall(ctx, [&]() {
+            return timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr,
+                                         1, flags, &pad, buf + prefix_len, room - prefix_len, 0, &len, nullptr);
+        });
+        if (rc == TIMG_HIP_OK)
+            HipCountFrames(kHipTwinSixel, true);
+        else
+            len = EncodeOnCpu(cpu, rc, ctx, buf, prefix_len, room, device_copy ? device_copy : pixels->data(), device_copy != nullptr, w, h,
                               "timg_hip_sixel_encode");
         if (device_copy) HipPoolFree(ctx, device_copy);
         return OutBuffer(buf, prefix_len + len);

@@ -57,7 +57,9 @@ private:
     // the device failed: one frame's bytes from the reference's own SixelCanvas (cpu-sibling.h; only in builds that have
     // that class, WITH_TIMG_SIXEL -- otherwise the failure stays fatal), appended behind `prefix` bytes of `buffer`
     // (which grows if it has to); returns their length
-    size_t EncodeOnCpu(timg_hip_ctx *ctx, char *&buffer, size_t prefix, size_t &cap, const uint8_t *pixels, bool on_device,
+    // (static, the sibling handed in: an encode job on the pool may outlive the canvas -- the reference's own job captures
+    // everything by value, src/sixel-canvas.cc:128-150 -- and must not reach back into it)
+    static size_t EncodeOnCpu(const std::shared_ptr<CpuSibling> &cpu, int rc, timg_hip_ctx *ctx, char *&buffer, size_t prefix, size_t &cap, const uint8_t *pixels, bool on_device,
                        int w, int h, const char *what);
     // held batches encoded at the same time, each on a context of its own (held-rows.h): a sixel batch keeps one CU
     // per frame busy for most of its 1.1 ms
@@ -67,7 +69,7 @@ private:
     const bool full_cell_jump_;
     const bool broken_cursor_;
     const SixelOptions sixel_options_;  // (a copy: the CPU sibling is constructed late)
-    std::unique_ptr<CpuSibling> cpu_;
+    std::shared_ptr<CpuSibling> cpu_;
     int EncodeFlags() const;  // timg_hip_sixel_encode flags of this canvas
     ThreadPool *const executor_;
     timg_hip_ctx *const ctx_;

@@ -36,6 +36,7 @@ HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool us
 size_t HipUnicodeBlockCanvas::EncodeOnCpu(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height,
                                           const char *what) {
     HipDegrade(ctx_, what);
+    HipCountFrames(kHipTwinBlock, false);
     std::vector<uint8_t> host;
     if (on_device) {  // (a frame of a device-resident source: its pixels have to come back first -- if the device still answers)
         host.resize((size_t)width * height * 4);
@@ -83,6 +84,8 @@ void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, bool on
                                               p.cap - p.prefix, &len, nullptr);
         }) != TIMG_HIP_OK)
         len = EncodeOnCpu(p, pixels, on_device, width, height, "timg_hip_block_canvas_send");
+    else
+        HipCountFrames(kHipTwinBlock, true);
     // nothing emitted: the reference keeps the buffer size zero, dropping the
     // cursor jump as well (:390-395)
     write_sequencer_->WriteBuffer(OutBuffer(p.buffer, len ? p.prefix + len : 0), seq_type, end_of_frame);
@@ -107,9 +110,10 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
             }) == TIMG_HIP_OK;
         for (size_t i = 0; i + 1 < n; ++i) {
             HeldFrame &p = batch.frames[i];
-            if (on_device)
+            if (on_device) {
                 memcpy(p.buffer + p.prefix, bytes.get() + i * slot, lens[i]);
-            else
+                HipCountFrames(kHipTwinBlock, true);
+            } else
                 lens[i] = EncodeOnCpu(p, batch.data() + i * frame_bytes, batch.on_device, batch.w, batch.h, "timg_hip_block_encode_grid");
             p.promise.set_value(OutBuffer(p.buffer, lens[i] ? p.prefix + lens[i] : 0));
         }
@@ -126,6 +130,8 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
                                               batch.on_device, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr);
         }) != TIMG_HIP_OK)
         len = EncodeOnCpu(p, batch.data() + (n - 1) * frame_bytes, batch.on_device, batch.w, batch.h, "timg_hip_block_canvas_send");
+    else
+        HipCountFrames(kHipTwinBlock, true);
     p.promise.set_value(OutBuffer(p.buffer, len ? p.prefix + len : 0));
 }
 

@@ -716,6 +716,12 @@ def main():
                                                         % os.path.basename(traffic_file))
                 if t.get("limiter") and not stale:
                     result["roofline"]["limiter"] = t["limiter"]
+                # the roof that binds this kernel beside the HBM one: the issue time of its vector instructions (counted by
+                # the same collection: SQ_INSTS_VALU x 4 clocks / 1024 SIMDs / the clock the counters saw)
+                if t.get("valu_issue") and not stale:
+                    vi = dict(t["valu_issue"])
+                    vi["frac_of_this_runs_launch"] = round(vi["issue_ms_per_launch"] / launches_per_batch / scale_avg_ms, 3)
+                    result["roofline"]["valu_issue"] = vi
                 break
         except Exception:
             pass

@@ -32,6 +32,7 @@ for spec in "${specs[@]}"; do
   pass fetch FETCH_SIZE
   pass write WRITE_SIZE
   pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY
+  pass sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VALU_CVT
   pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
   python3 - "$w" "$out" "$name" "$cfg" "$kind" <<'PY'
 import csv, glob, json, sys, collections
@@ -45,14 +46,24 @@ def counters(sub):
                 k = "ScaleStream" + r["Kernel_Name"].split("ScaleStream")[1].split("(")[0]
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
-sq1, sq2, fetch, write = counters("sq1"), counters("sq2"), counters("fetch"), counters("write")
+sq1, sq2, sq3, fetch, write = counters("sq1"), counters("sq2"), counters("sq3"), counters("fetch"), counters("write")
+def durations(sub):
+    """average duration (ns) per kernel of the pass's own kernel trace"""
+    acc = collections.defaultdict(list)
+    for fn in glob.glob(w + "/" + sub + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if "ScaleStream" in r["Kernel_Name"]:
+                k = "ScaleStream" + r["Kernel_Name"].split("ScaleStream")[1].split("(")[0]
+                acc[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+dur3 = durations("sq3")
 # the dominant kernel: most wave cycles per dispatch
 dom = max(sq1, key=lambda k: sq1[k].get("SQ_WAVE_CYCLES", 0.0)) if sq1 else (max(fetch, key=lambda k: fetch[k].get("FETCH_SIZE", 0.0)) if fetch else None)
 with open("%s/sq_counters_%s.txt" % (out, name), "w") as f:
     f.write("# python bench.py --config %s%s under rocprofv3 --pmc (profiles/collect_pmc.sh): averages per dispatch\n" % (cfg, " --kind " + kind if kind else ""))
     for k in sorted(set(sq1) | set(sq2)):
-        f.write("%s%s\n  sq1 %s\n  sq2 %s\n" % (k, "   <- dominant" if k == dom else "", {c: round(v, 1) for c, v in sq1.get(k, {}).items()},
-                                              {c: round(v, 1) for c, v in sq2.get(k, {}).items()}))
+        f.write("%s%s\n  sq1 %s\n  sq2 %s\n  sq3 %s\n" % (k, "   <- dominant" if k == dom else "", {c: round(v, 1) for c, v in sq1.get(k, {}).items()},
+                                              {c: round(v, 1) for c, v in sq2.get(k, {}).items()}, {c: round(v, 1) for c, v in sq3.get(k, {}).items()}))
 import hashlib, os
 lib = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "timg_amd", "libtimg_hip.so")
 res = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),  # (bench.py: a counter file of another binary is stale)
@@ -75,6 +86,19 @@ if dom and dom in sq1:
                      "valu_per_wave": round(a.get("SQ_INSTS_VALU", 0.0) / waves, 1), "salu_per_wave": round(b.get("SQ_INSTS_SALU", 0.0) / waves, 1),
                      "lds_per_wave": round(b.get("SQ_INSTS_LDS", 0.0) / waves, 1), "vmem_rd_per_wave": round(b.get("SQ_INSTS_VMEM_RD", 0.0) / waves, 1),
                      "lds_bank_conflict_over_active": round(b.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, b.get("SQ_LDS_IDX_ACTIVE", 1.0)), 3)}
+        # The OTHER roof of a byte-shuffling kernel: what its vector instructions cost to ISSUE.  A wave-wide VALU (or
+        # v_mfma_f32_4x4x1) instruction holds its SIMD for 4 clocks; the chip has 4 SIMDs in each of 256 CUs; the clock is
+        # the one the counters saw (GRBM_GUI_ACTIVE summed over the 8 XCDs / the dispatch's duration in that pass).
+        c = sq3.get(dom, {})
+        if c.get("GRBM_GUI_ACTIVE") and dur3.get(dom):
+            clock_ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / dur3[dom]
+            valu = a.get("SQ_INSTS_VALU", 0.0)
+            issue_ms = valu * 4.0 / 1024.0 / (clock_ghz * 1e6)
+            res["valu_issue"] = {"vector_instructions_per_wave": round(valu / waves, 1), "mfma_per_wave": round(c.get("SQ_INSTS_MFMA", 0.0) / waves, 1),
+                                 "cvt_per_wave": round(c.get("SQ_INSTS_VALU_CVT", 0.0) / waves, 1),
+                                 "clock_ghz_under_counters": round(clock_ghz, 3), "issue_ms_per_launch": round(issue_ms, 4),
+                                 "launch_ms_in_that_pass": round(dur3[dom] * 1e-6, 4), "frac_of_launch": round(issue_ms / (dur3[dom] * 1e-6), 3),
+                                 "how": "SQ_INSTS_VALU x 4 clocks / (256 CUs x 4 SIMDs) / clock; clock = GRBM_GUI_ACTIVE / 8 XCDs / duration"}
         s = res["sq"]
         res["limiter"] = ("profiles/%s/sq_counters_%s.txt (%s): waves issue %.0f %% of their cycles, wait (s_waitcnt / barrier) %.0f %%, "
                           "are issue-stalled %.0f %%; %d VALU + %d SALU + %d LDS + %d VMEM-read instructions per wave; HBM traffic %s x algorithmic"
@@ -83,5 +107,5 @@ if dom and dom in sq1:
 json.dump(res, open("%s/hbm_traffic_%s.json" % (out, name), "w"), indent=1)
 print(name, json.dumps({k: res[k] for k in res if k in ("dominant_kernel", "hbm_bytes_per_launch", "traffic_over_algorithmic", "frac_unprofiled", "limiter")})[:600])
 PY
-  rm -rf "$w"/fetch "$w"/write "$w"/sq1 "$w"/sq2
+  rm -rf "$w"/fetch "$w"/write "$w"/sq1 "$w"/sq2 "$w"/sq3
 done

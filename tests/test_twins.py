@@ -168,12 +168,15 @@ def test_a_device_failure_after_creation_degrades_to_the_cpu_classes(oracle, fai
     Send, a held grid row, a sixel batch, a scaler on a loader thread -- the twin says ONCE on stderr that the run
     continues on the CPU, produces that frame with the reference's own class (timg_amd/twins/cpu-sibling.h:
     UnicodeBlockCanvas / SixelCanvas on a private write sequencer; HipImageScaler: the reference's scaler) and every
-    later factory call builds the reference's classes.  The grid as src/timg.cc drives it (no animation: a frame
-    DIFFERENCE becomes a full frame after the switch) and the host-frames path stay byte-identical."""
+    later factory call builds the reference's classes.  The grid as src/timg.cc drives it -- WITH its animation since
+    round 6: the sibling is shown the frame the device saw last, so a frame DIFFERENCE stays a difference across the
+    switch (src/unicode-block-canvas.cc:343-346) -- and the host-frames path stay byte-identical."""
     if not os.path.exists(BIN):
         pytest.skip("tests/twins/build/twin_check not built (needs /root/reference at build time)")
     env = dict(os.environ, TIMG_HIP_FAIL_CALL=str(fail_at))
     r = subprocess.run([BIN, "degrade"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "streams identical to the reference classes" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     assert "degraded=1" in r.stdout, r.stdout[-500:]
+    # (fail_at 2 and 3 land between two frames of an animation on one block canvas: the sibling continues with a DIFFERENCE)
+    assert "block animation across the switch" in r.stdout and "frames 2-4 are differences" in r.stdout, r.stdout[-800:]
     assert r.stderr.count("continuing on the CPU") == 1, r.stderr[-1500:]

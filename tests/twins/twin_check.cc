@@ -342,8 +342,9 @@ static void CheckSixelCanvas(const char *dump_path) {
 // sequencer->Flush() while the canvas is still alive, then renderer, canvas and the encoder pool
 // destroyed in that order.  The reference canvas encodes every Send on its own; the twin holds
 // grid rows back (SetGridColumns) -- the two terminal streams must not differ in a byte.
-// (the "degrade" mode runs the grid without its animation: after a device failure the block twin sends FULL frames where
-// the device would have sent differences -- valid, but other bytes; every other Send must not differ in a byte)
+// (until round 6 the "degrade" mode ran the grid without its animation: after a device failure the block twin sent FULL
+// frames where the device would have sent differences.  The CPU sibling is now shown the frame the device saw last
+// (HipUnicodeBlockCanvas::RememberFrame), so the animation stays in: differences included, not a byte differs.)
 static bool g_grid_animation = true;
 template <class MakeCanvas>
 static std::string RunGridLikeTimg(int fd, size_t queue_len, int columns, bool sixel, MakeCanvas make) {
@@ -986,6 +987,46 @@ static void CheckPools() {
     fflush(stdout);
 }
 
+// An animation at one place on ONE block canvas, four Sends = four device calls: with TIMG_HIP_FAIL_CALL=2 (or 3) the
+// switch to the CPU sibling happens between two frames of it -- the frame after the switch must still be the frame
+// DIFFERENCE the reference sends (src/unicode-block-canvas.cc:343-346), not a full frame.  First stage of `degrade`.
+static void CheckBlockAnimationAcrossTheSwitch() {
+    std::string streams[2];
+    size_t first_frame[2] = {0, 0};
+    for (int twin = 0; twin < 2; ++twin) {
+        rng_state = 31337;
+        volatile sig_atomic_t intr = 0;
+        const int fd = memfd_create("anim", 0);
+        {
+            BufferedWriteSequencer seq(fd, false, 4, true, intr);
+            std::unique_ptr<TerminalCanvas> canvas;
+            if (twin && SharedHipContext()) canvas.reset(new HipUnicodeBlockCanvas(&seq, true, false, false));
+            else canvas.reset(new UnicodeBlockCanvas(&seq, true, false, false));
+            Framebuffer fb(100, 56);
+            Fill(&fb, 1);
+            canvas->Send(4, 0, fb, SeqType::StartOfAnimation, {});
+            seq.Flush();
+            first_frame[twin] = (size_t)lseek(fd, 0, SEEK_END);
+            for (int f = 0; f < 3; ++f) {
+                rgba_t c;
+                c.r = 250; c.g = (uint8_t)(80 * f); c.b = 20; c.a = 255;
+                for (int x = 10; x < 30; ++x) fb.SetPixel(x, 8 + 9 * f, c);
+                canvas->Send(4, -56, fb, SeqType::AnimationFrame, {});
+            }
+            canvas.reset();
+        }
+        streams[twin] = Slurp(fd);
+        close(fd);
+    }
+    CHECK(streams[0] == streams[1], "animation across the switch: %zu (reference) vs %zu bytes", streams[0].size(), streams[1].size());
+    // (the three later frames together are far smaller than the first: they ARE differences)
+    CHECK(streams[1].size() - first_frame[1] < first_frame[1] / 2, "the frames after the first are not differences: %zu + %zu bytes",
+          first_frame[1], streams[1].size() - first_frame[1]);
+    printf("block animation across the switch: %zu bytes, frames 2-4 are differences (%zu bytes)\n", streams[1].size(),
+           streams[1].size() - first_frame[1]);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv) {
     // twin_check [all|scaler|block|grid|sixel|timggrid|graphics|source|animation|autocrop|gather|hostpath|pools|bilinear|degrade] [sixel-dump-path]
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -1012,7 +1053,7 @@ int main(int argc, char **argv) {
     if (what == "degrade") {
         // run with TIMG_HIP_FAIL_CALL=k: the k-th device call of the process fails; the twins say so once on stderr and go
         // on with the reference's classes (cpu-sibling.h, HipImageScaler::ScaleOnCpu) -- same terminal streams
-        g_grid_animation = false;
+        CheckBlockAnimationAcrossTheSwitch();
         CheckGridLikeTimg();
         CheckHostFramesPath();
         printf("degrade: device failure injected (TIMG_HIP_FAIL_CALL=%s), degraded=%d: streams identical to the reference classes\n",

@@ -20,7 +20,7 @@ CpuSibling::~CpuSibling() {
     if (fd_ >= 0) close(fd_);
 }
 
-std::string CpuSibling::Encode(int x, const uint8_t *pixels, int width, int height) {
+std::string CpuSibling::Encode(int x, const uint8_t *pixels, int width, int height, int dy) {
     std::lock_guard<std::mutex> l(mu_);
     if (!canvas_) {
         fd_ = memfd_create("timg-cpu-sibling", 0);
@@ -39,7 +39,7 @@ std::string CpuSibling::Encode(int x, const uint8_t *pixels, int width, int heig
     // AppendDoubleRow<2> reads its first pixel for odd widths (src/unicode-block-canvas.cc:242-243).  The device path
     // defines that pixel as transparent black: the sibling continues a stream the device began, so it does too.
     memset((void *)fb.end(), 0, (size_t)width * 4);
-    canvas_->Send(x, 0, fb, SeqType::FrameImmediate, Duration());
+    canvas_->Send(x, dy, fb, SeqType::FrameImmediate, Duration());
     sequencer_->Flush();
     const off_t n = lseek(fd_, 0, SEEK_END);
     std::string bytes((size_t)(n > 0 ? n : 0), '\0');

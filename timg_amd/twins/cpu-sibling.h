@@ -31,9 +31,11 @@ public:
     // make(sequencer, pool): constructs the reference canvas (called once, on first use)
     explicit CpuSibling(std::function<TerminalCanvas *(BufferedWriteSequencer *, ThreadPool *)> make);
     ~CpuSibling();
-    // The bytes the reference canvas writes for Send(x, 0, frame): host pixels, RGBA8, tightly packed.
+    // The bytes the reference canvas writes for Send(x, dy, frame): host pixels, RGBA8, tightly packed.  (dy < 0 makes the
+    // canvas write its own cursor-up prefix in front and decide about a frame DIFFERENCE the way the reference does,
+    // src/unicode-block-canvas.cc:343-346; callers that have queued the cursor move themselves strip it.)
     // Thread-safe (one frame at a time).  Empty string: the canvas emitted nothing.
-    std::string Encode(int x, const uint8_t *pixels, int width, int height);
+    std::string Encode(int x, const uint8_t *pixels, int width, int height, int dy = 0);
 
 private:
     const std::function<TerminalCanvas *(BufferedWriteSequencer *, ThreadPool *)> make_;

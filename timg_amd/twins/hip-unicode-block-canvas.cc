@@ -33,6 +33,15 @@ HipUnicodeBlockCanvas::HipUnicodeBlockCanvas(BufferedWriteSequencer *ws, bool us
     DeviceFrameConsumerCreated();
 }
 
+void HipUnicodeBlockCanvas::RememberFrame(int x, const uint8_t *pixels, bool on_device, int width, int height) {
+    prev_valid_ = !on_device;  // (a device-resident frame is not brought back for this: after a switch its successor is a full frame)
+    if (on_device) return;
+    prev_pixels_.assign(pixels, pixels + (size_t)width * height * 4);
+    prev_x_ = x;
+    prev_w_ = width;
+    prev_h_ = height;
+}
+
 size_t HipUnicodeBlockCanvas::EncodeOnCpu(HeldFrame &p, const uint8_t *pixels, bool on_device, int width, int height,
                                           const char *what) {
     HipDegrade(ctx_, what);
@@ -43,7 +52,20 @@ size_t HipUnicodeBlockCanvas::EncodeOnCpu(HeldFrame &p, const uint8_t *pixels, b
         if (timg_hip_memcpy_d2h(ctx_, host.data(), pixels, host.size(), nullptr) != TIMG_HIP_OK) HipFatal(ctx_, what);
         pixels = host.data();
     }
-    const std::string bytes = cpu_->Encode(p.x, pixels, width, height);
+    // The sibling starts where the device canvas stopped: it is shown the frame the device saw last (its bytes are
+    // thrown away), so that THIS frame is a difference exactly when the reference would send one.
+    if (!sibling_primed_) {
+        sibling_primed_ = true;
+        if (prev_valid_) (void)cpu_->Encode(prev_x_, prev_pixels_.data(), prev_w_, prev_h_, 0);
+    }
+    // (dy goes to the sibling -- the difference rule needs it -- which then writes the cursor-up jump this twin has
+    // already queued in p's prefix: taken off again.  Nothing emitted stays nothing: src/unicode-block-canvas.cc:390-395.)
+    std::string bytes = cpu_->Encode(p.x, pixels, width, height, p.dy);
+    if (p.dy < 0 && !bytes.empty()) {
+        char jump[32];
+        const size_t n = (size_t)snprintf(jump, sizeof(jump), "\033[%dA", -cell_height_for_pixels(p.dy));
+        if (cell_height_for_pixels(p.dy) != 0 && bytes.compare(0, n, jump) == 0) bytes.erase(0, n);
+    }
     if (p.prefix + bytes.size() > p.cap) {
         char *bigger = new char[p.prefix + bytes.size()];
         memcpy(bigger, p.buffer, p.prefix);
@@ -82,10 +104,12 @@ void HipUnicodeBlockCanvas::SendNow(HeldFrame &p, const uint8_t *pixels, bool on
         HipCall(ctx_, [&]() {
             return timg_hip_block_canvas_send(canvas_, p.x, p.dy, pixels, width, height, 0, on_device, p.buffer + p.prefix,
                                               p.cap - p.prefix, &len, nullptr);
-        }) != TIMG_HIP_OK)
+        }) != TIMG_HIP_OK) {
         len = EncodeOnCpu(p, pixels, on_device, width, height, "timg_hip_block_canvas_send");
-    else
+    } else {
         HipCountFrames(kHipTwinBlock, true);
+        RememberFrame(p.x, pixels, on_device, width, height);
+    }
     // nothing emitted: the reference keeps the buffer size zero, dropping the
     // cursor jump as well (:390-395)
     write_sequencer_->WriteBuffer(OutBuffer(p.buffer, len ? p.prefix + len : 0), seq_type, end_of_frame);
@@ -130,8 +154,10 @@ void HipUnicodeBlockCanvas::EncodeBatch(HeldBatch &batch) {
                                               batch.on_device, p.buffer + p.prefix, p.cap - p.prefix, &len, nullptr);
         }) != TIMG_HIP_OK)
         len = EncodeOnCpu(p, batch.data() + (n - 1) * frame_bytes, batch.on_device, batch.w, batch.h, "timg_hip_block_canvas_send");
-    else
+    else {
         HipCountFrames(kHipTwinBlock, true);
+        RememberFrame(p.x, batch.data() + (n - 1) * frame_bytes, batch.on_device, batch.w, batch.h);
+    }
     p.promise.set_value(OutBuffer(p.buffer, len ? p.prefix + len : 0));
 }
 

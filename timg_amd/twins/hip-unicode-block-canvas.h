@@ -58,6 +58,13 @@ private:
     bool have_last_x_ = false;
     int last_x_       = 0;  // x of the previous Send
     std::unique_ptr<CpuSibling> cpu_;
+    // The frame the DEVICE canvas saw last (host-resident frames only), so that a CPU sibling that takes over in the
+    // middle of an animation can be shown it first and goes on emitting frame DIFFERENCES where the reference would
+    // (src/unicode-block-canvas.cc:343-346) -- until round 6 the frame after the switch was a full frame: valid, other bytes.
+    void RememberFrame(int x, const uint8_t *pixels, bool on_device, int width, int height);
+    std::vector<uint8_t> prev_pixels_;
+    int prev_x_ = 0, prev_w_ = 0, prev_h_ = 0;
+    bool prev_valid_ = false, sibling_primed_ = false;
     std::unique_ptr<HeldRows> rows_;  // (last member: its thread uses the ones above)
 };
 

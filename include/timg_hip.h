@@ -144,7 +144,8 @@ int timg_hip_scaler_set_kernel(timg_hip_scaler *s, int which);
 /* Introspection: info[0]=vertical_first [1]=h_widest [2]=v_is_gather
  * [3]=v_widest [4]=h_filter [5]=v_filter [6]=bit 0 streaming kernel applicable,
  * bit 1 its matrix-core variant serves the plan, bit 2 ... with a fifth live
- * output row (the overflow row) [7]=max active output rows per input row. */
+ * output row (the overflow row), bit 3 a horizontal-first plan served by the kernel
+ * that carries two output columns per lane pair [7]=max active output rows per input row. */
 int timg_hip_scaler_info(const timg_hip_scaler *s, int info[8]);
 /* Algorithmic HBM bytes of one frame (read source once + write result once,
  * SURVEY.md 8d). */

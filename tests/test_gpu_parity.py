@@ -725,6 +725,48 @@ def test_all_four_matrix_kernel_instantiations(hip, oracle):
     assert seen == {("photo", 0), ("photo", 1), ("alpha", 0), ("alpha", 1)}, seen
 
 
+def test_two_column_horizontal_first_kernel_and_its_fallback(hip, oracle, monkeypatch):
+    """Round 6: horizontal-first plans whose columns share most of their taps (8K -> 800: 39 taps, columns 9.6 pixels
+    apart) run ScaleStreamH2Kernel -- two output columns per lane pair, strips of 64 columns, the few columns at the
+    clamped edges alone in their pair -- for the opaque and the premultiplied channel set; tiles that need all seven
+    channels (a filtered alpha below 2^-120 that is NOT composed away) fall back to the one-column kernel on the two
+    halves of their strip.  One frame with all three kinds of tiles, uncomposed and composed, against the reference's
+    arithmetic; the same frame with the kernel switched off (TIMG_HIP_H2=0) gives the same bytes."""
+    sw, sh, dw, dh = 7680, 1000, 800, 100
+    assert oracle.plan_info(sw, sh, dw, dh)["vertical_first"] == 0
+    src = synth.photo(sw, sh, seed=41)
+    a = synth.alpha(sw, sh, seed=42)
+    src[:, 2600:5200] = a[:, 2600:5200]          # a band of columns with real alpha
+    src[200:700, 5200:7000, 3] = 0               # fully transparent: filtered alpha 0 -> the straight RGB sums are needed
+    want = oracle.scale(src, dw, dh)
+    sc = hip.scaler(sw, sh, dw, dh)
+    info = sc.info()
+    assert info["streaming_ok"] == 1 and info["vertical_first"] == 0 and info["two_column_kernel"] == 1, info
+    got = np.empty((dh, dw, 4), np.uint8)
+    hip.scale_blend(sc, src, got, 1, None)
+    assert np.array_equal(got, want)
+    blend = timg_amd.Blend.make(BG, PAT, 18, 18)
+    hip.scale_blend(sc, src, got, 1, blend)
+    assert np.array_equal(got, oracle.alpha_compose(want, BG, PAT, 18, 18)[0])
+    sc.close()
+    monkeypatch.setenv("TIMG_HIP_H2", "0")
+    sc0 = hip.scaler(sw, sh, dw, dh)
+    assert sc0.info()["two_column_kernel"] == 0
+    got0 = np.empty((dh, dw, 4), np.uint8)
+    hip.scale_blend(sc0, src, got0, 1, None)
+    assert np.array_equal(got0, want)
+    sc0.close()
+    # other widths that pair up (first step 4 or 5: 33 to 40 taps) and a bgra source
+    for (w2, d2) in ((7000, 800), (6601, 777), (8000, 800)):
+        s2 = synth.alpha(w2, 400, seed=w2)
+        sc2 = hip.scaler(w2, 400, d2, 40, in_fmt=1)
+        if oracle.plan_info(w2, 400, d2, 40)["vertical_first"] == 0:
+            g2 = np.empty((40, d2, 4), np.uint8)
+            hip.scale_blend(sc2, s2, g2, 1, None)
+            assert np.array_equal(g2, oracle.scale(s2, d2, 40, in_fmt=1)), (w2, d2, sc2.info())
+        sc2.close()
+
+
 @pytest.mark.parametrize("sw,sh,dw,dh", [(1366, 768, 200, 112), (1366, 768, 455, 256), (999, 1333, 333, 444),
                                          (1023, 767, 341, 255), (6, 1000, 3, 100), (5, 500, 2, 100),  # vertical-first
                                          (1001, 999, 100, 100), (1275, 1650, 150, 194), (2561, 1441, 320, 180),

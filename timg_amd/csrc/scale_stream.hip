@@ -1152,6 +1152,9 @@ ScaleStreamMKernel(DevPlan plan, StreamTables tab, MTables mt, DevBlend blend, F
 constexpr int kColsH    = 32;    // output columns per workgroup = ONE WAVE
 constexpr int kThreadsH = 64;    // ... two lanes per column: stb's even and odd tap chains
 constexpr int kWinMaxH  = 1024;  // source columns of a strip's window (multiple of 4)
+#ifndef TIMG_H2_WAVES
+#define TIMG_H2_WAVES 3
+#endif
 
 // One float4 per pixel in the row buffer: kOpaque (R, G, B, 1), kPremult (A, RA, GA, BA),
 // kFull (R, G, B, A) -- its weighted channels RA GA BA are formed while gathering, by the
@@ -1192,7 +1195,7 @@ __device__ __forceinline__ float FromPartner(float v) {
 template <int M, int TAPS, int LOADS>
 __global__ void __launch_bounds__(kThreadsH) __attribute__((amdgpu_waves_per_eu((M == kFull || TAPS > 20) ? 2 : 3, (M == kFull || TAPS > 20) ? 2 : 3)))
 ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch batch, int *tile_state,
-                   int gen, int win, int w4) {
+                   int gen, int win, int w4, int tile_pair) {
     static_assert(LOADS == 2 || LOADS == 4, "two or four 16-byte loads per lane and row");
     // One row buffer of 4 planes x w4 pixels: pixel n of the window lives in plane n & 3 at
     // index n >> 2.  The decoder's lanes hold 4 consecutive pixels each, so plane q is written
@@ -1203,9 +1206,13 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
     constexpr int kStride = 4;  // floats per pixel in the row buffer
     constexpr int kHc     = M == kFull ? 7 : 4;   // channels of the horizontal gather
     constexpr int kVc     = M == kFull ? 4 : 2;   // channels a lane carries through the vertical pass
-    const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // tile_pair: this launch is the LAST of a chain whose earlier kernels (ScaleStreamH2Kernel) tiled the frame in strips
+    // of twice the width -- strips 2k and 2k + 1 here are the halves of their strip k: their tile's state is read, none written
+    const int tile = tile_pair ? (blockIdx.z * gridDim.y + blockIdx.y) * (gridDim.x >> 1) + (blockIdx.x >> 1)
+                               : (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (tile_state[tile] == gen) return;  // done by an earlier kernel of this call (uniform: whole workgroup leaves)
     const StripInfo si    = LoadConstant(tab.strips + blockIdx.x);
+    if (si.ox0 >= si.ox1) return;  // (the empty second half of a narrow last strip)
     const BandInfo bi     = LoadConstant(tab.bands + blockIdx.y);
     const RowSched *sched = tab.sched + bi.sched;
     const int f           = blockIdx.z;
@@ -1466,12 +1473,275 @@ ScaleStreamHKernel(DevPlan plan, StreamTables tab, DevBlend blend, FrameBatch ba
 #undef TIMG_H_STEP
 #undef TIMG_H_ISSUE
     if (M == kPremult && __any(tiny)) return;  // (found by the last row)
-    if (tid == 0) tile_state[tile] = gen;  // (any other row that broke the channel set's assumption has left through row_step)
+    if (tid == 0 && !tile_pair) tile_state[tile] = gen;  // (any other row that broke the channel set's assumption has left through row_step)
+}
+
+
+// ===================================================================================
+// Horizontal-first plans whose neighbouring columns share most of their taps (round 6): TWO output columns per lane
+// pair.  The kernel above reads 16 bytes of LDS per (column, tap) -- at 8K -> 800x450 (39 taps, columns 9.6 source
+// pixels apart) 20 KB a wave and source row for a window of 5.5 KB, and its LDS pipe is busy 78 % of the time
+// (profiles/r5/sq_counters_c5.txt); no layout of the row buffer takes the bank conflicts of that gather below a factor
+// of 1.7 (48 source pixels are exactly 5 columns: scratch/sim_h_gather_banks.py, profiles/r6/h2_kernel.txt).  Here a
+// lane of pair i walks ONE chain parity p of source pixels  n0(A) + p + 2j,  j = 0 .. JS + TAPS,  for column A = 2i
+// AND for column B = 2i + 1, whose window starts d = n0(B) - n0(A) pixels further on: the pixel a step reads is tap
+// 2j + p of A (steps 0 .. TAPS - 1) and tap 2j + p - d of B (steps JS .. JS + TAPS: TAPS + 1 slots, the first or the
+// last of them padded with weight 0 according to the lane's own start (d + q - p) / 2 in {JS, JS + 1}).  B's taps met
+// by this lane form ONE chain of B (even or odd, by the parity of d), in stb's order; the partner lane meets the
+// other.  25 reads of 16 bytes serve what took 40 (two waves x 20); a wave carries 64 columns, its window 653 source
+// pixels instead of 2 x 346: half the horizontal halo as well.  Per column the multiply-adds are those of the kernel
+// above, operation for operation (stb_image_resize2.h:5801-6009).  After the gather the pair exchanges what the
+// other lane needs: lane 0 finishes column A, lane 1 column B -- all four channels of its column through the vertical
+// pass, a completed pixel straight from its own registers.
+// Applicability (host: H2Applicable): more than 3 taps, every pair's d gives starts in {JS, JS + 1}, windows of 64
+// columns within kWinMaxH.  The seven-channel set falls back to the kernel above on the two halves of every strip.
+constexpr int kColsH2 = 64;  // output columns per workgroup = ONE WAVE: 32 lane pairs x 2 columns
+
+template <int M, int TAPS, int JS, int LOADS>
+__global__ void __launch_bounds__(kThreadsH) __attribute__((amdgpu_waves_per_eu(TIMG_H2_WAVES, TIMG_H2_WAVES)))
+ScaleStreamH2Kernel(DevPlan plan, StreamTables tab, const int2 *pairs, DevBlend blend, FrameBatch batch, int *tile_state,
+                    int gen, int win, int w4) {
+    static_assert(M == kOpaque || M == kPremult, "the four-channel sets");
+    static_assert(LOADS == 2 || LOADS == 3 || LOADS == 4, "two to four 16-byte loads per lane and row");
+    static_assert(JS >= 1 && JS < TAPS, "the second column's window overlaps the first's");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kStride = 4;        // floats per pixel in the row buffer
+    constexpr int kSteps  = JS + TAPS + 1;
+    const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tile_state[tile] == gen) return;  // done by an earlier kernel of this call (uniform: whole workgroup leaves)
+    const StripInfo si    = LoadConstant(tab.strips + blockIdx.x);
+    const BandInfo bi     = LoadConstant(tab.bands + blockIdx.y);
+    const RowSched *sched = tab.sched + bi.sched;
+    const int f           = blockIdx.z;
+    const int tid         = threadIdx.x;
+    const int par         = tid & 1;  // the chain parity this lane walks -- and: 0 finishes column A, 1 column B
+    const int buf_floats  = 4 * w4 * kStride;
+    for (int i = tid; i < buf_floats / 4; i += kThreadsH)
+        reinterpret_cast<float4 *>(lds)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto slot = [&](int n) -> int { return ((n & 3) * w4 + (n >> 2)) * kStride; };  // float index of pixel n
+
+    // the pair's columns (host table, 32 entries a strip): B = A + 1 where the two windows sit as the steps assume, or none
+    // (-1: a column at a clamped edge, whose window starts where its neighbour's does, has the pair to itself)
+    const int2 pr    = pairs[(size_t)blockIdx.x * (kColsH2 / 2) + (tid >> 1)];
+    const int ox_a   = pr.x, ox_b = pr.y;
+    const bool has_a = ox_a >= 0, has_b = ox_b >= 0;
+    int2 ht_a        = make_int2(si.cx0, 0);
+    if (has_a) ht_a = plan.h_taps[ox_a];
+    int2 ht_b = make_int2(ht_a.x + 2 * JS, 0);
+    if (has_b) ht_b = plan.h_taps[ox_b];
+    const int d   = ht_b.x - ht_a.x;
+    const int n0l = ht_a.x - si.cx0;
+    float hw_a[TAPS], hw_b[TAPS + 1];
+    {
+        const float *hc_a = plan.h_coeff + (size_t)(has_a ? ox_a : 0) * plan.h_width;
+        const float *hc_b = plan.h_coeff + (size_t)(has_b ? ox_b : 0) * plan.h_width;
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) {
+            const int k = 2 * j + par;
+            hw_a[j]     = (has_a && k < ht_a.y) ? hc_a[k] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t <= TAPS; ++t) {
+            const int k = par + 2 * (JS + t) - d;  // B's tap under the pixel of step JS + t
+            hw_b[t]     = (has_b && k >= 0 && k < ht_b.y) ? hc_b[k] : 0.0f;
+        }
+    }
+    // the column this lane finishes
+    const int ox   = par ? ox_b : ox_a;
+    const bool has = par ? has_b : has_a;
+    int *flag = batch.transparent_flags ? batch.transparent_flags + f : nullptr;
+    uint8_t *dst_frame = batch.dst + (size_t)f * batch.dst_frame_stride;
+
+    // raw source rows: lane t owns the 4-pixel chunks t, t + 64, ... of the window (as in the kernel above)
+    const uint8_t *frame = batch.src + (size_t)f * batch.src_frame_stride;
+    const int r_last     = min(bi.r1, plan.in_h - 1);
+    const uint8_t *chunk_ptr[LOADS];
+    bool chunk_in[LOADS];
+    int chunk_shift[LOADS];
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+        const int c    = tid + j * kThreadsH;
+        const int col  = si.cx0 + 4 * c;
+        chunk_in[j]    = 4 * c < win;
+        chunk_ptr[j]   = frame + (size_t)min(min(col, si.cx0 + win - 4), plan.in_w - 4) * 4u;
+        chunk_shift[j] = (col < plan.in_w && col + 4 > plan.in_w) ? col + 4 - plan.in_w : 0;
+    }
+    bool any_shift = false;
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) any_shift = any_shift || __any(chunk_shift[j] != 0);
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    size_t next_off       = (size_t)min(bi.r0, r_last) * batch.src_stride;
+    const size_t last_off = (size_t)r_last * batch.src_stride;
+    auto issue_one = [&](u4v &q, int j) __attribute__((always_inline)) {
+        const uint8_t *p = chunk_ptr[j] + next_off;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q) : "v"(p) : "memory");
+    };
+    auto advance_row = [&]() __attribute__((always_inline)) { next_off = min(next_off + batch.src_stride, last_off); };  // uniform
+
+    float acc[kSlots][4];  // vertical sums of this lane's column, row-buffer channel order
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) acc[s][ch] = 0.0f;
+    uint32_t amin = 0xffffffffu;
+    bool tiny     = false;
+    const bool need_straight  = !(blend.enabled && blend.start_row <= bi.oy0);
+    const uint32_t amin_limit = M == kOpaque ? 0xff000000u : need_straight ? 0x01000000u : 0u;
+
+    RowSched rs_next          = LoadConstant(sched);
+    const RowSched *sched_ptr = sched;
+    auto row_step = [&](const uint4 &r0, const uint4 &r1, const uint4 &r2, const uint4 &r3) __attribute__((always_inline)) -> bool {
+        const uint4 raw[4] = {r0, r1, r2, r3};
+        const RowSched rs  = rs_next;
+        asm volatile("" ::"s"(rs.flags[0]), "s"(rs.weight[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        rs_next    = LoadConstant(++sched_ptr);
+        float *buf = lds;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) {
+            if (!chunk_in[j]) continue;
+            uint4 q = raw[j];
+            if (any_shift && chunk_shift[j]) {
+                if (chunk_shift[j] == 1) q = make_uint4(q.y, q.z, q.w, q.w);
+                else if (chunk_shift[j] == 2) q = make_uint4(q.z, q.w, q.w, q.w);
+                else q = make_uint4(q.w, q.w, q.w, q.w);
+            }
+            amin = MinU32(MinU32(MinU32(amin, q.x), q.y), MinU32(q.z, q.w));
+            float *dst = buf + (size_t)(tid + j * kThreadsH) * kStride;
+            DecodeToLds<M>(q.x, dst);
+            DecodeToLds<M>(q.y, dst + (size_t)w4 * kStride);
+            DecodeToLds<M>(q.z, dst + (size_t)2 * w4 * kStride);
+            DecodeToLds<M>(q.w, dst + (size_t)3 * w4 * kStride);
+        }
+        if (__any(amin < amin_limit || tiny)) return false;  // (the workgroup is this one wave)
+
+        // the lane's chain over the window of BOTH columns: steps alternate between two planes of the row buffer
+        const int nb      = n0l + par;
+        const float *b_ev = buf + slot(nb), *b_od = buf + slot(nb + 2);
+        f2v a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f}, b01 = {0.0f, 0.0f}, b23 = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < kSteps; ++j) {
+            const f4v t = LdsSlot(((j & 1) ? b_od : b_ev) + (size_t)(j >> 1) * kStride);
+            if (j < TAPS) {
+                a01 = a01 + f2v{t.x, t.y} * f2v{hw_a[j < TAPS ? j : 0], hw_a[j < TAPS ? j : 0]};
+                a23 = a23 + f2v{t.z, t.w} * f2v{hw_a[j < TAPS ? j : 0], hw_a[j < TAPS ? j : 0]};
+            }
+            if (j >= JS) {
+                b01 = b01 + f2v{t.x, t.y} * f2v{hw_b[j >= JS ? j - JS : 0], hw_b[j >= JS ? j - JS : 0]};
+                b23 = b23 + f2v{t.z, t.w} * f2v{hw_b[j >= JS ? j - JS : 0], hw_b[j >= JS ? j - JS : 0]};
+            }
+        }
+        // even chain + odd chain of a column = this lane's sum + the partner's (commutative): lane 0 takes A, lane 1 B --
+        // each hands the other what it has of the other's column
+        const f2v give01 = par ? a01 : b01, give23 = par ? a23 : b23;
+        const f2v keep01 = par ? b01 : a01, keep23 = par ? b23 : a23;
+        float h[4];
+        h[0] = keep01.x + FromPartner(give01.x);
+        h[1] = keep01.y + FromPartner(give01.y);
+        h[2] = keep23.x + FromPartner(give23.x);
+        h[3] = keep23.y + FromPartner(give23.y);
+
+        // vertical: feed the active output rows of this lane's column, finish the one that completes
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int fl = rs.flags[s];
+            if (!(fl & 1)) continue;  // wave-uniform
+            const float w = rs.weight[s];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) acc[s][ch] = acc[s][ch] + h[ch] * w;
+            if (fl & 4) {
+                Px7 px;
+                if (M == kOpaque) {  // (R, G, B, 1): with alpha == 1 the straight and the weighted sums coincide
+                    px.c[0] = acc[s][0];
+                    px.c[1] = acc[s][1];
+                    px.c[2] = acc[s][2];
+                    px.c[3] = acc[s][3];
+                    px.c[4] = acc[s][0];
+                    px.c[5] = acc[s][1];
+                    px.c[6] = acc[s][2];
+                } else {  // (RA, GA, BA, A)
+                    px.c[0] = px.c[1] = px.c[2] = 0.0f;
+                    px.c[3] = acc[s][3];
+                    px.c[4] = acc[s][0];
+                    px.c[5] = acc[s][1];
+                    px.c[6] = acc[s][2];
+                    if (need_straight && has && px.c[3] < TIMG_TINY_F32) tiny = true;  // (acted upon by the next row's check)
+                }
+                const int y = fl >> 8;
+                if (has) {
+                    const uint32_t out = FinishStreamPixel(px, ox, y, plan.swap_rb, blend, flag);
+                    *reinterpret_cast<uint32_t *>(dst_frame + (size_t)y * batch.dst_stride + (size_t)ox * 4) = out;
+                }
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) acc[s][ch] = 0.0f;
+            }
+        }
+        return true;
+    };
+
+    // rows in flight per lane: named register sets (see the kernels above), set k = (qka .. qk[LOADS])
+#ifndef TIMG_H2_DEPTH
+#define TIMG_H2_DEPTH 2  // (three rows in flight need 12 more registers than three waves a SIMD leave: spills behind vmcnt(0))
+#endif
+    constexpr int kDepth2 = LOADS <= 3 ? TIMG_H2_DEPTH : 2;  // (four rows of two loads: the compiler rotated the sets through copies -- check_ring_isa.py refused it)
+    const u4v z4 = {0, 0, 0, 0};
+    u4v q0a, q0b, q0c = z4, q0d = z4, q1a, q1b, q1c = z4, q1d = z4, q2a = z4, q2b = z4, q2c = z4, q2d = z4, q3a = z4, q3b = z4,
+        q3c = z4, q3d = z4;
+#define TIMG_H2_ISSUE(K)                                  \
+    issue_one(q##K##a, 0);                                \
+    issue_one(q##K##b, 1);                                \
+    if constexpr (LOADS >= 3) issue_one(q##K##c, 2);      \
+    if constexpr (LOADS >= 4) issue_one(q##K##d, 3);      \
+    advance_row();
+#define TIMG_H2_STEP(K)                                                                                                  \
+    if (left < K + 1) break;                                                                                             \
+    if constexpr (LOADS == 2)                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%2) ; ring %0 %1" : "+v"(q##K##a), "+v"(q##K##b) : "n"((kDepth2 - 1) * LOADS) : "memory"); \
+    else if constexpr (LOADS == 3)                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%3) ; ring %0 %1 %2" : "+v"(q##K##a), "+v"(q##K##b), "+v"(q##K##c)                 \
+                     : "n"((kDepth2 - 1) * LOADS) : "memory");                                                           \
+    else                                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(%4) ; ring %0 %1 %2 %3"                                                            \
+                     : "+v"(q##K##a), "+v"(q##K##b), "+v"(q##K##c), "+v"(q##K##d)                                        \
+                     : "n"((kDepth2 - 1) * LOADS) : "memory");                                                           \
+    if (!row_step(make_uint4(q##K##a.x, q##K##a.y, q##K##a.z, q##K##a.w), make_uint4(q##K##b.x, q##K##b.y, q##K##b.z, q##K##b.w), \
+                  make_uint4(q##K##c.x, q##K##c.y, q##K##c.z, q##K##c.w), make_uint4(q##K##d.x, q##K##d.y, q##K##d.z, q##K##d.w))) \
+        return;                                                                                                          \
+    TIMG_H2_ISSUE(K)
+    TIMG_H2_ISSUE(0)
+    TIMG_H2_ISSUE(1)
+    if constexpr (kDepth2 >= 3) {
+        TIMG_H2_ISSUE(2)
+    }
+    if constexpr (kDepth2 >= 4) {
+        TIMG_H2_ISSUE(3)
+    }
+    for (int left = bi.r1 - bi.r0 + 1; left > 0; left -= kDepth2) {  // (rows still to do)
+        TIMG_H2_STEP(0)
+        TIMG_H2_STEP(1)
+        if constexpr (kDepth2 >= 3) {
+            TIMG_H2_STEP(2)
+        }
+        if constexpr (kDepth2 >= 4) {
+            TIMG_H2_STEP(3)
+        }
+    }
+    // (loads still in flight must land before their registers mean anything else)
+    asm volatile("s_waitcnt vmcnt(0) ; ring all"
+                 : "+v"(q0a), "+v"(q0b), "+v"(q0c), "+v"(q0d), "+v"(q1a), "+v"(q1b), "+v"(q1c), "+v"(q1d), "+v"(q2a), "+v"(q2b),
+                   "+v"(q2c), "+v"(q2d), "+v"(q3a), "+v"(q3b), "+v"(q3c), "+v"(q3d)
+                 :
+                 : "memory");
+#undef TIMG_H2_STEP
+#undef TIMG_H2_ISSUE
+    if (M == kPremult && __any(tiny)) return;  // (found by the last row)
+    if (tid == 0) tile_state[tile] = gen;
 }
 
 }  // namespace
 
 // ---- host side: applicability + schedule ------------------------------------------
+static bool H2Instantiated(int taps_lane, int js);
 struct StreamVariant {
     void *device   = nullptr;
     StreamTables t = {};
@@ -1488,6 +1758,15 @@ struct StreamSchedule {
     int hrow        = 0;        // widest strip, in output columns
     bool hfirst     = false;    // horizontal-first plan: ScaleStreamHKernel
     int hwin        = 0;        // ... widest source window of a strip (multiple of 4)
+    // ScaleStreamH2Kernel (two columns per lane pair) serves the plan's opaque and premultiplied channel sets: its strips
+    // (up to 64 columns; the strips of the tables above are then their halves, for the seven-channel fallback), the
+    // widest window and the lanes' common first step of the second column
+    bool h2               = false;
+    StripInfo *h2_strips  = nullptr;  // device
+    int2 *h2_pairs        = nullptr;  // device: [strip][32] {column A, column B or -1} ({-1, -1}: an idle pair)
+    int h2_n_strips       = 0;
+    int h2_win            = 0;
+    int h2_js             = 0;
     // Tile bookkeeping of a scale call, per SLOT: calls of one scaler that may be in flight at the same time (the
     // pieces of timg_hip_scale_sixel_encode, each on its own stream) use different slots.
     static constexpr int kTileSlots = 4;
@@ -1762,8 +2041,9 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     for (int y = 1; y < p.out_h; ++y)
         if (last[y] < last[y - 1] || first[y] < first[y - 1]) return no("non-monotonic rows");
 
-    std::vector<StripInfo> strips;
-    int hwin = 0;
+    std::vector<StripInfo> strips, h2_wide;
+    std::vector<int2> h2_pairs_host;
+    int hwin = 0, h2_wide_win = 0, h2_js_min = 0;
     if (p.vertical_first) {
         // strips: as many output columns as fit with all their taps in kStripCols source columns
         for (int ox = 0; ox < p.out_w;) {
@@ -1788,26 +2068,138 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     } else {
         // horizontal-first: a lane pair per output column, the strip's source window in LDS;
         // equally wide strips (a narrow last strip would cost a full walk over the rows)
-        const int n_even = (p.out_w + kColsH - 1) / kColsH;
-        const int cols   = (p.out_w + n_even - 1) / n_even;
-        for (int ox = 0; ox < p.out_w;) {
-            StripInfo si;
-            si.ox0  = ox;
-            si.cx0  = p.h_taps[ox].n0 & ~3;
-            si.pad  = 0;
-            int end = ox, reach = si.cx0;
-            while (end < p.out_w && end - ox < cols) {
-                const HTaps &t = p.h_taps[end];
-                if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kWinMaxH) break;
-                reach = std::max(reach, t.n0 + t.count);
-                ++end;
+        auto cut = [&](int cols_max, std::vector<StripInfo> *out, int *win_out) -> bool {
+            const int n_even = (p.out_w + cols_max - 1) / cols_max;
+            const int cols   = (p.out_w + n_even - 1) / n_even;
+            for (int ox = 0; ox < p.out_w;) {
+                StripInfo si;
+                si.ox0  = ox;
+                si.cx0  = p.h_taps[ox].n0 & ~3;
+                si.pad  = 0;
+                int end = ox, reach = si.cx0;
+                while (end < p.out_w && end - ox < cols) {
+                    const HTaps &t = p.h_taps[end];
+                    if (t.n0 < si.cx0 || t.n0 + t.count > si.cx0 + kWinMaxH) break;
+                    reach = std::max(reach, t.n0 + t.count);
+                    ++end;
+                }
+                if (end == ox) return false;
+                si.ox1   = end;
+                *win_out = std::max(*win_out, (reach - si.cx0 + 3) & ~3);
+                out->push_back(si);
+                ox = end;
             }
-            if (end == ox) return no("horizontal window wider than the row buffer");
-            si.ox1 = end;
-            hwin   = std::max(hwin, (reach - si.cx0 + 3) & ~3);
-            strips.push_back(si);
-            ox = end;
+            return true;
+        };
+        // Two columns per lane pair (ScaleStreamH2Kernel) where the plan allows: more than three taps (two chains), and
+        // pairs (A, B = A + 1) whose second window starts d = n0(B) - n0(A) pixels on with  JS <= (d + q - p) / 2 <= JS + 1
+        // for both chain parities p (q = (p - d) & 1), JS one of the instantiated values -- then B's TAPS + 1 slots behind
+        // step JS hold its whole chain in either lane.  Columns that do not pair like that (the few at the clamped edges,
+        // whose windows all start at the first pixel) take a lane pair alone.
+        const int taps_lane = p.h_width <= 16 ? 8 : p.h_width <= 40 ? 20 : 40;
+        const char *h2_env  = getenv("TIMG_HIP_H2");
+        bool h2_ok          = !p.h_sequential && p.out_w >= 2 && !(h2_env && h2_env[0] == '0');
+        auto pair_steps = [&](int a, int *lo, int *hi) {  // first steps of column a + 1 in the two lanes of (a, a + 1)
+            const int d = p.h_taps[a + 1].n0 - p.h_taps[a].n0;
+            *lo = 1 << 30;
+            *hi = -(1 << 30);
+            for (int par = 0; par < 2; ++par) {
+                const int q = ((par - d) % 2 + 2) % 2, js = (d + q - par) / 2;
+                *lo = std::min(*lo, js);
+                *hi = std::max(*hi, js);
+            }
+        };
+        int js = 0;
+        if (h2_ok) {  // the most frequent first step
+            std::map<int, int> votes;
+            for (int a = 0; a + 1 < p.out_w; ++a) {
+                int lo, hi;
+                pair_steps(a, &lo, &hi);
+                if (hi - lo <= 1) ++votes[lo];
+            }
+            int best = 0;
+            for (const auto &kv : votes)
+                if (kv.second > best) best = kv.second, js = kv.first;
+            // (d alternates between two neighbouring values: half the pairs start at js, half at js or js + 1 -- take the
+            // smaller of the two most frequent when they are neighbours)
+            if (votes.count(js - 1) && votes[js - 1] * 4 >= best) js = js - 1;
+            h2_ok = best > 0 && js >= 1 && js < taps_lane && H2Instantiated(taps_lane, js);
         }
+        auto regular = [&](int a) {
+            if (a + 1 >= p.out_w) return false;
+            int lo, hi;
+            pair_steps(a, &lo, &hi);
+            return lo >= js && hi <= js + 1 && p.h_taps[a].count <= 2 * taps_lane && p.h_taps[a + 1].count <= 2 * taps_lane;
+        };
+        std::vector<StripInfo> wide;
+        std::vector<int2> pairs;
+        int wide_win = 0, n_pairs_total = 0, n_single = 0;
+        if (h2_ok) {
+            // strips of at most 32 lane pairs whose windows fit the row buffer; about equally many columns in each
+            const int n_even = (p.out_w + kColsH2 - 1) / kColsH2;
+            const int cols   = ((p.out_w + n_even - 1) / n_even + 1) & ~1;
+            for (int ox = 0; ox < p.out_w && h2_ok;) {
+                StripInfo si;
+                si.ox0  = ox;
+                si.cx0  = p.h_taps[ox].n0 & ~3;
+                si.pad  = 0;
+                int end = ox, reach = si.cx0, used = 0;
+                std::vector<int2> mine;
+                auto fits = [&](int c) { return p.h_taps[c].n0 >= si.cx0 && p.h_taps[c].n0 + p.h_taps[c].count <= si.cx0 + kWinMaxH; };
+                while (end < p.out_w && used < kColsH2 / 2 && end - ox < cols) {
+                    if (p.h_taps[end].count > 2 * taps_lane) h2_ok = false;
+                    if (!fits(end)) break;
+                    int2 e = make_int2(end, -1);
+                    if (regular(end) && fits(end + 1) && end + 1 - ox < cols) e.y = end + 1;
+                    else ++n_single;
+                    for (int c = end; c <= (e.y >= 0 ? e.y : end); ++c) reach = std::max(reach, p.h_taps[c].n0 + p.h_taps[c].count);
+                    mine.push_back(e);
+                    end = (e.y >= 0 ? e.y : end) + 1;
+                    ++used;
+                }
+                if (end == ox) h2_ok = false;
+                si.ox1   = end;
+                wide_win = std::max(wide_win, (reach - si.cx0 + 3) & ~3);
+                mine.resize(kColsH2 / 2, make_int2(-1, -1));
+                pairs.insert(pairs.end(), mine.begin(), mine.end());
+                n_pairs_total += used;
+                wide.push_back(si);
+                ox = end;
+            }
+            // (worth it only where most columns share a lane pair)
+            if (h2_ok && n_single * 8 > p.out_w) h2_ok = false;
+        }
+        if (h2_ok) {
+            // the tables' own strips: the two halves of every wide strip (the second may be empty)
+            for (const StripInfo &w : wide) {
+                const int half = std::min(kColsH, (w.ox1 - w.ox0 + 1) / 2);
+                for (int k = 0; k < 2; ++k) {
+                    StripInfo si;
+                    si.ox0 = k == 0 ? w.ox0 : std::min(w.ox1, w.ox0 + half);
+                    si.ox1 = k == 0 ? std::min(w.ox1, w.ox0 + half) : w.ox1;
+                    si.pad = 0;
+                    si.cx0 = p.h_taps[std::min(si.ox0, p.out_w - 1)].n0 & ~3;
+                    if (si.ox1 - si.ox0 > kColsH) h2_ok = false;  // (cannot happen: a wide strip has at most 64 columns)
+                    int reach = si.cx0;
+                    for (int c = si.ox0; c < si.ox1; ++c) reach = std::max(reach, p.h_taps[c].n0 + p.h_taps[c].count);
+                    if (reach - si.cx0 > kWinMaxH) h2_ok = false;
+                    hwin = std::max(hwin, (reach - si.cx0 + 3) & ~3);
+                    strips.push_back(si);
+                }
+            }
+        }
+        if (!h2_ok) {
+            strips.clear();
+            hwin = 0;
+            wide.clear();
+            pairs.clear();
+            if (!cut(kColsH, &strips, &hwin)) return no("horizontal window wider than the row buffer");
+        }
+        h2_pairs_host = pairs;
+        const int js_lo = js;
+        h2_wide     = wide;
+        h2_wide_win = wide_win;
+        h2_js_min   = js_lo;
     }
     StreamSchedule *ss = new StreamSchedule();
     ss->hfirst = !p.vertical_first;
@@ -1817,7 +2209,7 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     // horizontal-first plan pays every band's vertical halo with a full horizontal pass over the halo's source rows (39
     // rows of 8K per band at 9.6:1): 90 rows -- 4.20 ms per 64 8K frames against 4.44 at 45 (profiles/r5/band_rows_c5.txt;
     // 113 and more leave the 768 workgroup slots of that kernel half empty in the last round).
-    int tall = p.vertical_first ? 45 : 90;
+    int tall = p.vertical_first ? 45 : !h2_wide.empty() ? 75 : 90;  // (two columns a lane pair: half as many, longer tiles -- 75 rows fill the slots better: profiles/r6/h2_kernel.txt)
     if (const char *e = getenv("TIMG_HIP_BAND_ROWS")) tall = atoi(e) > 0 ? atoi(e) : tall;  // tuning
     tall = std::max(1, std::min(p.out_h, tall));
     tall = (p.out_h + (p.out_h + tall - 1) / tall - 1) / ((p.out_h + tall - 1) / tall);  // (equally tall bands)
@@ -1827,13 +2219,31 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     int fine           = tall;
     while (fine > 6 && (size_t)strips.size() * ((p.out_h + fine - 1) / fine) < 512)
         fine = std::max(6, fine / 2);
-    if (!BuildVariant(p, strips, first, last, tall, &ss->v[0]) ||
-        !BuildVariant(p, strips, first, last, fine, &ss->v[1])) {
+    bool uploaded = BuildVariant(p, strips, first, last, tall, &ss->v[0]) && BuildVariant(p, strips, first, last, fine, &ss->v[1]);
+    if (uploaded && !h2_wide.empty()) {
+        const size_t bytes = h2_wide.size() * sizeof(StripInfo);
+        const size_t pbytes = h2_pairs_host.size() * sizeof(int2);
+        uploaded = DevMalloc((void **)&ss->h2_strips, bytes) == hipSuccess &&
+                   hipMemcpy(ss->h2_strips, h2_wide.data(), bytes, hipMemcpyHostToDevice) == hipSuccess &&
+                   DevMalloc((void **)&ss->h2_pairs, pbytes) == hipSuccess &&
+                   hipMemcpy(ss->h2_pairs, h2_pairs_host.data(), pbytes, hipMemcpyHostToDevice) == hipSuccess;
+        ss->h2          = uploaded;
+        ss->h2_n_strips = (int)h2_wide.size();
+        ss->h2_win      = h2_wide_win;
+        ss->h2_js       = h2_js_min;
+    }
+    if (!uploaded) {
         for (auto &v : ss->v)
             if (v.device) (void)DevFree(v.device);
+        if (ss->h2_strips) (void)DevFree(ss->h2_strips);
+        if (ss->h2_pairs) (void)DevFree(ss->h2_pairs);
         delete ss;
         return no("uploading the schedule failed");
     }
+    if (getenv("TIMG_HIP_TRACE_SCHEDULE"))
+        fprintf(stderr, "timg_hip schedule %dx%d -> %dx%d: %s, %zu strips, h2 %d (js %d, %d strips, window %d), hwin %d\n", p.in_w, p.in_h,
+                p.out_w, p.out_h, p.vertical_first ? "vertical-first" : "horizontal-first", strips.size(), (int)ss->h2, ss->h2_js,
+                ss->h2_n_strips, ss->h2_win, ss->hwin);
     s->stream_tables = ss;
     if (const char *e = getenv("TIMG_HIP_NO_MATRIX")) s->stream_cfg[4] = atoi(e) != 0;  // tuning: all-VALU kernels
     s->stream_cfg[0] = ss->v[0].t.n_strips;
@@ -1842,11 +2252,12 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
     return true;
 }
 
-// bit 0: the matrix-core kernel serves this plan, bit 1: with the overflow row compiled in
+// bit 0: the matrix-core kernel serves this plan, bit 1: with the overflow row compiled in, bit 2: a horizontal-first plan
+// served by the kernel with two columns a lane pair (ScaleStreamH2Kernel)
 int StreamShapeBits(const timg_hip_scaler *s) {
     const StreamSchedule *ss = (const StreamSchedule *)s->stream_tables;
     if (!ss) return 0;
-    return (ss->v[0].m_ok ? 1 : 0) | (ss->v[0].m_ovf || ss->v[1].m_ovf ? 2 : 0);
+    return (ss->v[0].m_ok ? 1 : 0) | (ss->v[0].m_ovf || ss->v[1].m_ovf ? 2 : 0) | (ss->h2 ? 4 : 0);
 }
 
 void ReleaseStreamSchedule(timg_hip_scaler *s) {
@@ -1858,6 +2269,8 @@ void ReleaseStreamSchedule(timg_hip_scaler *s) {
         if (kv.second.device) (void)DevFree(kv.second.device);
     for (int *t : ss->tile_state)
         if (t) (void)DevFree(t);
+    if (ss->h2_strips) (void)DevFree(ss->h2_strips);
+    if (ss->h2_pairs) (void)DevFree(ss->h2_pairs);
     delete ss;
     s->stream_tables = nullptr;
 }
@@ -1920,6 +2333,49 @@ static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss
                    : LaunchModeMO<M, false>(s, ss, v, blend, batch, stream);
 }
 
+// which (taps per lane, first step of the second column) ScaleStreamH2Kernel exists for
+// (first steps 2 and 3 -- 17 to 32 taps at ratios 4 to 8 -- compiled into rings whose sets the compiler rotated through
+// copies: check_ring_isa.py refused them; those plans keep the kernel with one column a lane pair)
+static bool H2Instantiated(int taps_lane, int js) { return taps_lane == 20 && js >= 4 && js <= 5; }
+
+template <int M, int TAPS, int JS, int LOADS>
+static hipError_t LaunchModeH2TJL(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                                  const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    // pixels per plane: a quarter of (window + the steps past it), rounded up to 4 mod 16
+    int w4 = (ss->h2_win + 2 * (TAPS + JS + 1) + 3) / 4 + 1;
+    while ((w4 & 15) != 4) ++w4;
+    const size_t lds = (size_t)4 * w4 * 4 * sizeof(float);
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, []() {
+        attr_err = hipFuncSetAttribute((const void *)ScaleStreamH2Kernel<M, TAPS, JS, LOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    StreamTables t = v.t;
+    t.strips       = ss->h2_strips;
+    t.n_strips     = ss->h2_n_strips;
+    const dim3 grid(t.n_strips, t.n_bands, batch.n_frames);
+    hipLaunchKernelGGL((ScaleStreamH2Kernel<M, TAPS, JS, LOADS>), grid, dim3(kThreadsH), lds, stream, s->dev, t, ss->h2_pairs, blend,
+                       batch, ss->tile_state[ss->slot], ss->gen[ss->slot], ss->h2_win, w4);
+    return hipGetLastError();
+}
+template <int M, int TAPS, int JS>
+static hipError_t LaunchModeH2TJ(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                                 const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    const int chunks = (ss->h2_win / 4 + kThreadsH - 1) / kThreadsH;  // 16-byte loads per lane and row
+    if (chunks <= 2) return LaunchModeH2TJL<M, TAPS, JS, 2>(s, ss, v, blend, batch, stream);
+    if (chunks == 3) return LaunchModeH2TJL<M, TAPS, JS, 3>(s, ss, v, blend, batch, stream);
+    return LaunchModeH2TJL<M, TAPS, JS, 4>(s, ss, v, blend, batch, stream);
+}
+template <int M>
+static hipError_t LaunchModeH2(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
+                               const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
+    switch (ss->h2_js) {  // (H2Instantiated)
+    case 4: return LaunchModeH2TJ<M, 20, 4>(s, ss, v, blend, batch, stream);
+    default: return LaunchModeH2TJ<M, 20, 5>(s, ss, v, blend, batch, stream);
+    }
+}
+
 template <int M, int TAPS, int LOADS>
 static hipError_t LaunchModeHTL(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                                 const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
@@ -1936,7 +2392,7 @@ static hipError_t LaunchModeHTL(const timg_hip_scaler *s, const StreamSchedule *
     if (attr_err != hipSuccess) return attr_err;
     const dim3 grid(v.t.n_strips, v.t.n_bands, batch.n_frames);
     hipLaunchKernelGGL((ScaleStreamHKernel<M, TAPS, LOADS>), grid, dim3(kThreadsH), lds, stream, s->dev, v.t, blend,
-                       batch, ss->tile_state[ss->slot], ss->gen[ss->slot], ss->hwin, w4);
+                       batch, ss->tile_state[ss->slot], ss->gen[ss->slot], ss->hwin, w4, ss->h2 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -2029,6 +2485,14 @@ hipError_t LaunchScaleStream(const timg_hip_scaler *s, const DevBlend &blend,
     // cheapest channel set first; tiles whose data breaks its assumption stay
     // open for the next kernel (stream_cfg[3] can skip the optimistic passes)
     const int first_mode = s->stream_cfg[3];
+    if (ss->hfirst && ss->h2) {
+        // two columns per lane pair for the four-channel sets; the seven-channel set on the halves of their strips
+        if (first_mode <= kOpaque && (e = LaunchModeH2<kOpaque>(s, ss, v, blend, batch, stream)) != hipSuccess)
+            return e;
+        if (first_mode <= kPremult && (e = LaunchModeH2<kPremult>(s, ss, v, blend, batch, stream)) != hipSuccess)
+            return e;
+        return LaunchModeH<kFull>(s, ss, v, blend, batch, stream);
+    }
     if (ss->hfirst) {
         if (first_mode <= kOpaque && (e = LaunchModeH<kOpaque>(s, ss, v, blend, batch, stream)) != hipSuccess)
             return e;

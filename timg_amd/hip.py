@@ -144,7 +144,8 @@ class Scaler:
                 "v_filter", "streaming_ok", "max_active_rows"]
         d = dict(zip(keys, list(a)))
         bits = d["streaming_ok"]
-        d.update(streaming_ok=bits & 1, matrix_kernel=(bits >> 1) & 1, matrix_overflow_row=(bits >> 2) & 1)
+        d.update(streaming_ok=bits & 1, matrix_kernel=(bits >> 1) & 1, matrix_overflow_row=(bits >> 2) & 1,
+                 two_column_kernel=(bits >> 3) & 1)
         return d
 
     def set_kernel(self, which: int):

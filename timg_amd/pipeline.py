@@ -81,11 +81,15 @@ class GridPipeline:
     def encode_begin(self, slot: int = 0):
         assert self.can_async()
         if not hasattr(self, "_jobs"):
-            self._jobs = {}
+            self._jobs, self._outs = {}, {}
         if slot not in self._jobs:
             self._jobs[slot] = self.hip.sixel_job(self.n)
+            # every job slot has its OWN output buffer: the header's contract is that `out` stays untouched until the wait
+            # returns, and the next step is enqueued (into the other slot) before this one is waited for -- with one
+            # buffer, finish(k) would have found step k + 1 writing over the bytes it reports
+            self._outs[slot] = self.out if not self._outs else torch.empty_like(self.out)
         self.hip.sixel_encode_async(self._jobs[slot], self.scaled.data_ptr(), self.out_w, self.out_h,
-                                    self.out.data_ptr(), self.cap, n_frames=self.n, pad_blend=self.blend,
+                                    self._outs[slot].data_ptr(), self.cap, n_frames=self.n, pad_blend=self.blend,
                                     stream=self.stream_ptr())
 
     def begin(self, src: torch.Tensor, slot: int = 0):
@@ -94,6 +98,7 @@ class GridPipeline:
 
     def finish(self, slot: int = 0):
         self.lengths = self.hip.sixel_encode_wait(self._jobs[slot], self.n)
+        self.out = self._outs[slot]  # (frame_bytes / packed_output now speak of THIS step: its own buffer, its own counts)
         return self.lengths
 
     def step(self, src: torch.Tensor):
@@ -121,7 +126,7 @@ class GridPipeline:
     def close(self):
         for j in getattr(self, "_jobs", {}).values():
             self.hip.sixel_job_destroy(j)
-        self._jobs = {}
+        self._jobs, self._outs = {}, {}
         self.scaler.close()
 
 

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "gfx_layout.h"
+#include "h2_strips.h"
 #include "resample_plan.h"
 #include "sixel_launch.h"
 
@@ -123,4 +124,31 @@ extern "C" void timg_hip_debug_sixel_launch(int w, int h6, int n_frames, int cu_
     out[10] = (long)timg_amd::kDitherStaticLds;
     out[11] = timg_amd::kDitherMaxWaves;
     out[12] = L.one_trip ? 1 : 0;
+}
+
+// The two-column horizontal-first kernel's tiling of a plan (h2_strips.h; what scale_stream.hip uploads): header[0..5] =
+// ok, taps per lane, first step of the second column, widest window, strips, widest half window; strips[3 * n] (ox0, ox1,
+// cx0), pairs[2 * 32 * n] (a, b), halves[3 * 2 * n].  Returns the number of strips, -1 when the arrays are too small
+// (cap_strips) or the plan is degenerate.  The set of instantiated (taps, step) pairs is scale_stream.hip's.
+extern "C" int timg_hip_debug_h2_tiling(int sw, int sh, int in_fmt, int dw, int dh, int filter, int cap_strips, int *header,
+                                        int *strips, int *pairs, int *halves) {
+    timg_amd::ResamplePlan p;
+    if (!timg_amd::BuildResamplePlan(sw, sh, in_fmt, dw, dh, filter, &p)) return -1;
+    const timg_amd::H2Tiling t = timg_amd::BuildH2Tiling(p, 64, 32, 1024, [](int taps_lane, int js) { return taps_lane == 20 && js >= 4 && js <= 5; });
+    header[0] = t.ok;
+    header[1] = t.taps_lane;
+    header[2] = t.js;
+    header[3] = t.win;
+    header[4] = (int)t.strips.size();
+    header[5] = t.half_win;
+    if (!t.ok) return 0;
+    if ((int)t.strips.size() > cap_strips) return -1;
+    for (size_t i = 0; i < t.strips.size(); ++i) {
+        strips[3 * i] = t.strips[i].ox0, strips[3 * i + 1] = t.strips[i].ox1, strips[3 * i + 2] = t.strips[i].cx0;
+    }
+    for (size_t i = 0; i < t.pairs.size(); ++i) pairs[2 * i] = t.pairs[i].a, pairs[2 * i + 1] = t.pairs[i].b;
+    for (size_t i = 0; i < t.halves.size(); ++i) {
+        halves[3 * i] = t.halves[i].ox0, halves[3 * i + 1] = t.halves[i].ox1, halves[3 * i + 2] = t.halves[i].cx0;
+    }
+    return (int)t.strips.size();
 }

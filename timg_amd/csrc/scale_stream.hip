@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "context.h"
+#include "h2_strips.h"
 #include "pixel_math.h"
 
 namespace timg_amd {
@@ -2091,109 +2092,22 @@ bool PrepareStreamSchedule(timg_hip_scaler *s, std::string *why_not) {
             }
             return true;
         };
-        // Two columns per lane pair (ScaleStreamH2Kernel) where the plan allows: more than three taps (two chains), and
-        // pairs (A, B = A + 1) whose second window starts d = n0(B) - n0(A) pixels on with  JS <= (d + q - p) / 2 <= JS + 1
-        // for both chain parities p (q = (p - d) & 1), JS one of the instantiated values -- then B's TAPS + 1 slots behind
-        // step JS hold its whole chain in either lane.  Columns that do not pair like that (the few at the clamped edges,
-        // whose windows all start at the first pixel) take a lane pair alone.
-        const int taps_lane = p.h_width <= 16 ? 8 : p.h_width <= 40 ? 20 : 40;
+        // Two columns per lane pair (ScaleStreamH2Kernel) where the plan allows: h2_strips.h
         const char *h2_env  = getenv("TIMG_HIP_H2");
-        bool h2_ok          = !p.h_sequential && p.out_w >= 2 && !(h2_env && h2_env[0] == '0');
-        auto pair_steps = [&](int a, int *lo, int *hi) {  // first steps of column a + 1 in the two lanes of (a, a + 1)
-            const int d = p.h_taps[a + 1].n0 - p.h_taps[a].n0;
-            *lo = 1 << 30;
-            *hi = -(1 << 30);
-            for (int par = 0; par < 2; ++par) {
-                const int q = ((par - d) % 2 + 2) % 2, js = (d + q - par) / 2;
-                *lo = std::min(*lo, js);
-                *hi = std::max(*hi, js);
-            }
-        };
-        int js = 0;
-        if (h2_ok) {  // the most frequent first step
-            std::map<int, int> votes;
-            for (int a = 0; a + 1 < p.out_w; ++a) {
-                int lo, hi;
-                pair_steps(a, &lo, &hi);
-                if (hi - lo <= 1) ++votes[lo];
-            }
-            int best = 0;
-            for (const auto &kv : votes)
-                if (kv.second > best) best = kv.second, js = kv.first;
-            // (d alternates between two neighbouring values: half the pairs start at js, half at js or js + 1 -- take the
-            // smaller of the two most frequent when they are neighbours)
-            if (votes.count(js - 1) && votes[js - 1] * 4 >= best) js = js - 1;
-            h2_ok = best > 0 && js >= 1 && js < taps_lane && H2Instantiated(taps_lane, js);
-        }
-        auto regular = [&](int a) {
-            if (a + 1 >= p.out_w) return false;
-            int lo, hi;
-            pair_steps(a, &lo, &hi);
-            return lo >= js && hi <= js + 1 && p.h_taps[a].count <= 2 * taps_lane && p.h_taps[a + 1].count <= 2 * taps_lane;
-        };
+        H2Tiling tiling;
+        if (!(h2_env && h2_env[0] == '0')) tiling = BuildH2Tiling(p, kColsH2, kColsH, kWinMaxH, H2Instantiated);
         std::vector<StripInfo> wide;
         std::vector<int2> pairs;
-        int wide_win = 0, n_pairs_total = 0, n_single = 0;
-        if (h2_ok) {
-            // strips of at most 32 lane pairs whose windows fit the row buffer; about equally many columns in each
-            const int n_even = (p.out_w + kColsH2 - 1) / kColsH2;
-            const int cols   = ((p.out_w + n_even - 1) / n_even + 1) & ~1;
-            for (int ox = 0; ox < p.out_w && h2_ok;) {
-                StripInfo si;
-                si.ox0  = ox;
-                si.cx0  = p.h_taps[ox].n0 & ~3;
-                si.pad  = 0;
-                int end = ox, reach = si.cx0, used = 0;
-                std::vector<int2> mine;
-                auto fits = [&](int c) { return p.h_taps[c].n0 >= si.cx0 && p.h_taps[c].n0 + p.h_taps[c].count <= si.cx0 + kWinMaxH; };
-                while (end < p.out_w && used < kColsH2 / 2 && end - ox < cols) {
-                    if (p.h_taps[end].count > 2 * taps_lane) h2_ok = false;
-                    if (!fits(end)) break;
-                    int2 e = make_int2(end, -1);
-                    if (regular(end) && fits(end + 1) && end + 1 - ox < cols) e.y = end + 1;
-                    else ++n_single;
-                    for (int c = end; c <= (e.y >= 0 ? e.y : end); ++c) reach = std::max(reach, p.h_taps[c].n0 + p.h_taps[c].count);
-                    mine.push_back(e);
-                    end = (e.y >= 0 ? e.y : end) + 1;
-                    ++used;
-                }
-                if (end == ox) h2_ok = false;
-                si.ox1   = end;
-                wide_win = std::max(wide_win, (reach - si.cx0 + 3) & ~3);
-                mine.resize(kColsH2 / 2, make_int2(-1, -1));
-                pairs.insert(pairs.end(), mine.begin(), mine.end());
-                n_pairs_total += used;
-                wide.push_back(si);
-                ox = end;
-            }
-            // (worth it only where most columns share a lane pair)
-            if (h2_ok && n_single * 8 > p.out_w) h2_ok = false;
-        }
-        if (h2_ok) {
-            // the tables' own strips: the two halves of every wide strip (the second may be empty)
-            for (const StripInfo &w : wide) {
-                const int half = std::min(kColsH, (w.ox1 - w.ox0 + 1) / 2);
-                for (int k = 0; k < 2; ++k) {
-                    StripInfo si;
-                    si.ox0 = k == 0 ? w.ox0 : std::min(w.ox1, w.ox0 + half);
-                    si.ox1 = k == 0 ? std::min(w.ox1, w.ox0 + half) : w.ox1;
-                    si.pad = 0;
-                    si.cx0 = p.h_taps[std::min(si.ox0, p.out_w - 1)].n0 & ~3;
-                    if (si.ox1 - si.ox0 > kColsH) h2_ok = false;  // (cannot happen: a wide strip has at most 64 columns)
-                    int reach = si.cx0;
-                    for (int c = si.ox0; c < si.ox1; ++c) reach = std::max(reach, p.h_taps[c].n0 + p.h_taps[c].count);
-                    if (reach - si.cx0 > kWinMaxH) h2_ok = false;
-                    hwin = std::max(hwin, (reach - si.cx0 + 3) & ~3);
-                    strips.push_back(si);
-                }
-            }
-        }
-        if (!h2_ok) {
-            strips.clear();
-            hwin = 0;
-            wide.clear();
-            pairs.clear();
-            if (!cut(kColsH, &strips, &hwin)) return no("horizontal window wider than the row buffer");
+        int wide_win = 0, js = 0;
+        if (tiling.ok) {
+            for (const H2Strip &w : tiling.strips) wide.push_back(StripInfo{w.ox0, w.ox1, w.cx0, 0});
+            for (const H2Pair &e : tiling.pairs) pairs.push_back(make_int2(e.a, e.b));
+            for (const H2Strip &w : tiling.halves) strips.push_back(StripInfo{w.ox0, w.ox1, w.cx0, 0});
+            wide_win = tiling.win;
+            hwin     = tiling.half_win;
+            js       = tiling.js;
+        } else if (!cut(kColsH, &strips, &hwin)) {
+            return no("horizontal window wider than the row buffer");
         }
         h2_pairs_host = pairs;
         const int js_lo = js;

@@ -79,6 +79,24 @@ def test_clobber_on_a_side_path_is_caught(tmp_path):
     assert rc == 1 and "v_mov_b32_e32 v3, 0" in out
 
 
+def test_typed_buffer_loads_are_ring_loads_too(tmp_path):
+    """Round 6 (scratch/experiments/r6_typed_loads.patch): four buffer_load_format_xyzw per source row; a register of a row
+    in flight that the compiler touches is the same bug whatever instruction loads it."""
+    typed_head = HEAD.replace("global_load_dwordx4 v[2:5], v[20:21], off", "buffer_load_format_xyzw v[2:5], v20, s[4:7], s8 offen") \
+                     .replace("global_load_dwordx4 v[6:9], v[20:21], off", "buffer_load_format_xyz v[6:8], v21, s[4:7], s8 offen")
+    step = ("\t;;#ASMSTART\n\ts_waitcnt vmcnt(1) ; ring v[2:5]\n\t;;#ASMEND\n\tv_pk_mul_f32 v[2:3], v[2:3], s[10:11]\n"
+            "\t;;#ASMSTART\n\tbuffer_load_format_xyzw v[2:5], v20, s[4:7], s8 offen\n\t;;#ASMEND\n"
+            "\t;;#ASMSTART\n\ts_waitcnt vmcnt(1) ; ring v[6:8]\n\t;;#ASMEND\n\tv_mul_f32_e32 v6, v6, v31\n"
+            "\t;;#ASMSTART\n\tbuffer_load_format_xyz v[6:8], v21, s[4:7], s8 offen\n\t;;#ASMEND\n")
+    path = tmp_path / "k.s"
+    path.write_text(typed_head + step + TAIL)
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    path.write_text(typed_head + "\tv_min3_f32 v40, v40, v5, v8\n" + step + TAIL)  # alpha looked at before its load has landed
+    r = subprocess.run([sys.executable, CHECK, str(path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "v_min3_f32" in r.stdout, r.stdout
+
+
 def test_loads_without_ring_markers_fail(tmp_path):
     path = tmp_path / "k.s"
     path.write_text(HEAD + "\ts_endpgm\n.Lfunc_end0:\n")
@@ -92,7 +110,8 @@ def test_built_library_passes():
     r = subprocess.run([sys.executable, CHECK, BUILT], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     # 4 instantiations of the matrix kernel + 18 of the horizontal-first kernel (3 channel sets x 3 tap counts x 2 load widths)
-    assert "22 kernels" in r.stdout
+    # + 12 of the two-column kernel (2 channel sets x first steps 4 and 5 x 2 / 3 / 4 loads a row; round 6)
+    assert "34 kernels" in r.stdout
     # ... and the four matrix instantiations write their A operand by v_writelane, four wait states ahead of the first v_mfma
     assert "4 kernels with v_writelane -> v_mfma" in r.stdout
     # the sixel diffusion keeps eight source pixels (and, in its one-trip forms, eight palette indices) in flight the

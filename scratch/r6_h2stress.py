@@ -1,5 +1,5 @@
 """scratch/r6_h2stress.py [seconds] -- random horizontal-first geometries around the two-column kernel's range (ratios 8 to
-10.5, odd widths, windows near the row buffer's bound, frames with opaque / alpha / fully transparent regions, composed and
+10.6 (the range of the two-column kernel: 17 to 40 taps), odd widths, windows near the row buffer's bound, frames with opaque / alpha / fully transparent regions, composed and
 not) against the restatement, byte for byte; counts how many ran on ScaleStreamH2Kernel."""
 import os, sys, time, random
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -14,10 +14,10 @@ n = n_h2 = n_hf = 0
 BG, PAT = (30, 30, 46, 255), (96, 96, 128, 255)
 while time.time() < t_end:
     dw = rng.randint(40, 1100)
-    ratio = rng.uniform(7.9, 10.6)
+    ratio = rng.uniform(4.2, 10.6)
     sw = max(dw + 1, int(dw * ratio) + rng.randint(-3, 3))
     dh = rng.randint(6, 60)
-    sh = int(dh * rng.uniform(8.0, 11.0))
+    sh = max(dh, int(dh * (rng.uniform(8.0, 11.0) if ratio > 8 else rng.uniform(1.0, 12.0))))
     info = oracle.plan_info(sw, sh, dw, dh)
     kind = rng.choice(["photo", "alpha", "mixed"])
     src = synth.photo(sw, sh, seed=n) if kind == "photo" else synth.alpha(sw, sh, seed=n)

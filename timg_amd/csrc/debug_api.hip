@@ -134,7 +134,7 @@ extern "C" int timg_hip_debug_h2_tiling(int sw, int sh, int in_fmt, int dw, int 
                                         int *strips, int *pairs, int *halves) {
     timg_amd::ResamplePlan p;
     if (!timg_amd::BuildResamplePlan(sw, sh, in_fmt, dw, dh, filter, &p)) return -1;
-    const timg_amd::H2Tiling t = timg_amd::BuildH2Tiling(p, 64, 32, 1024, [](int taps_lane, int js) { return taps_lane == 20 && js >= 4 && js <= 5; });
+    const timg_amd::H2Tiling t = timg_amd::BuildH2Tiling(p, 64, 32, 1024, [](int taps_lane, int js) { return taps_lane == 20 && js >= 2 && js <= 5; });
     header[0] = t.ok;
     header[1] = t.taps_lane;
     header[2] = t.js;

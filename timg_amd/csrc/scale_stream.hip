@@ -2248,9 +2248,9 @@ static hipError_t LaunchModeM(const timg_hip_scaler *s, const StreamSchedule *ss
 }
 
 // which (taps per lane, first step of the second column) ScaleStreamH2Kernel exists for
-// (first steps 2 and 3 -- 17 to 32 taps at ratios 4 to 8 -- compiled into rings whose sets the compiler rotated through
-// copies: check_ring_isa.py refused them; those plans keep the kernel with one column a lane pair)
-static bool H2Instantiated(int taps_lane, int js) { return taps_lane == 20 && js >= 4 && js <= 5; }
+// (17 to 40 taps, ratios 4.25 to 10; with THREE rows in flight first steps 2 and 3 compiled into rings whose sets the compiler
+// rotated through copies -- check_ring_isa.py refused them; with two rows in flight every instantiation passes)
+static bool H2Instantiated(int taps_lane, int js) { return taps_lane == 20 && js >= 2 && js <= 5; }
 
 template <int M, int TAPS, int JS, int LOADS>
 static hipError_t LaunchModeH2TJL(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
@@ -2285,6 +2285,8 @@ template <int M>
 static hipError_t LaunchModeH2(const timg_hip_scaler *s, const StreamSchedule *ss, const StreamVariant &v,
                                const DevBlend &blend, const FrameBatch &batch, hipStream_t stream) {
     switch (ss->h2_js) {  // (H2Instantiated)
+    case 2: return LaunchModeH2TJ<M, 20, 2>(s, ss, v, blend, batch, stream);
+    case 3: return LaunchModeH2TJ<M, 20, 3>(s, ss, v, blend, batch, stream);
     case 4: return LaunchModeH2TJ<M, 20, 4>(s, ss, v, blend, batch, stream);
     default: return LaunchModeH2TJ<M, 20, 5>(s, ss, v, blend, batch, stream);
     }

@@ -110,8 +110,8 @@ def test_built_library_passes():
     r = subprocess.run([sys.executable, CHECK, BUILT], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     # 4 instantiations of the matrix kernel + 18 of the horizontal-first kernel (3 channel sets x 3 tap counts x 2 load widths)
-    # + 24 of the two-column kernel (2 channel sets x first steps 2 to 5 x 2 / 3 / 4 loads a row; round 6)
-    assert "46 kernels" in r.stdout
+    # + 24 of the two-column kernel (2 channel sets x first steps 2 to 5 x 2 / 3 / 4 loads a row) + 6 of a 28-tap one-column kernel (round 6)
+    assert "52 kernels" in r.stdout
     # ... and the four matrix instantiations write their A operand by v_writelane, four wait states ahead of the first v_mfma
     assert "4 kernels with v_writelane -> v_mfma" in r.stdout
     # the sixel diffusion keeps eight source pixels (and, in its one-trip forms, eight palette indices) in flight the

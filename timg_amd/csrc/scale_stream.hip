@@ -2328,6 +2328,9 @@ static hipError_t LaunchModeH(const timg_hip_scaler *s, const StreamSchedule *ss
     const int taps = s->plan.h_width;
     if (taps <= 16) return LaunchModeHT<M, 8>(s, ss, v, blend, batch, stream);
     if (taps <= 40) return LaunchModeHT<M, 20>(s, ss, v, blend, batch, stream);
+    // (ratios 10 to 14: 28 weights a lane fit two waves a SIMD without the spills of the 40-tap instantiation; TIMG_HIP_H28=0: comparison)
+    static const bool h28 = !(getenv("TIMG_HIP_H28") && getenv("TIMG_HIP_H28")[0] == '0');
+    if (taps <= 56 && h28) return LaunchModeHT<M, 28>(s, ss, v, blend, batch, stream);
     return LaunchModeHT<M, 40>(s, ss, v, blend, batch, stream);
 }
 

@@ -767,6 +767,42 @@ def test_two_column_horizontal_first_kernel_and_its_fallback(hip, oracle, monkey
         sc2.close()
 
 
+def test_two_column_kernel_on_random_geometries(hip, oracle):
+    """Sixty random horizontal-first geometries over the two-column kernel's whole range (17 to 40 taps: ratios 4.2 to 10.6,
+    first steps 2 to 5, two to four loads a row), odd widths, b,g,r,a sources, frames with opaque / alpha / fully
+    transparent regions, composed and not -- byte for byte against the restatement (the long form of this sweep is
+    scratch/r6_h2stress.py: 1 776 geometries)."""
+    import random
+    rng = random.Random(66)
+    n = on_h2 = 0
+    while n < 60:
+        dw = rng.randint(40, 900)
+        ratio = rng.uniform(4.2, 10.6)
+        sw = max(dw + 1, int(dw * ratio) + rng.randint(-3, 3))
+        dh = rng.randint(6, 40)
+        sh = max(dh, int(dh * (rng.uniform(8.0, 11.0) if ratio > 8 else rng.uniform(1.0, 12.0))))
+        if oracle.plan_info(sw, sh, dw, dh)["vertical_first"]:
+            continue
+        kind = rng.choice(["photo", "alpha", "mixed"])
+        src = synth.photo(sw, sh, seed=n) if kind == "photo" else synth.alpha(sw, sh, seed=n)
+        if kind == "mixed":
+            src[:, : sw // 3] = synth.photo(sw, sh, seed=n + 1000)[:, : sw // 3]
+            src[sh // 4: sh // 2, sw // 2: sw // 2 + sw // 5, 3] = 0
+        fmt = rng.randint(0, 1)
+        sc = hip.scaler(sw, sh, dw, dh, in_fmt=fmt)
+        on_h2 += sc.info()["two_column_kernel"]
+        want = oracle.scale(src, dw, dh, in_fmt=fmt)
+        got = np.empty((dh, dw, 4), np.uint8)
+        blend = None if rng.random() < 0.5 else timg_amd.Blend.make(BG, PAT, rng.randint(1, 20), rng.randint(1, 20))
+        hip.scale_blend(sc, src, got, 1, blend)
+        if blend is not None:
+            want = oracle.alpha_compose(want, BG, PAT, blend.pattern_w, blend.pattern_h)[0]
+        assert np.array_equal(got, want), (sw, sh, dw, dh, kind, fmt, sc.info())
+        sc.close()
+        n += 1
+    assert on_h2 >= 40, on_h2  # (most of them really ran on the two-column kernel)
+
+
 @pytest.mark.parametrize("sw,sh,dw,dh", [(1366, 768, 200, 112), (1366, 768, 455, 256), (999, 1333, 333, 444),
                                          (1023, 767, 341, 255), (6, 1000, 3, 100), (5, 500, 2, 100),  # vertical-first
                                          (1001, 999, 100, 100), (1275, 1650, 150, 194), (2561, 1441, 320, 180),

@@ -231,7 +231,12 @@ def main():
                     help="after the timed region, time the same K steps again on this many concurrent batched "
                          "streams and report it as `batched_streams` (0 = skip; metric configuration only)")
     ap.add_argument("--frames", type=int, default=0, help="override the configuration's frame count")
-    ap.add_argument("--chunk", type=int, default=64, help="frames per batched launch (c4, c5)")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="frames per batched launch (c4, c5).  0 = the fewest equal launches of at most 256 frames: the sixel "
+                         "chain is latency-bound (one frame costs 0.54 ms of kernels, sixty-four 0.80: profiles/r5/"
+                         "chain_by_frames.txt) and with up to 256 frames a call every frame's diffusion still has a CU of "
+                         "its own -- c4 as 3 x 200 frames 11.2 ms a step against 13.8 as 64s, c5 as 1 x 256 17.2 against 19.7 "
+                         "(profiles/r6/chunk_sweep.txt)")
     ap.add_argument("--kind", default="", choices=["", "photo", "noise", "alpha"])
     ap.add_argument("--mode", default="", choices=["", "sixel", "quarter", "half", "kitty", "iterm2", "png"],
                     help="canvas override: sixel, half/quarter blocks, or a graphics protocol at --compress=0")
@@ -439,7 +444,15 @@ def main():
     else:
         mine = list(range(rank * cfg["frames"], (rank + 1) * cfg["frames"]))
     n_mine = len(mine)
-    chunk = n_mine if not strong else max(1, min(args.chunk, (cfg["frames"] + world - 1) // world))
+    if strong:
+        share = (cfg["frames"] + world - 1) // world  # the largest rank's frames
+        if args.chunk > 0:
+            chunk = max(1, min(args.chunk, share))
+        else:
+            launches = (share + 255) // 256
+            chunk = max(1, (share + launches - 1) // launches)
+    else:
+        chunk = n_mine
     pw, ph = (18, 18) if cfg.get("checker") else (0, 0)  # -B pattern: pattern_size * cell px (9 x 18 cells)
     blend = timg_amd.Blend.make(BG, PATTERN if cfg.get("checker") else (0, 0, 0, 0), pw, ph)
 

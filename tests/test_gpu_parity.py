@@ -533,6 +533,26 @@ def test_sixel_diffusion_spread_over_several_cus(hip, oracle, monkeypatch, parts
         assert got == oracle.sixel_encode(fb, BG, lookup_mode=1), (parts, kind, w1, h1)
 
 
+@pytest.mark.parametrize("n", [200, 256, 300])
+def test_sixel_batches_as_long_as_the_chip_has_cus_and_longer(hip, oracle, n):
+    """bench.py cuts BASELINE configs 4 and 5 into the fewest launches of at most 256 frames (round 6: the chain is
+    latency-bound, 3 x 200 frames cost 11.2 ms where ten launches of 64 cost 13.8).  With more than 64 frames a call a
+    frame's diffusion no longer gets four CUs but one (PlanDither: parts capped by CUs / frames, the two-trip lookup
+    beside up to sixteen boundary rows), with more than 256 the workgroups of a launch no longer fit the chip at once:
+    every frame of such a batch is the frame the oracle encodes, and the frame a 64-frame call produced."""
+    w, h, distinct = 800, 450, 7
+    base = np.stack([synth.make(("photo", "alpha")[i % 2], w, h, seed=900 + i) for i in range(distinct)])
+    frames = base[np.arange(n) % distinct]
+    d = hip.upload(np.ascontiguousarray(frames))
+    cap = hip.sixel_max_bytes(w, h)
+    outs = hip.sixel_encode(d, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 9, 9), n_frames=n, out_cap=cap)
+    first = hip.sixel_encode(d, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 9, 9), n_frames=64, out_cap=cap)
+    hip.free(d)
+    want = [oracle.sixel_encode(base[i], BG, PAT, 9, 9, lookup_mode=1) for i in range(distinct)]
+    assert [i for i in range(n) if outs[i] != want[i % distinct]] == []
+    assert first == outs[:64]
+
+
 def test_sixel_diffusion_hand_over_under_uneven_load(hip):
     """The memory hand-over between the parts of a frame, with the chip shared unevenly: three contexts on three host
     threads encode batches of different sizes at the same time (192 + 64 + 7 frames' worth of workgroups queue for 256

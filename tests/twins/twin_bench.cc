@@ -6,7 +6,7 @@
 // already exist: on the device for the twins, in host memory for the reference classes), the main thread
 // presents them in order (PresentImages, src/timg.cc:311-396: canvas, Renderer::Create with the grid,
 // CursorOff / SendFrames / CursorOn per source, sequencer->Flush()), the bytes go through the reference's
-// BufferedWriteSequencer (queue length 4 = src/timg.cc:972, or 2 * columns + 1: what lets the twins hold a
+// BufferedWriteSequencer (queue length 4 = src/timg.cc:972, 2 * columns + 1: what lets the twins hold a
 // whole grid row, held-rows.h) into /dev/null.
 //
 //   GPU path: HipRawRGBASource ("synth:..." frames generated in device memory) -> Renderer ->
@@ -94,12 +94,19 @@ static RunResult RunLikeTimg(const Config &c, bool gpu, size_t queue_len, int lo
     opts.cell_y_px      = c.cell_y_px;
     opts.width_stretch  = c.width_stretch;
     opts.bgcolor_getter = []() { rgba_t bg; bg.r = 0x1e; bg.g = 0x1e; bg.b = 0x2e; bg.a = 255; return bg; };
+    // TWIN_BENCH_TIMELINE in the environment: when (ms after the start) every source was loaded and presented
+    static const bool timeline = getenv("TWIN_BENCH_TIMELINE") != nullptr;
+    std::vector<double> t_loaded(c.sources, 0.0), t_got(c.sources, 0.0), t_sent(c.sources, 0.0);
     const double t0 = Now();
     {
         ThreadPool loaders(loader_threads);
         std::vector<std::future<ImageSource *>> loaded;
         for (int i = 0; i < c.sources; ++i) {
-            const std::function<ImageSource *()> f = [i, &opts, &make_source]() { return make_source(i, opts); };
+            const std::function<ImageSource *()> f = [i, &opts, &make_source, &t_loaded, t0]() {
+                ImageSource *s = make_source(i, opts);
+                t_loaded[i]    = Now() - t0;
+                return s;
+            };
             loaded.push_back(loaders.ExecAsync(f));
         }
         BufferedWriteSequencer seq(fd, false, queue_len, true, intr);
@@ -129,8 +136,10 @@ static RunResult RunLikeTimg(const Config &c, bool gpu, size_t queue_len, int lo
             }
             {
                 auto renderer = Renderer::Create(canvas.get(), opts, c.cols, c.rows, Duration(), Duration());
+                int idx = -1;
                 for (auto &fut : loaded) {
                     std::unique_ptr<ImageSource> source(fut.get());
+                    t_got[++idx] = Now() - t0;
                     if (!source) {
                         fprintf(stderr, "twin_bench: a source could not be created\n");
                         exit(1);
@@ -138,9 +147,18 @@ static RunResult RunLikeTimg(const Config &c, bool gpu, size_t queue_len, int lo
                     canvas->CursorOff();
                     source->SendFrames(Duration::InfiniteFuture(), 1, intr, renderer->render_cb(""));
                     canvas->CursorOn();
+                    t_sent[idx] = Now() - t0;
                     ++res.frames;
                 }
+                const double t_flush = Now() - t0;
                 seq.Flush();
+                if (timeline) {
+                    fprintf(stderr, "timeline %s (ms): loaded", c.name);
+                    for (int i = 0; i < c.sources; ++i) fprintf(stderr, " %.2f", t_loaded[i] * 1e3);
+                    fprintf(stderr, "\ntimeline %s (ms): presented", c.name);
+                    for (int i = 0; i < c.sources; ++i) fprintf(stderr, " %.2f", t_sent[i] * 1e3);
+                    fprintf(stderr, "\ntimeline %s (ms): flush from %.2f to %.2f\n", c.name, t_flush * 1e3, (Now() - t0) * 1e3);
+                }
             }
             canvas.reset();
             compression_pool.reset();
@@ -190,6 +208,7 @@ int main(int argc, char **argv) {
         if (qs.empty()) {
             qs.push_back(4);  // src/timg.cc:972
             if (c.cols > 1) qs.push_back((size_t)(2 * c.cols + 1));             // a grid row per device call
+            if (c.cols > 1) qs.push_back((size_t)(4 * c.cols + 1));             // two rows: what integration/timg-hip.patch sets
             if (c.cols > 1) qs.push_back((size_t)(2 * c.cols * c.rows + 1));    // the whole grid
             if (c.frames_each > 1) qs.push_back(64);  // a stream: frames held per device call = the queue
         }

@@ -75,8 +75,9 @@ std::future<OutBuffer> HeldRows::Hold(int w, int h, const uint8_t *pixels, bool 
         }
         if (pad) open_.pad = *pad;
         if (on_device) {
-            // (on the context's stream: ordered before the encode and before the source's free)
-            if (timg_hip_memcpy_d2d(ctx_, open_.dev_pixels + open_.frames.size() * frame_bytes, pixels, frame_bytes,
+            // (on the copy context's stream, hip-context.h: the worker waits for it before it encodes, the source before
+            // it frees the frame)
+            if (timg_hip_memcpy_d2d(CopyHipContext(), open_.dev_pixels + open_.frames.size() * frame_bytes, pixels, frame_bytes,
                                     nullptr) != TIMG_HIP_OK)
                 abort();
         } else {
@@ -128,13 +129,14 @@ void HeldRows::Work(timg_hip_ctx *worker_ctx) {
         sealed_.pop_front();
         ++busy_;
         l.unlock();
-        // device frames were gathered with copies on the SHARED context's stream (Hold): they have to have
-        // landed before another context's stream reads them
-        if (batch.on_device && worker_ctx != ctx_ && timg_hip_sync(ctx_, nullptr) != TIMG_HIP_OK) abort();
+        // device frames were gathered with copies on the COPY context's stream (Hold): they have to have landed
+        // before this worker's stream reads them
+        if (batch.on_device && timg_hip_sync(CopyHipContext(), nullptr) != TIMG_HIP_OK) abort();
         encode_(batch, worker_ctx);
         if (batch.dev_pixels) {
-            // (the pool hands the block out again at once: this worker's stream must be done with it)
-            if (worker_ctx != ctx_) (void)timg_hip_sync(worker_ctx, nullptr);
+            // (the pool hands the block out again at once -- to a row whose copies run on another stream: this worker's
+            // stream must be done with it)
+            (void)timg_hip_sync(worker_ctx, nullptr);
             HipPoolFree(ctx_, batch.dev_pixels);
         }
         l.lock();

@@ -20,7 +20,8 @@
 // queues a CursorOn), and a full queue blocks the caller (src/buffered-write-sequencer.cc:73-78).
 // HoldLimit() keeps a row's futures plus their CursorOn writes inside the queue; with the
 // reference's queue of 4 (src/timg.cc:972) that is 2 images per device call -- raise the queue
-// length to 2 * columns + 1 for whole rows.
+// length to 2 * columns + 1 for whole rows (integration/timg-hip.patch: 4 * columns + 1, two rows -- one is
+// encoded while the next is gathered).
 #ifndef TIMG_AMD_TWINS_HELD_ROWS_H
 #define TIMG_AMD_TWINS_HELD_ROWS_H
 

@@ -109,6 +109,29 @@ timg_hip_ctx *ExtraHipContext(int k) {
     return extra[k - 1];
 }
 
+namespace {
+std::atomic<timg_hip_ctx *> g_copy_ctx{nullptr};
+}
+
+timg_hip_ctx *CopyHipContext() {
+    // (objects that exist keep working on their contexts after a degrade: not SharedHipContext(), which hides it then)
+    timg_hip_ctx *shared = SharedHipContextEvenIfDegraded();
+    if (!shared) return nullptr;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char *d   = getenv("TIMG_HIP_DEVICE");
+        timg_hip_ctx *c = nullptr;
+        if (timg_hip_init(d ? atoi(d) : 0, &c) == TIMG_HIP_OK) g_copy_ctx.store(c);
+    });
+    timg_hip_ctx *c = g_copy_ctx.load();
+    return c ? c : shared;
+}
+
+void HipFrameCopiesDone() {
+    timg_hip_ctx *c = g_copy_ctx.load();
+    if (c) (void)timg_hip_sync(c, nullptr);
+}
+
 timg_hip_ctx *LoaderHipContext() {
     // Loader threads (src/timg.cc:948-968 runs 3/4 of the cores as loaders) scale frames that live in HOST memory: a
     // call uploads the frame, scales and downloads the result under its context's lock -- on ONE context every loader

@@ -25,6 +25,17 @@ timg_hip_ctx *ExtraHipContext(int k);
 // context's lock.  Falls back to the shared context.
 timg_hip_ctx *LoaderHipContext();
 
+// The context whose stream carries the canvases' device-to-device frame copies (a held grid row gathers the frames of
+// its Sends back to back, an asynchronous sixel Send keeps a copy: the Framebuffer is only valid during the call) and
+// NOTHING else: such a copy is a microsecond of work, and whoever has to know that it has landed -- the worker that
+// encodes the row, the source that frees the frame -- waits for a stream that never holds a 0.8 ms encode.  (Until
+// round 6 the copies went on the shared context's stream, which orders them against everything else on that stream;
+// with the sources loading on contexts of their own that order no longer covers a frame block the pool hands to the
+// next loader.)  Falls back to the shared context.
+timg_hip_ctx *CopyHipContext();
+// Waits until every frame copy enqueued so far has landed (no-op when no copy was ever made).
+void HipFrameCopiesDone();
+
 // GPU selection: TIMG_HIP_DEVICE=<n> (default 0), TIMG_HIP=0 disables.
 bool HipTwinsEnabled();
 // TIMG_HIP_TWIN_TRACE in the environment: the twins say on stderr what they do (the context, every scaler and canvas

@@ -18,7 +18,12 @@ static uint32_t PackColor(rgba_t c) {
 
 HipRawRGBASource::~HipRawRGBASource() {
     if (image_) UnregisterDeviceFrame(image_.get());
-    if (device_frames_) HipPoolFree(ctx_, device_frames_);
+    if (device_frames_) {
+        // (a canvas may have copied a frame of this source a moment ago, on the copy context's stream: the block goes back
+        // to the pool -- to the next loader, on a stream of its own -- only when those copies have landed)
+        HipFrameCopiesDone();
+        HipPoolFree(ctx_, device_frames_);
+    }
 }
 
 ImageSource *HipRawRGBASource::TryCreate(const std::string &filename, const DisplayOptions &options,
@@ -92,6 +97,16 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
     if (!feed.Open(filename())) return false;
     ctx_ = SharedHipContext();
     if (!ctx_) return false;  // no device: the next loader of the chain gets the file
+    // The frames are delivered, cropped, scaled and composed on the LOADER thread's own context (own stream, own
+    // scratch: LoaderHipContext): timg creates its sources on a pool of loader threads (src/timg.cc:948-968), and on
+    // the one shared context their calls queued behind each other's -- 64 sources of a 4K frame were loaded 0.13 ms
+    // apart, 8.3 of the 11.3 ms the whole 8x8 grid took (profiles/r6/twin_timeline.txt); a frame alone fills 40 of the
+    // chip's 1 024 workgroup slots, eight loaders' frames run side by side.  The call below ends with a sync of
+    // that context, so whoever reads the frames later -- a canvas on another context's stream -- finds them complete.
+    timg_hip_ctx *const load_ctx = [&]() {
+        timg_hip_ctx *c = LoaderHipContext();
+        return c ? c : ctx_;
+    }();
 
     orig_width_       = feed.w;
     orig_height_      = feed.h;
@@ -118,12 +133,12 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
     bool any_transparent = false;
     for (int done = 0; ok && done < n; done += chunk) {
         const int m = std::min(chunk, n - done);
-        ok          = feed.Deliver(ctx_, f0 + done, m, src, &staging);
+        ok          = feed.Deliver(load_ctx, f0 + done, m, src, &staging);
         if (ok && done == 0) {
             if (!is_animation && (opts.crop_border > 0 || opts.auto_crop)) {
                 if (opts.auto_crop) {
-                    ok = HipCall(ctx_, [&]() {
-                             return timg_hip_autocrop_bbox(ctx_, src, feed.w, feed.h, 0, 0, 1, 1, std::max(0, opts.crop_border),
+                    ok = HipCall(load_ctx, [&]() {
+                             return timg_hip_autocrop_bbox(load_ctx, src, feed.w, feed.h, 0, 0, 1, 1, std::max(0, opts.crop_border),
                                                            box, nullptr);
                          }) == TIMG_HIP_OK;
                     if (ok && (box[2] <= 0 || box[3] <= 0)) {  // nothing but border: GraphicsMagick's trim() keeps a pixel
@@ -142,15 +157,15 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
             CalcScaleToFitDisplay(box[2], box[3], opts, false, &target_width, &target_height);
             frame_bytes_ = (size_t)target_width * target_height * 4;
             if (ok) {
-                scaler = HipScalerAcquire(ctx_, box[2], box[3], TIMG_HIP_FMT_RGBA, target_width, target_height, HipScalerFilter());
+                scaler = HipScalerAcquire(load_ctx, box[2], box[3], TIMG_HIP_FMT_RGBA, target_width, target_height, HipScalerFilter());
                 device_frames_ = (uint8_t *)HipPoolMalloc(ctx_, frame_bytes_ * n);
                 ok             = scaler != nullptr && device_frames_ != nullptr;
             }
         }
         // -- scale on the device, as src/qoi-image-source.cc:63-68 does on the host: one launch per chunk
         const uint8_t *window = src + (size_t)box[1] * feed.w * 4 + (size_t)box[0] * 4;
-        ok = ok && HipCall(ctx_, [&]() {
-                       return timg_hip_scale_blend(ctx_, scaler, window, feed.w * 4, src_frame, 1,
+        ok = ok && HipCall(load_ctx, [&]() {
+                       return timg_hip_scale_blend(load_ctx, scaler, window, feed.w * 4, src_frame, 1,
                                                    device_frames_ + frame_bytes_ * done, 0, 0, 1, m, nullptr, transparent.data(),
                                                    nullptr);
                    }) == TIMG_HIP_OK;
@@ -166,11 +181,11 @@ bool HipRawRGBASource::LoadAndScale(const DisplayOptions &opts, int frame_offset
         b.pattern_w = opts.pattern_size * opts.cell_x_px;
         b.pattern_h = opts.pattern_size * opts.cell_y_px / 2;
         b.start_row = 0;
-        ok = HipCall(ctx_, [&]() {
-                 return timg_hip_alpha_compose(ctx_, device_frames_, target_width, target_height, 0, 0, 1, n, &b, nullptr, nullptr);
+        ok = HipCall(load_ctx, [&]() {
+                 return timg_hip_alpha_compose(load_ctx, device_frames_, target_width, target_height, 0, 0, 1, n, &b, nullptr, nullptr);
              }) == TIMG_HIP_OK;
     }
-    if (ok) ok = timg_hip_sync(ctx_, nullptr) == TIMG_HIP_OK;
+    if (ok) ok = timg_hip_sync(load_ctx, nullptr) == TIMG_HIP_OK;
     HipScalerRelease(scaler);
     HipPoolFree(ctx_, src);
     if (!ok) return false;

@@ -221,14 +221,15 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
     char *const buffer   = new char[cap];
     char *const offset   = AppendPrefixToBuffer(buffer);  // must happen on this thread
     // The framebuffer is only valid during this call: copy before going async (device frames:
-    // a device-to-device copy on the context's stream, ordered before whatever the source does next).
+    // a device-to-device copy on the copy context's stream; the source waits for that stream before it frees a frame).
     const size_t frame_bytes = (size_t)w * h * 4;
     auto pixels              = std::make_shared<std::vector<uint8_t>>(device ? 0 : frame_bytes);
     uint8_t *device_copy     = nullptr;
     timg_hip_ctx *ctx        = ctx_;
     if (device) {
         device_copy = (uint8_t *)HipPoolMalloc(ctx, frame_bytes);
-        if (!device_copy || timg_hip_memcpy_d2d(ctx, device_copy, device, frame_bytes, nullptr) != TIMG_HIP_OK)
+        // (on the copy context's stream, hip-context.h; the encode job below waits for it)
+        if (!device_copy || timg_hip_memcpy_d2d(CopyHipContext(), device_copy, device, frame_bytes, nullptr) != TIMG_HIP_OK)
             HipFatal(ctx, "HipSixelCanvas::Send");
     } else {
         memcpy(pixels->data(), fb_orig.begin(), frame_bytes);
@@ -240,6 +241,7 @@ void HipSixelCanvas::Send(int x, int dy, const Framebuffer &fb_orig, SeqType seq
         size_t len = 0;
         char *buf  = buffer;
         size_t room = cap;
+        if (device_copy) HipFrameCopiesDone();
         const int rc = HipDegraded() ? TIMG_HIP_ERR_DEVICE : HipCall(ctx, [&]() {
             return timg_hip_sixel_encode(ctx, device_copy ? device_copy : pixels->data(), w, h, 0, 0, device_copy != nullptr,
                                          1, flags, &pad, buf + prefix_len, room - prefix_len, 0, &len, nullptr);

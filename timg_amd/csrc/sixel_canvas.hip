@@ -1284,17 +1284,17 @@ constexpr int kDitherAhead    = 8;  // source pixels are requested this many ste
 // constants.  Changing any of them must move kDitherOverrun (sixel_launch.h) with it: ADVICE r4.
 static_assert(kDitherOverrun >= 2 * (kPairRows - 1) + kDitherAhead + 8 + 7 + 5, "record reads past a row's end must stay inside the slack");
 
-// wave_shr:1 -- every lane receives the value of the lane below it in index
-__device__ __forceinline__ uint32_t FromLaneAbove(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
-}
+// (0x138 below: wave_shr:1 -- every lane receives the value of the lane below it in index)
 
 typedef short PairI16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ PairI16 AsPair(uint32_t u) { return __builtin_bit_cast(PairI16, u); }
 __device__ __forceinline__ uint32_t AsBits(PairI16 v) { return __builtin_bit_cast(uint32_t, v); }
 
-__device__ __forceinline__ uint32_t FromRowAbove(uint32_t v) {  // the same half of the pair one row up
-    return FromLaneAbove(FromLaneAbove(v));
+// the same half of the pair one row up; the two lanes of the wave's first row, which have no row above them in the wave,
+// receive lane 0's `first` (lane 1) and `second` (lane 0)
+__device__ __forceinline__ uint32_t DownOneRow(uint32_t v, uint32_t first, uint32_t second) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)second, (int)t, 0x138, 0xf, 0xf, false);
 }
 __device__ __forceinline__ uint32_t FromPairPartner(uint32_t v) {  // quad_perm [1,0,3,2]
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);
@@ -1579,18 +1579,22 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // (a wave with no row above it finds every column "published": its own counter, against a base far below)
         const int in_base        = follows ? producer_round * n_pub : -(1 << 30);
 
-        // terms of this row's own recent errors (pairs of q << 8):
-        //   own7 = 7/16 of e(x-1)  -> this row's next pixel
-        //   a1   = 3/16 of e(x-1), b2 = 5/16 of e(x-2), c3 = 1/16 of e(x-3) -> the row below
-        uint32_t own7 = 0, a1 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, c3 = 0;
+        // terms of this row's own recent errors: own7 = 7/16 of e(x-1) as a pair of q << 8 -> this row's next pixel.
+        // What goes to the row BELOW travels as the two words of the column's RECORD (w2, w1: the format of the boundary
+        // rows above), moved down one row -- two lanes -- a step after they were packed and unpacked by the receiver, one
+        // v_perm per term: 3/16 from the record that arrived this step (column x + 1 of the row above), 5/16 from the one
+        // before (column x), 1/16 from the one before that (column x - 1).  The wave's first row takes the same words
+        // from the boundary row: lane 0 hands its two reads (and its partner's first word) to the lane moves as the value
+        // of the lanes that have no lane above them, so one instruction stream serves every row.  (Until round 6 the
+        // three terms were moved as three registers, two v_mov_dpp each, the first row chose between them and its
+        // unpacked boundary terms with three v_cndmask, and every term was masked for the add: 16 instructions of a
+        // step for what takes 9.)
+        uint32_t own7 = 0;
+        uint32_t w1p = 0, w2p = 0;                      // the record this row packed a step ago
+        uint32_t s1a = 0, s1b = 0, s2a = 0, s2b = 0;    // the records that arrived one and two steps ago (a: w1, b: w2)
         uint32_t first_q3 = 0;
         uint32_t pk_lo = 0, pk_hi = 0;  // the last eight indices, the newest in pk_hi's top byte
-        // terms from above for the wave's first row: at step t (column t) it adds 1/16 of the error of column t - 1, 5/16
-        // of column t, 3/16 of column t + 1; record t + 2 is unpacked, record t + 3 requested
-        uint32_t up1_a = 0, up1_b = 0, up1_c = 0;  // 1/16 of columns t - 1, t, t + 1
-        uint32_t up5_a = 0, up5_b = 0;             // 5/16 of columns t, t + 1
-        uint32_t up3_a = 0;                        // 3/16 of column t + 1
-        uint32_t n_lo = 0, n_hi = 0;               // the record requested a step ago, still packed
+        uint32_t n_lo = 0, n_hi = 0;    // the boundary record requested a step ago (column t + 1 at step t)
         // The producer's progress counter is read EVERY step, one step before it is looked at (two instructions, no
         // wait: the value has long arrived), so a wave follows its producer as closely as the data allows and the
         // common case -- the producer is far enough -- is a branch that is NOT taken.  (Measured with
@@ -1630,20 +1634,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             n_lo = slot[0];
             n_hi = slot[1];
         };
-        auto unpack = [&](uint32_t &m1, uint32_t &m5, uint32_t &m3) __attribute__((always_inline)) {
-            m1 = __builtin_amdgcn_perm(n_hi, n_lo, sel_u1);
-            m5 = __builtin_amdgcn_perm(n_hi, n_lo, sel_u5);
-            m3 = __builtin_amdgcn_perm(n_hi, n_lo, sel_u3);
-        };
         peek();
-        {
-            uint32_t unused;
-            request(0, in_addr + 12u);
-            unpack(up1_b, up5_a, unused);  // column 0: its 1/16 goes to column 1, its 5/16 to column 0
-            request(1, in_addr + 24u);
-            unpack(up1_c, up5_b, up3_a);   // column 1
-            request(2, in_addr + 36u);     // (unpacked by step 0)
+        request(0, in_addr + 12u);  // column 0 of the row above the wave's first row: "arrived a step ago" at step 0
+        if (rl == 0) {
+            s1a = n_hi;
+            s1b = n_lo;
         }
+        request(1, in_addr + 24u);  // (step 0 hands it to the lane moves)
 
         // Source pixels: unconditional, from clamped addresses, 8 steps ahead, as inline assembly
         // with hand-placed waits.  Left to the compiler, the ring of 8 loads in flight loses its
@@ -1684,21 +1681,28 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // latency covered nothing).
             // the eight indices completed by this block (see idx_q): one store, in the block's last step
             if constexpr (k == 7) {
-                if (!(kDitherAbl & 8) && stores_idx && (unsigned)idx_q < (unsigned)g.idx_stride)
+                if (!(kDitherAbl & (8 | 512)) && stores_idx && (unsigned)idx_q < (unsigned)g.idx_stride)
                     *reinterpret_cast<uint2 *>(s.index + idx_addr) = make_uint2(pk_lo, pk_hi);
             }
-            // the record requested a step ago (column t + 2), and the request for column t + 3
+            // the boundary record requested a step ago (column t + 1), and the request for column t + 2
             const uint32_t q_lo = n_lo, q_hi = n_hi;
             // (the counter is looked at every other step, for two records: half the scalar work of the check ...
             // ... and read only in the step before it is looked at: a read nobody uses still has to land before its
             // register takes the next record)
-            request(t + 3 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 4) * 12u, (k & 1) == 0, (k & 1) != 0);
-            uint32_t up_r = FromRowAbove(a1), up_c = FromRowAbove(b2), up_l = FromRowAbove(c3);
-            if (rl == 0) {
-                up_l = up1_a;
-                up_c = up5_a;
-                up_r = up3_a;
-            }
+            request(t + 2 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 3) * 12u, (k & 1) == 0, (k & 1) != 0);
+            // last step's records, one row down (wave_shr:1 twice; a lane with no lane above it keeps `old`: lane 0 in both
+            // moves -- its own reads the second time, what lane 1 has to end up with the first time)
+            // (the partner's word with bound_ctrl: every lane has a source, no `old` to prepare)
+            const uint32_t q_pt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q_lo, 0xb1, 0xf, 0xf, true);
+            const uint32_t sb   = DownOneRow(w2p, q_pt, q_lo);
+            const uint32_t sa = DownOneRow(w1p, w1p, q_hi);  // (the odd lanes' terms are all in w2)
+            const uint32_t up_r = __builtin_amdgcn_perm(sa, sb, sel_u3);
+            const uint32_t up_c = __builtin_amdgcn_perm(s1a, s1b, sel_u5);
+            const uint32_t up_l = __builtin_amdgcn_perm(s2a, s2b, sel_u1);
+            s2a = s1a;
+            s2b = s1b;
+            s1a = sa;
+            s1b = sb;
             PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_hi) ^ px_bias);  // (px is dead from here: its register takes the next request)
             v = ApplyPair(v, up_l);
             v = ApplyPair(v, up_c);
@@ -1721,11 +1725,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 const uint32_t at = cell + tab_base;
                 const uint32_t t0 = (kDitherAbl & 16) ? at & 0xffu : tab8[at];          // r / b
                 const uint32_t t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
-                if (!(kDitherAbl & 2)) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
+                if (!(kDitherAbl & (2 | 512))) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
+                // (512: what a step would issue if helper waves staged the pixels into LDS and took the cells from it -- one
+                // conflict-free ds_read_b32 and one ds_write_b16 instead of three row-scattered memory instructions)
+                if (kDitherAbl & 512) *(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)(slack + 1024u + 2u * (uint32_t)lane) = (uint16_t)cell;
                 // (the pixel for kDitherAhead steps on is requested HERE, in the shadow of the table reads, with the
                 // unpacking below: ~48 clocks of LDS latency otherwise spent in s_waitcnt)
                 if constexpr (kPix2) {  // (the pair of this step and the one before it is used up: its next request)
                     if constexpr ((k & 1) != 0) *pair = fetch2(t - 1 + kDitherAhead);
+                } else if (kDitherAbl & 512) {
+                    px = *(volatile LdsU32 *)(uintptr_t)(slack + 768u + 4u * (uint32_t)lane);
                 } else if (!(kDitherAbl & 4)) {
                     px = fetch(t + kDitherAhead);
                 }
@@ -1735,12 +1744,6 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 px     = fetch(t + kDitherAhead);
                 p_cell = pal_half[lidx];
             }
-            up1_a = up1_b;
-            up1_b = up1_c;
-            up5_a = up5_b;
-            up1_c = __builtin_amdgcn_perm(q_hi, q_lo, sel_u1);
-            up5_b = __builtin_amdgcn_perm(q_hi, q_lo, sel_u5);
-            up3_a = __builtin_amdgcn_perm(q_hi, q_lo, sel_u3);
             // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
             // zero in lanes that never spread (k_err, c16_mask) and outside the columns 0 .. W - 2 of the row
             const PairU16 p8  = __builtin_bit_cast(PairU16, p_cell);
@@ -1751,11 +1754,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // trunc(err * n / 16) << 8 == (16 * err * n + (err < 0 ? 240 : 0)) & 0xff00: two channels at a time
             const PairI16 k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
             const PairI16 sgn = AsPair(AsBits(err >> 15) & 0x00f000f0u);
+            // (only what is ADDED as it stands needs its low bytes cleared: the records take the high bytes by v_perm)
             const uint32_t m7 = AsBits(err * k7 + sgn) & 0xff00ff00u;
-            const uint32_t m5 = AsBits(err * k5 + sgn) & 0xff00ff00u;
-            const uint32_t m3 = AsBits(err * k3 + sgn) & 0xff00ff00u;
-            const uint32_t m1 = AsBits(err + sgn) & 0xff00ff00u;
-            if constexpr ((k & 1) == 0) first_q3 = x == 0 ? m3 : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
+            const uint32_t m5 = AsBits(err * k5 + sgn);
+            const uint32_t m3 = AsBits(err * k3 + sgn);
+            const uint32_t m1 = AsBits(err + sgn);
+            if constexpr ((k & 1) == 0) first_q3 = x == 0 ? (m3 & 0xff00ff00u) : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
             {  // (all lanes, see rec_lo above; column W: outside the row, a record of zeros)
                 const uint32_t w1 = __builtin_amdgcn_perm(m5, m1, sel_w1);
                 const uint32_t w2 = __builtin_amdgcn_perm(m3, w1, sel_w2);
@@ -1766,18 +1770,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     rec[0] = w2;
                     rec[1] = w1;
                 }
+                w1p = w1;
+                w2p = w2;
                 asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
                 int pv;
                 asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + k), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
                 if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
             }
             own7 = m7;
-            c3   = c2;
-            c2   = c1;
-            c1   = m1;
-            b2   = b1;
-            b1   = m5;
-            a1   = m3;
         };
 
         if constexpr (kPix2) {
@@ -1843,7 +1843,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // the step's own request into the same variable, it was given a second register and copied, in flight, at
         // the back edge (check_ring_isa.py refused the build).
 #define TIMG_DITHER_STEP(k, P, L)                                                             \
-    if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                        \
+    if constexpr (kOneTrip && (kDitherAbl & 512) != 0)                                        \
+        ;                                                                                     \
+    else if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                   \
         asm volatile("v_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     else if constexpr (kOneTrip)                                                              \
         asm volatile("s_waitcnt vmcnt(14) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \

@@ -140,11 +140,31 @@ timg_hip_ctx *LoaderHipContext() {
     // upload runs beside another's kernels.  They are the loaders' OWN contexts, created on demand, one per loader
     // thread that actually shows up (a single-image run creates one, not the five encoder contexts in front of it and
     // itself: ADVICE r4) -- the encoders' contexts (ExtraHipContext) are not touched.
+    //
+    // A thread holds its slot for its lifetime and hands it back when it ends: a process that runs ONE loader at a time
+    // -- a single image; a caller that starts a fresh thread pool per presentation, as tests/twins/twin_bench.cc does per
+    // run -- keeps meeting the same, warm context (numbered by thread birth, every new pool of one thread paid a new
+    // context, its first launch and a scaler plan of its own: one 4K frame 4.3 ms instead of 0.9).
     constexpr int kLoaderContexts = 8;
     static std::mutex mu;
     static timg_hip_ctx *loaders[kLoaderContexts] = {};
-    static std::atomic<int> next{0};
-    thread_local int mine = next.fetch_add(1) % kLoaderContexts;
+    static int users[kLoaderContexts]             = {};
+    struct Slot {
+        int index;
+        Slot() {
+            std::lock_guard<std::mutex> l(mu);
+            index = 0;
+            for (int i = 1; i < kLoaderContexts; ++i)  // (the least used slot, the lowest of them)
+                if (users[i] < users[index]) index = i;
+            ++users[index];
+        }
+        ~Slot() {
+            std::lock_guard<std::mutex> l(mu);
+            --users[index];
+        }
+    };
+    thread_local Slot slot;
+    const int mine       = slot.index;
     timg_hip_ctx *shared = SharedHipContext();
     if (!shared) return nullptr;
     std::lock_guard<std::mutex> l(mu);

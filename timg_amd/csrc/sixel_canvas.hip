@@ -1529,6 +1529,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // (the index rows are padded to a multiple of four and nobody reads the pad)
     // (+ 8: a row's last group of eight indices is completed by up to seven junk ones -- nobody reads the row's padding)
     const int steps          = W + 2 * (kPairRows - 1) + kDitherAhead + 8;
+    // the steady blocks (see step below): t = 64, 72, ... <= W - 16 -- the last row of the wave has begun (t >= 62), the
+    // first has not reached its last column (t + 7 <= W - 2), the pixels requested kDitherAhead steps early exist
+    // (t + 7 + kDitherAhead <= W - 1); rows too short for one: none
+    static_assert(2 * (kPairRows - 1) <= 64 && kDitherAhead == 8, "the steady blocks' range is written for these constants");
+    const bool has_steady    = !kNarrow && W - 16 >= 64;
+    const int t_steady0      = has_steady ? 64 : steps;
+    const int t_steady1      = has_steady ? ((W - 16) / 8) * 8 + 8 : steps;
     bool gave_up             = false;
     for (int round = 0; round * rows_per_round + first_row < H; ++round) {
         const int row      = round * rows_per_round + first_row + rl;
@@ -1574,6 +1581,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         const uint32_t rec_lo    = hands_down ? my_row : slack + 8u * (uint32_t)lane;                      // slot 0 = column -1
         const uint32_t rec_hi    = hands_down ? my_row + 12u * (uint32_t)(W + 2) : slack + 8u * (uint32_t)lane;
         const uint32_t prog_addr = (hands_down && !odd) ? lds0 + 4u * (uint32_t)wave : slack + 512u + 4u * (uint32_t)lane;
+        // (steady blocks: the record's address without the clamp -- the row's own for the pair that hands down, the dummy
+        // slot, which does not advance, for everybody else; a dummy record at + 12 k overlaps other lanes' dummies)
+        uint32_t out_steady      = 0;
+        const uint32_t out_pace  = hands_down ? 96u : 0u;
         int prog_run             = round * n_pub + 1 - 2 * rl;  // (+ t: columns this row has finished, before clamping)
         const int prog_lo = round * n_pub, prog_hi = round * n_pub + n_pub;
         // (a wave with no row above it finds every column "published": its own counter, against a base far below)
@@ -1649,18 +1660,25 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // The loads return in order, so "at most 14 younger operations outstanding" (seven steps' pixel and
         // index requests; 7 in the two-trip form, which requests pixels only) means the oldest pixel -- and the index
         // requested before it -- has arrived (the index stores in between only make the wait more conservative).
-        auto fetch = [&](int t) -> uint32_t {
+        // (inside: the caller knows that the column is inside the row for every lane -- the steady blocks below)
+        auto fetch = [&](int t, auto inside_tag) -> uint32_t {
             uint32_t x;  // the column, clamped into the row (one v_med3: the compiler cannot know 0 <= W - 1)
-            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(t - 2 * rl), "s"(W - 1));
+            if constexpr (decltype(inside_tag)::value)
+                x = (uint32_t)(t - 2 * rl);
+            else
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(t - 2 * rl), "s"(W - 1));
             const uint8_t *p = src_row + (size_t)x * 4;
             uint32_t v;
             asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));
             return v;
         };
         typedef uint32_t PixPair __attribute__((ext_vector_type(2)));
-        auto fetch2 = [&](int t) -> PixPair {  // columns t - 2 * rl (even) and the next one, the pair clamped into the row
+        auto fetch2 = [&](int t, auto inside_tag) -> PixPair {  // columns t - 2 * rl (even) and the next one, the pair clamped into the row
             uint32_t x;
-            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(t - 2 * rl), "s"(W - 2));
+            if constexpr (decltype(inside_tag)::value)
+                x = (uint32_t)(t - 2 * rl);
+            else
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x) : "v"(t - 2 * rl), "s"(W - 2));
             const uint8_t *p = src_row + (size_t)x * 4;
             PixPair v;
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
@@ -1672,8 +1690,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // produces zero terms.  `lidx` receives the step's request for the palette index of its pixel (consumed
         // kDitherAhead steps later, with the wait for that step's pixel).
         // (k: the step's position in the unrolled body -- t - k is a multiple of eight)
-        auto step = [&](int t, uint32_t &px, uint32_t &lidx, auto k_tag, PixPair *pair = nullptr) __attribute__((always_inline)) {
-            constexpr int k = decltype(k_tag)::value;
+        // (steady: a step of a block in which EVERY lane's column is inside 0 .. W - 2 and so are the columns whose pixels
+        // it requests -- blocks 64 <= t <= W - 16, five sixths of an 800-column row.  Nothing of what only the ends of a
+        // row need is in such a step: the column itself, the error's range select, the wrap term and the capture of the
+        // row's first 3/16, the clamps of the pixel, record and progress addresses -- 12 instructions of 59.)
+        auto step = [&](int t, uint32_t &px, uint32_t &lidx, auto k_tag, auto steady_tag, PixPair *pair = nullptr) __attribute__((always_inline)) {
+            constexpr int k       = decltype(k_tag)::value;
+            constexpr bool steady = decltype(steady_tag)::value;
             const int x = t - 2 * rl;
             // What can branch goes first -- the index store and the poll inside request() -- so that everything
             // from the pixel to the error terms is ONE basic block: the table reads and their uses are then
@@ -1710,7 +1733,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
             // the last pixel of a row also receives 3/16 of the row's FIRST error (its "below-left"
             // neighbour in libsixel's linear addressing)
-            if (!kNarrow) {
+            if constexpr (steady) {
+                v = ApplyPair(v, own7);
+            } else if (!kNarrow) {
                 v = ApplyPair(v, wrap);
                 v = ApplyPair(v, own7);
             } else {
@@ -1732,16 +1757,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 // (the pixel for kDitherAhead steps on is requested HERE, in the shadow of the table reads, with the
                 // unpacking below: ~48 clocks of LDS latency otherwise spent in s_waitcnt)
                 if constexpr (kPix2) {  // (the pair of this step and the one before it is used up: its next request)
-                    if constexpr ((k & 1) != 0) *pair = fetch2(t - 1 + kDitherAhead);
+                    if constexpr ((k & 1) != 0) *pair = fetch2(t - 1 + kDitherAhead, steady_tag);
                 } else if (kDitherAbl & 512) {
                     px = *(volatile LdsU32 *)(uintptr_t)(slack + 768u + 4u * (uint32_t)lane);
                 } else if (!(kDitherAbl & 4)) {
-                    px = fetch(t + kDitherAhead);
+                    px = fetch(t + kDitherAhead, steady_tag);
                 }
                 p_cell = t0 | (t1 << 16);
             } else {
                 lidx   = tab8[cell];
-                px     = fetch(t + kDitherAhead);
+                px     = fetch(t + kDitherAhead, steady_tag);
                 p_cell = pal_half[lidx];
             }
             // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
@@ -1750,7 +1775,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);
             const PairI16 e0  = __builtin_bit_cast(PairI16, p8 * __builtin_bit_cast(PairU16, k_err) + c16);
             const PairI16 zero  = {0, 0};
-            const PairI16 err   = (unsigned)x < (unsigned)(W - 1) ? e0 : zero;
+            const PairI16 err   = steady || (unsigned)x < (unsigned)(W - 1) ? e0 : zero;
             // trunc(err * n / 16) << 8 == (16 * err * n + (err < 0 ? 240 : 0)) & 0xff00: two channels at a time
             const PairI16 k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
             const PairI16 sgn = AsPair(AsBits(err >> 15) & 0x00f000f0u);
@@ -1759,12 +1784,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t m5 = AsBits(err * k5 + sgn);
             const uint32_t m3 = AsBits(err * k3 + sgn);
             const uint32_t m1 = AsBits(err + sgn);
-            if constexpr ((k & 1) == 0) first_q3 = x == 0 ? (m3 & 0xff00ff00u) : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
+            if constexpr ((k & 1) == 0 && !steady) first_q3 = x == 0 ? (m3 & 0xff00ff00u) : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
             {  // (all lanes, see rec_lo above; column W: outside the row, a record of zeros)
                 const uint32_t w1 = __builtin_amdgcn_perm(m5, m1, sel_w1);
                 const uint32_t w2 = __builtin_amdgcn_perm(m3, w1, sel_w2);
                 uint32_t at;  // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32)
-                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(out_addr + (uint32_t)k * 12u), "v"(rec_lo), "v"(rec_hi));
+                if constexpr (steady)  // (the pair that hands down is inside its row; the others' dummies may overlap each other)
+                    at = out_steady + (uint32_t)k * 12u;
+                else
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(out_addr + (uint32_t)k * 12u), "v"(rec_lo), "v"(rec_hi));
                 LdsU32 *rec = (LdsU32 *)(uintptr_t)at;
                 if (!(kDitherAbl & 32)) {
                     rec[0] = w2;
@@ -1774,7 +1802,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 w2p = w2;
                 asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
                 int pv;
-                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + k), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
+                if constexpr (steady)
+                    pv = prog_run + k;
+                else
+                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + k), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
                 if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
             }
             own7 = m7;
@@ -1786,36 +1817,45 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // pairs -- 9; odd step k: its index was requested in step k - 8 in front of that step's pair, then 7 indices
             // and 3 pairs -- 11 (its pixel arrived with the pair, a step ago).
             asm volatile("" ::: "memory");
-            PixPair q0 = fetch2(0), q1 = fetch2(2), q2 = fetch2(4), q3 = fetch2(6);
+            PixPair q0 = fetch2(0, std::false_type()), q1 = fetch2(2, std::false_type()), q2 = fetch2(4, std::false_type()),
+                    q3 = fetch2(6, std::false_type());
             uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;
             asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
-#define TIMG_DITHER_STEP_EVEN(k, Q, L)                                                                         \
+#define TIMG_DITHER_STEP_EVEN(k, Q, L, S)                                                                      \
     asm volatile("s_waitcnt vmcnt(9) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(Q), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     {                                                                                                          \
         uint32_t px_k = Q.x;                                                                                   \
-        step(t + k, px_k, L, std::integral_constant<int, k>(), &Q);                                            \
+        step(t + k, px_k, L, std::integral_constant<int, k>(), S(), &Q);                                       \
     }
-#define TIMG_DITHER_STEP_ODD(k, Q, L)                                                                          \
+#define TIMG_DITHER_STEP_ODD(k, Q, L, S)                                                                       \
     asm volatile("s_waitcnt vmcnt(11) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     {                                                                                                          \
         uint32_t px_k = Q.y;                                                                                   \
-        step(t + k, px_k, L, std::integral_constant<int, k>(), &Q);                                            \
+        step(t + k, px_k, L, std::integral_constant<int, k>(), S(), &Q);                                       \
     }
-            for (int t = 0; t < steps; t += 8) {
-                TIMG_DITHER_STEP_EVEN(0, q0, l0)
-                TIMG_DITHER_STEP_ODD(1, q0, l1)
-                TIMG_DITHER_STEP_EVEN(2, q1, l2)
-                TIMG_DITHER_STEP_ODD(3, q1, l3)
-                TIMG_DITHER_STEP_EVEN(4, q2, l4)
-                TIMG_DITHER_STEP_ODD(5, q2, l5)
-                TIMG_DITHER_STEP_EVEN(6, q3, l6)
-                TIMG_DITHER_STEP_ODD(7, q3, l7)
-                in_addr += 96u;
-                out_addr += 96u;
-                prog_run += 8;
-                idx_addr += 8u;
-                idx_q += 8;
-            }
+#define TIMG_DITHER_BLOCK(S)                    \
+    {                                           \
+        TIMG_DITHER_STEP_EVEN(0, q0, l0, S)     \
+        TIMG_DITHER_STEP_ODD(1, q0, l1, S)      \
+        TIMG_DITHER_STEP_EVEN(2, q1, l2, S)     \
+        TIMG_DITHER_STEP_ODD(3, q1, l3, S)      \
+        TIMG_DITHER_STEP_EVEN(4, q2, l4, S)     \
+        TIMG_DITHER_STEP_ODD(5, q2, l5, S)      \
+        TIMG_DITHER_STEP_EVEN(6, q3, l6, S)     \
+        TIMG_DITHER_STEP_ODD(7, q3, l7, S)      \
+        in_addr += 96u;                         \
+        out_addr += 96u;                        \
+        out_steady += out_pace;                 \
+        prog_run += 8;                          \
+        idx_addr += 8u;                         \
+        idx_q += 8;                             \
+    }
+            int t = 0;
+            for (; t < t_steady0; t += 8) TIMG_DITHER_BLOCK(std::false_type)
+            out_steady = hands_down ? out_addr : rec_lo;
+            for (; t < t_steady1; t += 8) TIMG_DITHER_BLOCK(std::true_type)
+            for (; t < steps; t += 8) TIMG_DITHER_BLOCK(std::false_type)
+#undef TIMG_DITHER_BLOCK
             asm volatile("s_waitcnt vmcnt(0) ; ring all"
                          : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4), "+v"(l5),
                            "+v"(l6), "+v"(l7)
@@ -1825,8 +1865,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
 #undef TIMG_DITHER_STEP_ODD
         } else {
         asm volatile("" ::: "memory");
-        uint32_t p0 = fetch(0), p1 = fetch(1), p2 = fetch(2), p3 = fetch(3), p4 = fetch(4), p5 = fetch(5),
-                 p6 = fetch(6), p7 = fetch(7);
+        const std::false_type clamped;
+        uint32_t p0 = fetch(0, clamped), p1 = fetch(1, clamped), p2 = fetch(2, clamped), p3 = fetch(3, clamped), p4 = fetch(4, clamped),
+                 p5 = fetch(5, clamped), p6 = fetch(6, clamped), p7 = fetch(7, clamped);
         uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;  // (nothing in flight yet: not consumed before step 8)
         // "At most 14 younger operations" names the oldest pixel only once the ring is full: with the eight requests of
         // the prologue alone in flight the first seven waits would let their steps through with nothing arrived.  The
@@ -1842,7 +1883,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // the top byte -- INSIDE the wait's asm statement: as a value the compiler could see between its wait and
         // the step's own request into the same variable, it was given a second register and copied, in flight, at
         // the back edge (check_ring_isa.py refused the build).
-#define TIMG_DITHER_STEP(k, P, L)                                                             \
+#define TIMG_DITHER_STEP(k, P, L, S)                                                          \
     if constexpr (kOneTrip && (kDitherAbl & 512) != 0)                                        \
         ;                                                                                     \
     else if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                   \
@@ -1853,22 +1894,31 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
         asm volatile("s_waitcnt vmcnt(7) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
                      : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");                \
-    step(t + k, P, L, std::integral_constant<int, k>());
-        for (int t = 0; t < steps; t += 8) {
-            TIMG_DITHER_STEP(0, p0, l0)
-            TIMG_DITHER_STEP(1, p1, l1)
-            TIMG_DITHER_STEP(2, p2, l2)
-            TIMG_DITHER_STEP(3, p3, l3)
-            TIMG_DITHER_STEP(4, p4, l4)
-            TIMG_DITHER_STEP(5, p5, l5)
-            TIMG_DITHER_STEP(6, p6, l6)
-            TIMG_DITHER_STEP(7, p7, l7)
-            in_addr += 96u;
-            out_addr += 96u;
-            prog_run += 8;
-            idx_addr += 8u;
-                idx_q += 8;
-        }
+    step(t + k, P, L, std::integral_constant<int, k>(), S());
+#define TIMG_DITHER_BLOCK(S)              \
+    {                                     \
+        TIMG_DITHER_STEP(0, p0, l0, S)    \
+        TIMG_DITHER_STEP(1, p1, l1, S)    \
+        TIMG_DITHER_STEP(2, p2, l2, S)    \
+        TIMG_DITHER_STEP(3, p3, l3, S)    \
+        TIMG_DITHER_STEP(4, p4, l4, S)    \
+        TIMG_DITHER_STEP(5, p5, l5, S)    \
+        TIMG_DITHER_STEP(6, p6, l6, S)    \
+        TIMG_DITHER_STEP(7, p7, l7, S)    \
+        in_addr += 96u;                   \
+        out_addr += 96u;                  \
+        out_steady += out_pace;           \
+        prog_run += 8;                    \
+        idx_addr += 8u;                   \
+        idx_q += 8;                       \
+    }
+        int t = 0;
+        for (; t < t_steady0; t += 8) TIMG_DITHER_BLOCK(std::false_type)
+        out_steady = hands_down ? out_addr : rec_lo;
+        if constexpr (!kNarrow)
+            for (; t < t_steady1; t += 8) TIMG_DITHER_BLOCK(std::true_type)
+        for (; t < steps; t += 8) TIMG_DITHER_BLOCK(std::false_type)
+#undef TIMG_DITHER_BLOCK
         // the 16 requests still in flight must land before their registers are used for anything else
         asm volatile("s_waitcnt vmcnt(0) ; ring all"
                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(l0), "+v"(l1),

@@ -1600,9 +1600,16 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // three terms were moved as three registers, two v_mov_dpp each, the first row chose between them and its
         // unpacked boundary terms with three v_cndmask, and every term was masked for the add: 16 instructions of a
         // step for what takes 9.)
+        //
+        // A step's serial chain is: the row above's record of a step ago -> two lane moves -> 3/16 -> pixel value -> cell ->
+        // table bytes (an LDS round trip) -> error -> terms -> record.  Everything else of the NEXT step's pixel value --
+        // the pixel's bytes into the number format, the 1/16 and 5/16 from records that arrived earlier -- is computed a
+        // step ahead (v_pre), in the shadow of the table reads: a wave alone on its SIMD issues in order, so whatever
+        // stands in front of the table reads delays them, and whatever stands behind them is free while they travel.
         uint32_t own7 = 0;
-        uint32_t w1p = 0, w2p = 0;                      // the record this row packed a step ago
-        uint32_t s1a = 0, s1b = 0, s2a = 0, s2b = 0;    // the records that arrived one and two steps ago (a: w1, b: w2)
+        uint32_t w1p = 0, w2p = 0;      // the record this row packed a step ago
+        uint32_t s1a = 0, s1b = 0;      // the record that arrived a step ago (a: w1, b: w2)
+        PairI16 v_pre = {0, 0};         // this step's pixel with the 1/16 and 5/16 from above added
         uint32_t first_q3 = 0;
         uint32_t pk_lo = 0, pk_hi = 0;  // the last eight indices, the newest in pk_hi's top byte
         uint32_t n_lo = 0, n_hi = 0;    // the boundary record requested a step ago (column t + 1 at step t)
@@ -1694,7 +1701,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // it requests -- blocks 64 <= t <= W - 16, five sixths of an 800-column row.  Nothing of what only the ends of a
         // row need is in such a step: the column itself, the error's range select, the wrap term and the capture of the
         // row's first 3/16, the clamps of the pixel, record and progress addresses -- 12 instructions of 59.)
-        auto step = [&](int t, uint32_t &px, uint32_t &lidx, auto k_tag, auto steady_tag, PixPair *pair = nullptr) __attribute__((always_inline)) {
+        // px_next: the NEXT step's pixel (landed: the wait in front of a step is for it); px_slot: the ring register the
+        // step's own request goes to (one pixel a request); pair: the same for pixel pairs (odd steps)
+        auto step = [&](int t, uint32_t px_next, uint32_t &px_slot, uint32_t &lidx, auto k_tag, auto steady_tag, PixPair *pair = nullptr) __attribute__((always_inline)) {
             constexpr int k       = decltype(k_tag)::value;
             constexpr bool steady = decltype(steady_tag)::value;
             const int x = t - 2 * rl;
@@ -1720,16 +1729,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t sb   = DownOneRow(w2p, q_pt, q_lo);
             const uint32_t sa = DownOneRow(w1p, w1p, q_hi);  // (the odd lanes' terms are all in w2)
             const uint32_t up_r = __builtin_amdgcn_perm(sa, sb, sel_u3);
-            const uint32_t up_c = __builtin_amdgcn_perm(s1a, s1b, sel_u5);
-            const uint32_t up_l = __builtin_amdgcn_perm(s2a, s2b, sel_u1);
-            s2a = s1a;
-            s2b = s1b;
-            s1a = sa;
-            s1b = sb;
-            PairI16 v = AsPair(__builtin_amdgcn_perm(px, px, sel_hi) ^ px_bias);  // (px is dead from here: its register takes the next request)
-            v = ApplyPair(v, up_l);
-            v = ApplyPair(v, up_c);
-            v = ApplyPair(v, up_r);
+            PairI16 v = ApplyPair(v_pre, up_r);
             const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
             // the last pixel of a row also receives 3/16 of the row's FIRST error (its "below-left"
             // neighbour in libsixel's linear addressing)
@@ -1745,11 +1745,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t c5   = AsBits(__builtin_bit_cast(PairU16, v) >> 11);  // 5 bits per channel, biased
             const uint32_t part = __builtin_amdgcn_udot2(__builtin_bit_cast(PairU16, c5), __builtin_bit_cast(PairU16, cell_mul), 0u, false);
             const uint32_t cell = part | FromPairPartner(part);  // the biased cell, in both lanes of the pair
+            // 16 * c of 16 * err = 16 * c - 16 * p: c is the high byte of v ^ 0x8000 (zero in lanes that never spread: c16_mask)
+            const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);
             uint32_t p_cell;  // the cell's palette colour as this lane's pair, times 1 (one trip) or 16
+            uint32_t t0 = 0, t1 = 0;
             if constexpr (kOneTrip) {
                 const uint32_t at = cell + tab_base;
-                const uint32_t t0 = (kDitherAbl & 16) ? at & 0xffu : tab8[at];          // r / b
-                const uint32_t t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
+                t0 = (kDitherAbl & 16) ? at & 0xffu : tab8[at];          // r / b
+                t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
                 if (!(kDitherAbl & (2 | 512))) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
                 // (512: what a step would issue if helper waves staged the pixels into LDS and took the cells from it -- one
                 // conflict-free ds_read_b32 and one ds_write_b16 instead of three row-scattered memory instructions)
@@ -1759,20 +1762,35 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 if constexpr (kPix2) {  // (the pair of this step and the one before it is used up: its next request)
                     if constexpr ((k & 1) != 0) *pair = fetch2(t - 1 + kDitherAhead, steady_tag);
                 } else if (kDitherAbl & 512) {
-                    px = *(volatile LdsU32 *)(uintptr_t)(slack + 768u + 4u * (uint32_t)lane);
+                    px_slot = *(volatile LdsU32 *)(uintptr_t)(slack + 768u + 4u * (uint32_t)lane);
                 } else if (!(kDitherAbl & 4)) {
-                    px = fetch(t + kDitherAhead, steady_tag);
+                    px_slot = fetch(t + kDitherAhead, steady_tag);
                 }
-                p_cell = t0 | (t1 << 16);
             } else {
-                lidx   = tab8[cell];
-                px     = fetch(t + kDitherAhead, steady_tag);
-                p_cell = pal_half[lidx];
+                lidx    = tab8[cell];
+                px_slot = fetch(t + kDitherAhead, steady_tag);
+                p_cell  = pal_half[lidx];
             }
+            __builtin_amdgcn_sched_barrier(0);  // (the table reads are on their way: what follows is free)
+            {  // the next step's pixel value as far as it does not depend on this step's error (see v_pre)
+                const uint32_t nx_l = __builtin_amdgcn_perm(s1a, s1b, sel_u1);  // 1/16 of column x of the row above (for x + 1)
+                const uint32_t nx_c = __builtin_amdgcn_perm(sa, sb, sel_u5);    // 5/16 of column x + 1
+                v_pre = AsPair(__builtin_amdgcn_perm(px_next, px_next, sel_hi) ^ px_bias);
+                v_pre = ApplyPair(v_pre, nx_l);
+                v_pre = ApplyPair(v_pre, nx_c);
+                s1a   = sa;
+                s1b   = sb;
+                // (pinned here: as a value with its one use in the next step, the compiler sank the five instructions
+                // into that step's first block -- in front of its table reads -- wherever a step begins with a branch)
+                uint32_t pin = AsBits(v_pre);
+                asm volatile("" : "+v"(pin));
+                v_pre = AsPair(pin);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kOneTrip) p_cell = t0 | (t1 << 16);
             // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
             // zero in lanes that never spread (k_err, c16_mask) and outside the columns 0 .. W - 2 of the row
             const PairU16 p8  = __builtin_bit_cast(PairU16, p_cell);
-            const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);
             const PairI16 e0  = __builtin_bit_cast(PairI16, p8 * __builtin_bit_cast(PairU16, k_err) + c16);
             const PairI16 zero  = {0, 0};
             const PairI16 err   = steady || (unsigned)x < (unsigned)(W - 1) ? e0 : zero;
@@ -1821,28 +1839,28 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     q3 = fetch2(6, std::false_type());
             uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;
             asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
+            v_pre = ApplyPair(AsPair(__builtin_amdgcn_perm(q0.x, q0.x, sel_hi) ^ px_bias), __builtin_amdgcn_perm(s1a, s1b, sel_u5));
+            // A step reads the NEXT step's pixel (v_pre).  Even step k: that is its own pair's second half; the pair landed
+            // before the step in front of it (the wait below names the index alone).  Odd step k: the first half of the
+            // NEXT pair, requested in step k - 6; behind it 5 index requests (steps k - 5 ... k - 1) and 2 pairs (k - 4,
+            // k - 2) -- 7.  The index consumed by the alignbytes was requested in step k - 8, in front of either.
+            uint32_t no_slot = 0;
 #define TIMG_DITHER_STEP_EVEN(k, Q, L, S)                                                                      \
-    asm volatile("s_waitcnt vmcnt(9) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(Q), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
-    {                                                                                                          \
-        uint32_t px_k = Q.x;                                                                                   \
-        step(t + k, px_k, L, std::integral_constant<int, k>(), S(), &Q);                                       \
-    }
-#define TIMG_DITHER_STEP_ODD(k, Q, L, S)                                                                       \
-    asm volatile("s_waitcnt vmcnt(11) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
-    {                                                                                                          \
-        uint32_t px_k = Q.y;                                                                                   \
-        step(t + k, px_k, L, std::integral_constant<int, k>(), S(), &Q);                                       \
-    }
+    asm volatile("s_waitcnt vmcnt(9) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
+    step(t + k, Q.y, no_slot, L, std::integral_constant<int, k>(), S(), &Q);
+#define TIMG_DITHER_STEP_ODD(k, Q, QN, L, S)                                                                   \
+    asm volatile("s_waitcnt vmcnt(7) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(QN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
+    step(t + k, QN.x, no_slot, L, std::integral_constant<int, k>(), S(), &Q);
 #define TIMG_DITHER_BLOCK(S)                    \
     {                                           \
         TIMG_DITHER_STEP_EVEN(0, q0, l0, S)     \
-        TIMG_DITHER_STEP_ODD(1, q0, l1, S)      \
+        TIMG_DITHER_STEP_ODD(1, q0, q1, l1, S)  \
         TIMG_DITHER_STEP_EVEN(2, q1, l2, S)     \
-        TIMG_DITHER_STEP_ODD(3, q1, l3, S)      \
+        TIMG_DITHER_STEP_ODD(3, q1, q2, l3, S)  \
         TIMG_DITHER_STEP_EVEN(4, q2, l4, S)     \
-        TIMG_DITHER_STEP_ODD(5, q2, l5, S)      \
+        TIMG_DITHER_STEP_ODD(5, q2, q3, l5, S)  \
         TIMG_DITHER_STEP_EVEN(6, q3, l6, S)     \
-        TIMG_DITHER_STEP_ODD(7, q3, l7, S)      \
+        TIMG_DITHER_STEP_ODD(7, q3, q0, l7, S)  \
         in_addr += 96u;                         \
         out_addr += 96u;                        \
         out_steady += out_pace;                 \
@@ -1872,39 +1890,41 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // "At most 14 younger operations" names the oldest pixel only once the ring is full: with the eight requests of
         // the prologue alone in flight the first seven waits would let their steps through with nothing arrived.  The
         // first pixels are awaited as a whole (a wave's first step waits a memory round trip either way).
-        if constexpr (kOneTrip)
-            asm volatile("s_waitcnt vmcnt(0) ; ring all"
-                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
-                         :
-                         : "memory");
+        asm volatile("s_waitcnt vmcnt(0) ; ring all"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                     :
+                     : "memory");
+        v_pre = ApplyPair(AsPair(__builtin_amdgcn_perm(p0, p0, sel_hi) ^ px_bias), __builtin_amdgcn_perm(s1a, s1b, sel_u5));
+        // A step reads the NEXT step's pixel (v_pre), requested in step k - 7: behind it the index and pixel requests of
+        // steps k - 6 ... k - 1 -- 12 (two trips, pixels only: 6).
         // (no early exit inside the unrolled body: with one the compiler loses count of the
         // loads in flight; the up to 7 extra steps find every lane out of range)
         // The index that arrived goes into packed_idx -- four per 32-bit store, the newest (pixel x - kDitherAhead) at
         // the top byte -- INSIDE the wait's asm statement: as a value the compiler could see between its wait and
         // the step's own request into the same variable, it was given a second register and copied, in flight, at
         // the back edge (check_ring_isa.py refused the build).
-#define TIMG_DITHER_STEP(k, P, L, S)                                                          \
+#define TIMG_DITHER_STEP(k, P, PN, L, S)                                                      \
     if constexpr (kOneTrip && (kDitherAbl & 512) != 0)                                        \
         ;                                                                                     \
     else if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                   \
-        asm volatile("v_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
+        asm volatile("v_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
     else if constexpr (kOneTrip)                                                              \
-        asm volatile("s_waitcnt vmcnt(14) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
-                     : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");                \
+        asm volatile("s_waitcnt vmcnt(12) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
+                     : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");               \
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
-        asm volatile("s_waitcnt vmcnt(7) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
-                     : "+v"(P), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");                \
-    step(t + k, P, L, std::integral_constant<int, k>(), S());
-#define TIMG_DITHER_BLOCK(S)              \
-    {                                     \
-        TIMG_DITHER_STEP(0, p0, l0, S)    \
-        TIMG_DITHER_STEP(1, p1, l1, S)    \
-        TIMG_DITHER_STEP(2, p2, l2, S)    \
-        TIMG_DITHER_STEP(3, p3, l3, S)    \
-        TIMG_DITHER_STEP(4, p4, l4, S)    \
-        TIMG_DITHER_STEP(5, p5, l5, S)    \
-        TIMG_DITHER_STEP(6, p6, l6, S)    \
-        TIMG_DITHER_STEP(7, p7, l7, S)    \
+        asm volatile("s_waitcnt vmcnt(6) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
+                     : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");               \
+    step(t + k, PN, P, L, std::integral_constant<int, k>(), S());
+#define TIMG_DITHER_BLOCK(S)                  \
+    {                                         \
+        TIMG_DITHER_STEP(0, p0, p1, l0, S)    \
+        TIMG_DITHER_STEP(1, p1, p2, l1, S)    \
+        TIMG_DITHER_STEP(2, p2, p3, l2, S)    \
+        TIMG_DITHER_STEP(3, p3, p4, l3, S)    \
+        TIMG_DITHER_STEP(4, p4, p5, l4, S)    \
+        TIMG_DITHER_STEP(5, p5, p6, l5, S)    \
+        TIMG_DITHER_STEP(6, p6, p7, l6, S)    \
+        TIMG_DITHER_STEP(7, p7, p0, l7, S)    \
         in_addr += 96u;                   \
         out_addr += 96u;                  \
         out_steady += out_pace;           \

@@ -1607,7 +1607,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // step ahead (v_pre), in the shadow of the table reads: a wave alone on its SIMD issues in order, so whatever
         // stands in front of the table reads delays them, and whatever stands behind them is free while they travel.
         uint32_t own7 = 0;
-        uint32_t w1p = 0, w2p = 0;      // the record this row packed a step ago
+        uint32_t w1p = 0, w2p = 0;      // the record this row packed a step ago (stored for the next wave a step late, see below)
+        uint32_t q_pt = 0;              // lane 1's first word of the boundary record in lane 0 (prepared a step ahead)
         uint32_t s1a = 0, s1b = 0;      // the record that arrived a step ago (a: w1, b: w2)
         PairI16 v_pre = {0, 0};         // this step's pixel with the 1/16 and 5/16 from above added
         uint32_t first_q3 = 0;
@@ -1659,6 +1660,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             s1b = n_lo;
         }
         request(1, in_addr + 24u);  // (step 0 hands it to the lane moves)
+        q_pt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_lo, 0xb1, 0xf, 0xf, true);
 
         // Source pixels: unconditional, from clamped addresses, 8 steps ahead, as inline assembly
         // with hand-placed waits.  Left to the compiler, the ring of 8 loads in flight loses its
@@ -1703,7 +1705,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // row's first 3/16, the clamps of the pixel, record and progress addresses -- 12 instructions of 59.)
         // px_next: the NEXT step's pixel (landed: the wait in front of a step is for it); px_slot: the ring register the
         // step's own request goes to (one pixel a request); pair: the same for pixel pairs (odd steps)
-        auto step = [&](int t, uint32_t px_next, uint32_t &px_slot, uint32_t &lidx, auto k_tag, auto steady_tag, PixPair *pair = nullptr) __attribute__((always_inline)) {
+        // next_wait: the ring wait (and index alignbytes) in front of the NEXT step, issued in this step's shadow
+        auto step = [&](int t, uint32_t px_next, uint32_t &px_slot, uint32_t &lidx, auto k_tag, auto steady_tag, PixPair *pair, auto next_wait) __attribute__((always_inline)) {
             constexpr int k       = decltype(k_tag)::value;
             constexpr bool steady = decltype(steady_tag)::value;
             const int x = t - 2 * rl;
@@ -1723,12 +1726,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // register takes the next record)
             request(t + 2 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 3) * 12u, (k & 1) == 0, (k & 1) != 0);
             // last step's records, one row down (wave_shr:1 twice; a lane with no lane above it keeps `old`: lane 0 in both
-            // moves -- its own reads the second time, what lane 1 has to end up with the first time)
-            // (the partner's word with bound_ctrl: every lane has a source, no `old` to prepare)
-            const uint32_t q_pt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q_lo, 0xb1, 0xf, 0xf, true);
+            // moves -- its own reads the second time, what lane 1 has to end up with the first time).  Only w2 is on the
+            // step's chain: the 3/16 of either half of the pair are in it; w1 follows in the shadow of the table reads.
             const uint32_t sb   = DownOneRow(w2p, q_pt, q_lo);
-            const uint32_t sa = DownOneRow(w1p, w1p, q_hi);  // (the odd lanes' terms are all in w2)
-            const uint32_t up_r = __builtin_amdgcn_perm(sa, sb, sel_u3);
+            const uint32_t up_r = __builtin_amdgcn_perm(sb, sb, sel_u3);
             PairI16 v = ApplyPair(v_pre, up_r);
             const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
             // the last pixel of a row also receives 3/16 of the row's FIRST error (its "below-left"
@@ -1772,6 +1773,28 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 p_cell  = pal_half[lidx];
             }
             __builtin_amdgcn_sched_barrier(0);  // (the table reads are on their way: what follows is free)
+            {  // LAST step's record and the counter behind it (all lanes, see rec_lo above; column W: a record of zeros)
+                uint32_t at;  // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32)
+                if constexpr (steady)  // (the pair that hands down is inside its row; the others' dummies may overlap each other)
+                    at = out_steady + (uint32_t)(k - 1) * 12u;
+                else
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(out_addr + (uint32_t)(k - 1) * 12u), "v"(rec_lo), "v"(rec_hi));
+                LdsU32 *rec = (LdsU32 *)(uintptr_t)at;
+                if (!(kDitherAbl & 32)) {
+                    rec[0] = w2p;
+                    rec[1] = w1p;
+                }
+                asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
+                int pv;
+                if constexpr (steady)
+                    pv = prog_run + (k - 1);
+                else
+                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + (k - 1)), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
+                if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
+            }
+            const uint32_t sa = DownOneRow(w1p, w1p, q_hi);  // (the odd lanes' terms are all in w2)
+            q_pt              = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_lo, 0xb1, 0xf, 0xf, true);  // (bound_ctrl: every lane has a source)
+            next_wait();
             {  // the next step's pixel value as far as it does not depend on this step's error (see v_pre)
                 const uint32_t nx_l = __builtin_amdgcn_perm(s1a, s1b, sel_u1);  // 1/16 of column x of the row above (for x + 1)
                 const uint32_t nx_c = __builtin_amdgcn_perm(sa, sb, sel_u5);    // 5/16 of column x + 1
@@ -1803,30 +1826,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             const uint32_t m3 = AsBits(err * k3 + sgn);
             const uint32_t m1 = AsBits(err + sgn);
             if constexpr ((k & 1) == 0 && !steady) first_q3 = x == 0 ? (m3 & 0xff00ff00u) : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
-            {  // (all lanes, see rec_lo above; column W: outside the row, a record of zeros)
-                const uint32_t w1 = __builtin_amdgcn_perm(m5, m1, sel_w1);
-                const uint32_t w2 = __builtin_amdgcn_perm(m3, w1, sel_w2);
-                uint32_t at;  // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32)
-                if constexpr (steady)  // (the pair that hands down is inside its row; the others' dummies may overlap each other)
-                    at = out_steady + (uint32_t)k * 12u;
-                else
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(at) : "v"(out_addr + (uint32_t)k * 12u), "v"(rec_lo), "v"(rec_hi));
-                LdsU32 *rec = (LdsU32 *)(uintptr_t)at;
-                if (!(kDitherAbl & 32)) {
-                    rec[0] = w2;
-                    rec[1] = w1;
-                }
-                w1p = w1;
-                w2p = w2;
-                asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
-                int pv;
-                if constexpr (steady)
-                    pv = prog_run + k;
-                else
-                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + k), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
-                if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
-            }
+            // the column's record: moved down a row by the next step, stored for the next wave in that step's shadow
+            w1p  = __builtin_amdgcn_perm(m5, m1, sel_w1);
+            w2p  = __builtin_amdgcn_perm(m3, w1p, sel_w2);
             own7 = m7;
+            // (pinned like v_pre: used by the next step only, the terms were sunk behind that step's poll branch -- and the
+            // table bytes, crossing a block boundary, came back through a v_and each)
+            asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(own7));
         };
 
         if constexpr (kPix2) {
@@ -1845,22 +1851,26 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // NEXT pair, requested in step k - 6; behind it 5 index requests (steps k - 5 ... k - 1) and 2 pairs (k - 4,
             // k - 2) -- 7.  The index consumed by the alignbytes was requested in step k - 8, in front of either.
             uint32_t no_slot = 0;
-#define TIMG_DITHER_STEP_EVEN(k, Q, L, S)                                                                      \
-    asm volatile("s_waitcnt vmcnt(9) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
-    step(t + k, Q.y, no_slot, L, std::integral_constant<int, k>(), S(), &Q);
-#define TIMG_DITHER_STEP_ODD(k, Q, QN, L, S)                                                                   \
-    asm volatile("s_waitcnt vmcnt(7) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(QN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
-    step(t + k, QN.x, no_slot, L, std::integral_constant<int, k>(), S(), &Q);
-#define TIMG_DITHER_BLOCK(S)                    \
-    {                                           \
-        TIMG_DITHER_STEP_EVEN(0, q0, l0, S)     \
-        TIMG_DITHER_STEP_ODD(1, q0, q1, l1, S)  \
-        TIMG_DITHER_STEP_EVEN(2, q1, l2, S)     \
-        TIMG_DITHER_STEP_ODD(3, q1, q2, l3, S)  \
-        TIMG_DITHER_STEP_EVEN(4, q2, l4, S)     \
-        TIMG_DITHER_STEP_ODD(5, q2, q3, l5, S)  \
-        TIMG_DITHER_STEP_EVEN(6, q3, l6, S)     \
-        TIMG_DITHER_STEP_ODD(7, q3, q0, l7, S)  \
+            // The wait in front of a step -- and the alignbytes that take the index that landed with it -- are issued in the
+            // shadow of the step BEFORE it, behind that step's own requests: the counts are the same.
+#define TIMG_DITHER_WAIT_EVEN(L) \
+    asm volatile("s_waitcnt vmcnt(9) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
+#define TIMG_DITHER_WAIT_ODD(QN, L) \
+    asm volatile("s_waitcnt vmcnt(7) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(QN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
+#define TIMG_DITHER_STEP_EVEN(k, Q, QNN, L, LN, S) /* (the step behind it is odd: it waits for the pair after this one) */ \
+    step(t + k, Q.y, no_slot, L, std::integral_constant<int, k>(), S(), &Q, [&]() __attribute__((always_inline)) { TIMG_DITHER_WAIT_ODD(QNN, LN); });
+#define TIMG_DITHER_STEP_ODD(k, Q, QN, L, LN, S)                                                               \
+    step(t + k, QN.x, no_slot, L, std::integral_constant<int, k>(), S(), &Q, [&]() __attribute__((always_inline)) { TIMG_DITHER_WAIT_EVEN(LN); });
+#define TIMG_DITHER_BLOCK(S)                        \
+    {                                               \
+        TIMG_DITHER_STEP_EVEN(0, q0, q1, l0, l1, S) \
+        TIMG_DITHER_STEP_ODD(1, q0, q1, l1, l2, S)  \
+        TIMG_DITHER_STEP_EVEN(2, q1, q2, l2, l3, S) \
+        TIMG_DITHER_STEP_ODD(3, q1, q2, l3, l4, S)  \
+        TIMG_DITHER_STEP_EVEN(4, q2, q3, l4, l5, S) \
+        TIMG_DITHER_STEP_ODD(5, q2, q3, l5, l6, S)  \
+        TIMG_DITHER_STEP_EVEN(6, q3, q0, l6, l7, S) \
+        TIMG_DITHER_STEP_ODD(7, q3, q0, l7, l0, S)  \
         in_addr += 96u;                         \
         out_addr += 96u;                        \
         out_steady += out_pace;                 \
@@ -1869,11 +1879,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         idx_q += 8;                             \
     }
             int t = 0;
+            TIMG_DITHER_WAIT_EVEN(l0);
             for (; t < t_steady0; t += 8) TIMG_DITHER_BLOCK(std::false_type)
             out_steady = hands_down ? out_addr : rec_lo;
             for (; t < t_steady1; t += 8) TIMG_DITHER_BLOCK(std::true_type)
             for (; t < steps; t += 8) TIMG_DITHER_BLOCK(std::false_type)
 #undef TIMG_DITHER_BLOCK
+#undef TIMG_DITHER_WAIT_EVEN
+#undef TIMG_DITHER_WAIT_ODD
             asm volatile("s_waitcnt vmcnt(0) ; ring all"
                          : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4), "+v"(l5),
                            "+v"(l6), "+v"(l7)
@@ -1903,7 +1916,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // the top byte -- INSIDE the wait's asm statement: as a value the compiler could see between its wait and
         // the step's own request into the same variable, it was given a second register and copied, in flight, at
         // the back edge (check_ring_isa.py refused the build).
-#define TIMG_DITHER_STEP(k, P, PN, L, S)                                                      \
+        // (PN: the pixel of the step the wait stands in front of + 1; L: the index that step's alignbytes take)
+#define TIMG_DITHER_WAIT(PN, L)                                                               \
     if constexpr (kOneTrip && (kDitherAbl & 512) != 0)                                        \
         ;                                                                                     \
     else if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                   \
@@ -1913,18 +1927,19 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                      : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");               \
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
         asm volatile("s_waitcnt vmcnt(6) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
-                     : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");               \
-    step(t + k, PN, P, L, std::integral_constant<int, k>(), S());
-#define TIMG_DITHER_BLOCK(S)                  \
-    {                                         \
-        TIMG_DITHER_STEP(0, p0, p1, l0, S)    \
-        TIMG_DITHER_STEP(1, p1, p2, l1, S)    \
-        TIMG_DITHER_STEP(2, p2, p3, l2, S)    \
-        TIMG_DITHER_STEP(3, p3, p4, l3, S)    \
-        TIMG_DITHER_STEP(4, p4, p5, l4, S)    \
-        TIMG_DITHER_STEP(5, p5, p6, l5, S)    \
-        TIMG_DITHER_STEP(6, p6, p7, l6, S)    \
-        TIMG_DITHER_STEP(7, p7, p0, l7, S)    \
+                     : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");
+#define TIMG_DITHER_STEP(k, P, PN, PNN, L, LN, S) \
+    step(t + k, PN, P, L, std::integral_constant<int, k>(), S(), nullptr, [&]() __attribute__((always_inline)) { TIMG_DITHER_WAIT(PNN, LN) });
+#define TIMG_DITHER_BLOCK(S)                          \
+    {                                                 \
+        TIMG_DITHER_STEP(0, p0, p1, p2, l0, l1, S)    \
+        TIMG_DITHER_STEP(1, p1, p2, p3, l1, l2, S)    \
+        TIMG_DITHER_STEP(2, p2, p3, p4, l2, l3, S)    \
+        TIMG_DITHER_STEP(3, p3, p4, p5, l3, l4, S)    \
+        TIMG_DITHER_STEP(4, p4, p5, p6, l4, l5, S)    \
+        TIMG_DITHER_STEP(5, p5, p6, p7, l5, l6, S)    \
+        TIMG_DITHER_STEP(6, p6, p7, p0, l6, l7, S)    \
+        TIMG_DITHER_STEP(7, p7, p0, p1, l7, l0, S)    \
         in_addr += 96u;                   \
         out_addr += 96u;                  \
         out_steady += out_pace;           \
@@ -1933,12 +1948,14 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         idx_q += 8;                       \
     }
         int t = 0;
+        TIMG_DITHER_WAIT(p1, l0)
         for (; t < t_steady0; t += 8) TIMG_DITHER_BLOCK(std::false_type)
         out_steady = hands_down ? out_addr : rec_lo;
         if constexpr (!kNarrow)
             for (; t < t_steady1; t += 8) TIMG_DITHER_BLOCK(std::true_type)
         for (; t < steps; t += 8) TIMG_DITHER_BLOCK(std::false_type)
 #undef TIMG_DITHER_BLOCK
+#undef TIMG_DITHER_WAIT
         // the 16 requests still in flight must land before their registers are used for anything else
         asm volatile("s_waitcnt vmcnt(0) ; ring all"
                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(l0), "+v"(l1),

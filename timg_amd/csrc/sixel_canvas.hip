@@ -1376,10 +1376,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     uint32_t *pal      = lds + 8192;
     // Boundary rows, one per wave plus one that stays zero (what a wave with no row above it reads).  A row holds one
     // 12-byte RECORD per column of the producer's last row -- the three terms its error sends down -- at slot x + 1:
-    //     bytes 0..3   3/16 as (r, g, 0, 0)            } written by the even lane of the pair as ONE two-word store
+    //     bytes 0..3   3/16 as (0, r, 0, g)            } written by the even lane of the pair as ONE two-word store
     //     bytes 4..7   1/16 as (r, g), 5/16 as (r, g)  }
-    //     bytes 8..11  (1/16, 5/16, 3/16) of b, 0      -- the odd lane's store, whose upper half spills into the next
+    //     bytes 8..11  (0, 3/16, 1/16, 5/16) of b      -- the odd lane's store, whose upper half spills into the next
     //                                                     slot's first word and is overwritten a step later
+    // (A lane's first word is its 3/16 as a TERM WORD -- the one term on a step's serial chain is added as it arrives; the
+    // odd lane's other two terms ride in the half of its pair that carries no channel, where what they add up to is never
+    // looked at.)
     // Slot 0 (column -1) stays zero; column W -- outside the row, all terms zero -- is written like any other, so that
     // what spilled into slot W + 1 is replaced before the consumer's last column reads it: W + 3 slots, and W + 1
     // columns to publish.  The consumer reads one record per step (column c needs 1/16 of c - 1, 5/16 of c, 3/16 of
@@ -1517,10 +1520,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     // bytes and the 3/16 -- the finished word]; the 8-byte store takes (w2, w1).  Unpacking, one v_perm per term
     // from the 8 bytes read (v_perm_b32(hi, lo, .): bytes 0-3 of the selector's index space are lo, 4-7 hi).
     const uint32_t sel_w1 = odd ? 0x0c0c0501u : 0x07050301u;
-    const uint32_t sel_w2 = odd ? 0x0c050100u : 0x0c0c0705u;
-    const uint32_t sel_u1 = odd ? 0x0c0c000cu : 0x050c040cu;
-    const uint32_t sel_u5 = odd ? 0x0c0c010cu : 0x070c060cu;
-    const uint32_t sel_u3 = odd ? 0x0c0c020cu : 0x010c000cu;
+    const uint32_t sel_w2 = odd ? 0x0100050cu : 0x070c050cu;  // (the 3/16 as a term word; odd: 1/16 and 5/16 of b in the unused half)
+    const uint32_t sel_u1 = odd ? 0x0c0c020cu : 0x050c040cu;
+    const uint32_t sel_u5 = odd ? 0x0c0c030cu : 0x070c060cu;
 
     const int rows_per_round = (kSplit ? n_all : n_waves) * kPairRows;  // (kSplit: one round)
     const int first_row      = (group0 + wave - lw0) * kPairRows;
@@ -1729,8 +1731,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // moves -- its own reads the second time, what lane 1 has to end up with the first time).  Only w2 is on the
             // step's chain: the 3/16 of either half of the pair are in it; w1 follows in the shadow of the table reads.
             const uint32_t sb   = DownOneRow(w2p, q_pt, q_lo);
-            const uint32_t up_r = __builtin_amdgcn_perm(sb, sb, sel_u3);
-            PairI16 v = ApplyPair(v_pre, up_r);
+            PairI16 v = ApplyPair(v_pre, sb);  // (3/16 of column x + 1 of the row above: the record's first word as it is)
             const uint32_t wrap = x == W - 1 ? first_q3 : 0u;
             // the last pixel of a row also receives 3/16 of the row's FIRST error (its "below-left"
             // neighbour in libsixel's linear addressing)
@@ -1832,7 +1833,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             own7 = m7;
             // (pinned like v_pre: used by the next step only, the terms were sunk behind that step's poll branch -- and the
             // table bytes, crossing a block boundary, came back through a v_and each)
-            asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(own7));
+            // (not the 7/16: its two instructions find room between the next step's lane moves)
+            asm volatile("" : "+v"(w1p), "+v"(w2p));
         };
 
         if constexpr (kPix2) {

@@ -1442,6 +1442,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const int zero_row = n_local > 1 ? n_local : 0;
     for (int i = tid; i < (zero_row + 1) * brow; i += blockDim.x) boundary[i] = 0u;
     if (tid < n_local) progress[tid] = 0;
+    if (tid < kDitherMaxWaves)  // the waves' spin counts (wait_for below): in the slack behind the rows, past the lanes' dummy stores
+        boundary[(zero_row + 1) * brow + 192 + tid] = 0u;
     const bool dither = s.meta[1] != 0;
     __syncthreads();
 
@@ -1538,7 +1540,6 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     const bool has_steady    = !kNarrow && W - 16 >= 64;
     const int t_steady0      = has_steady ? 64 : steps;
     const int t_steady1      = has_steady ? ((W - 16) / 8) * 8 + 8 : steps;
-    bool gave_up             = false;
     for (int round = 0; round * rows_per_round + first_row < H; ++round) {
         const int row      = round * rows_per_round + first_row + rl;
         const bool has_row = row < H;
@@ -1622,24 +1623,33 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // scratch/ubench/wave_latency.hip: a wave alone on its SIMD issues one instruction of any kind per 4 clocks,
         // dependent or not, but a TAKEN branch costs ~80; the previous form polled in batches of four columns behind
         // a taken branch per step: ~80 clocks a step for the branch and ~50 a step for the polls, of ~600.)
-        int spins = 0;
+        // The check itself is one scalar add, a compare and the branch: the value the counter must have reached is kept
+        // running (lim_run, + 8 a block), and the path that waits keeps NO state in registers -- its spin count lives in
+        // an LDS word of the wave's own, it reports a give-up where it happens.  (With a spin count and a flag carried
+        // through the steps the compiler put their copies -- three scalar moves -- on the path that does not wait, and
+        // computed the threshold from the column with a min every time: 8 scalar instructions a check, of a step's 55.)
         uint32_t prog_raw = 0;
+        int lim_run       = in_base + 4;               // (+ t + k: published columns before record t + k + 3 is requested)
+        const int lim_cap = in_base + n_pub;           // (a row publishes no more)
+        LdsU32 *const spun = (LdsU32 *)(uintptr_t)(slack + 768u + 4u * (uint32_t)wave);
         auto peek = [&]() __attribute__((always_inline)) {
             prog_raw = (uint32_t)__hip_atomic_load(&progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        auto wait_for = [&](int need) __attribute__((always_inline)) {
+        auto wait_for = [&](int lim) __attribute__((always_inline)) {
             if (kDitherAbl & 1) return;
-            int avail = __builtin_amdgcn_readfirstlane((int)prog_raw) - in_base;
-            if (__builtin_expect(avail < need, 0)) {
-                do {
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)prog_raw) < lim, 0)) {
+                for (;;) {
                     __builtin_amdgcn_s_sleep(1);
-                    avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                                &progress[producer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - in_base;
-                    if (++spins > kDitherSpinLimit) {  // never on a healthy run: give up (reported below), do not hang
-                        gave_up = true;
+                    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&progress[producer], __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_WORKGROUP)) >= lim)
+                        break;
+                    const uint32_t n = *(volatile LdsU32 *)spun + 1u;
+                    *(volatile LdsU32 *)spun = n;
+                    if (n > (uint32_t)kDitherSpinLimit) {  // never on a healthy run: give up and say so, do not hang
+                        if (lane == 0) __hip_atomic_store(b.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
-                } while (avail < need);
+                }
             }
             asm volatile("" ::: "memory");
         };
@@ -1647,8 +1657,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // requested one step before it is unpacked.  (The slot is not clamped to the row: past its end the slots of the
         // following row -- or the slack behind the last one, sixel_launch.h -- are read, for lanes that are outside
         // their rows by then.)
-        auto request = [&](int x_rec, uint32_t slot_addr, bool check = true, bool look = true) __attribute__((always_inline)) {
-            if (check) wait_for(min(x_rec + 1, n_pub));
+        auto request = [&](int lim, uint32_t slot_addr, bool check = true, bool look = true) __attribute__((always_inline)) {
+            if (check) wait_for(lim);
             if (kDitherAbl & 64) return;
             if (look) peek();
             const LdsU32 *slot = (const LdsU32 *)(uintptr_t)slot_addr;  // = this half's part of slot x_rec + 1
@@ -1656,12 +1666,12 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             n_hi = slot[1];
         };
         peek();
-        request(0, in_addr + 12u);  // column 0 of the row above the wave's first row: "arrived a step ago" at step 0
+        request(in_base + 1, in_addr + 12u);  // column 0 of the row above the wave's first row: "arrived a step ago" at step 0
         if (rl == 0) {
             s1a = n_hi;
             s1b = n_lo;
         }
-        request(1, in_addr + 24u);  // (step 0 hands it to the lane moves)
+        request(in_base + 2, in_addr + 24u);  // (step 0 hands it to the lane moves)
         q_pt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_lo, 0xb1, 0xf, 0xf, true);
 
         // Source pixels: unconditional, from clamped addresses, 8 steps ahead, as inline assembly
@@ -1726,7 +1736,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // (the counter is looked at every other step, for two records: half the scalar work of the check ...
             // ... and read only in the step before it is looked at: a read nobody uses still has to land before its
             // register takes the next record)
-            request(t + 2 + ((k & 1) == 0 ? 1 : 0), in_addr + (uint32_t)(k + 3) * 12u, (k & 1) == 0, (k & 1) != 0);
+            // (steady blocks end sixteen columns before the row does: no cap)
+            request(steady ? lim_run + k : min(lim_run + k, lim_cap), in_addr + (uint32_t)(k + 3) * 12u, (k & 1) == 0, (k & 1) != 0);
             // last step's records, one row down (wave_shr:1 twice; a lane with no lane above it keeps `old`: lane 0 in both
             // moves -- its own reads the second time, what lane 1 has to end up with the first time).  Only w2 is on the
             // step's chain: the 3/16 of either half of the pair are in it; w1 follows in the shadow of the table reads.
@@ -1876,6 +1887,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         in_addr += 96u;                         \
         out_addr += 96u;                        \
         out_steady += out_pace;                 \
+        lim_run += 8;                           \
         prog_run += 8;                          \
         idx_addr += 8u;                         \
         idx_q += 8;                             \
@@ -1945,6 +1957,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         in_addr += 96u;                   \
         out_addr += 96u;                  \
         out_steady += out_pace;           \
+        lim_run += 8;                     \
         prog_run += 8;                    \
         idx_addr += 8u;                   \
         idx_q += 8;                       \
@@ -1967,9 +1980,6 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
 #undef TIMG_DITHER_STEP
         }
     }
-    // (outside the loops: a memory operation inside the poll loop would cost the compiler its
-    // count of the prefetches in flight)
-    if (gave_up && lane == 0) atomicExch(b.error, 1);
 }
 
 // (libtimg_hip_debug.so only -- csrc/Makefile compiles this file a second time with TIMG_SIXEL_FIRST_HIT_BUILD: the

@@ -101,6 +101,13 @@ struct SixelBatch {
     char *out;
     size_t out_cap;
     unsigned long long *out_len;
+    // One group of frames (the default): the step's first kernel clears the error word and its last one writes the
+    // frames' byte counts and the error word straight into the caller's PINNED words -- no memset in front of the chain,
+    // no copy behind it (two launches of ~4 us and their gaps, 1.3 % of a 64-frame step).  Null / 0: hipMemsetAsync and
+    // hipMemcpyAsync as before (several groups on side streams: a group's kernels must not clear or report for another's).
+    int clears_error;
+    unsigned long long *len_host;  // [frames] mirror of out_len (this group's first frame at 0)
+    unsigned long long *err_host;  // [1]
 };
 
 __device__ __forceinline__ uint32_t IndexRow(const SixelGeom &g, int row) {  // byte offset of pixel 0 of `row`
@@ -177,6 +184,7 @@ __global__ void __launch_bounds__(kHistThreads) HistKernel(SixelGeom g, SixelBat
     const SixelFrameScratch s = FrameScratch(b, g, f);
     const uint8_t *frame      = b.fb + (size_t)f * g.frame_stride;
 
+    if (b.clears_error && f == 0 && tid == 0) *b.error = 0;  // (only the diffusion, three kernels on, ever sets it)
     for (int i = tid; i < 32768; i += kHistThreads) hist_lds[i] = 0xffffffffu;
     // the thread's samples k = tid, tid + 1024, ...: all loads in flight together, hashes
     // kept in registers for the passes below; (x, y) advance without divisions
@@ -3028,6 +3036,10 @@ __global__ void __launch_bounds__(256) AssembleBandsKernel(SixelGeom g, SixelBat
             StoreChar(out, b.out_cap, end + 1, '\\');
             StoreChar(out, b.out_cap, end + 2, g.broken_cursor ? '\n' : '\r');
             b.out_len[f] = (unsigned long long)end + 3ull;
+            if (b.len_host) {  // (pinned host words: visible to the host once the stream has passed this kernel)
+                b.len_host[f] = (unsigned long long)end + 3ull;
+                if (f == 0) *b.err_host = (unsigned long long)(unsigned)*b.error;
+            }
         }
     }
     __syncthreads();
@@ -3296,12 +3308,27 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     // ~1.8 ms of cross-queue event hand-over per 64-frame batch (1 group 2.8 ms, 2 groups
     // 4.7 ms, 4 groups 6.3 ms), far more than the overlap wins -- so the default is ONE
     // group; TIMG_HIP_SIXEL_GROUPS keeps the experiment reproducible.
-    TIMG_HIP_TRY(ctx, hipMemsetAsync(b.error, 0, sizeof(unsigned long long), st));
     int n_groups = pieces_req > 0 ? pieces_req : 1;
     if (pieces_req <= 0)
         if (const char *e = getenv("TIMG_HIP_SIXEL_GROUPS"))  // tuning
             n_groups = atoi(e);
     n_groups = std::max(1, std::min(n_groups, std::min(n_frames, (int)timg_hip_ctx::kSideStreams)));
+    // the words the byte counts and the error word end up in: the job's, or the context's (both pinned)
+    unsigned long long *len_h = nullptr;
+    if (job) {
+        len_h = job->len_h;
+    } else {
+        TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * (nf + 1)));
+        len_h = (unsigned long long *)ctx->pin[0].ptr;
+    }
+    const bool direct = n_groups == 1 && !getenv("TIMG_HIP_SIXEL_COPY_LENGTHS");  // (the switch: the old form, for comparison)
+    b.clears_error    = direct ? 1 : 0;
+    b.len_host        = direct ? len_h : nullptr;
+    b.err_host        = direct ? len_h + nf : nullptr;
+    if (direct)
+        len_h[nf] = 0;  // (nothing of an earlier call is in flight towards these words: a job is not pending, a blocking call has returned)
+    else
+        TIMG_HIP_TRY(ctx, hipMemsetAsync(b.error, 0, sizeof(unsigned long long), st));
     if (n_groups > 1 || hook_ms) TIMG_HIP_TRY(ctx, ctx->EnsureSideStreams());
     if (n_groups > 1) TIMG_HIP_TRY(ctx, hipEventRecord(ctx->fork_event, st));
     for (int grp = 0; grp < n_groups; ++grp) {
@@ -3341,6 +3368,7 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         gb.xwg         = b.xwg + o * (kDitherMaxParts - 1) * XwgStride(w);
         gb.out         = b.out + o * b.out_cap;
         gb.out_len     = b.out_len + o;
+        gb.len_host    = b.len_host ? b.len_host + o : nullptr;
 
         if (before_piece) {
             if (hook_ms) TIMG_HIP_TRY(ctx, hipEventRecord(ctx->hook_event[2 * grp], gs));
@@ -3382,7 +3410,8 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         // the asynchronous form: the frames' byte counts (and the device's error word) go to the JOB's pinned words
         // behind an event on the caller's stream; nothing is waited for -- the caller may enqueue its next batch (the
         // scratch is reused in stream order; the counts above were copied out before the next call's kernels run)
-        TIMG_HIP_TRY(ctx, hipMemcpyAsync(job->len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
+        if (!direct)
+            TIMG_HIP_TRY(ctx, hipMemcpyAsync(job->len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
         TIMG_HIP_TRY(ctx, hipEventRecord(job->done, st));
         if (!ctx->sixel_done) TIMG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->sixel_done, hipEventDisableTiming));
         TIMG_HIP_TRY(ctx, hipEventRecord(ctx->sixel_done, st));  // (the context's own event: the job may be destroyed first)
@@ -3394,10 +3423,8 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         return TIMG_HIP_OK;
     }
 
-    TIMG_HIP_TRY(ctx, ctx->pin[0].Reserve(sizeof(unsigned long long) * (nf + 1)));
-    unsigned long long *len_h = (unsigned long long *)ctx->pin[0].ptr;
-    TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * (nf + 1),
-                                     hipMemcpyDeviceToHost, st));
+    if (!direct)
+        TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     ctx->sixel_in_flight = false;  // (this call waited behind whatever was in flight, and has finished itself)
     if ((int)len_h[nf] != 0)

@@ -1322,6 +1322,15 @@ constexpr int kDitherSpinLimit = 1 << 22;
 #define TIMG_DITHER_ABL 0
 #endif
 constexpr int kDitherAbl = TIMG_DITHER_ABL;
+// (timing experiment: -DTIMG_DITHER_NOWAIT lets the pixel-pair kernels' steps through without waiting for their pixels -- garbage out;
+// what the waits cost, if anything)
+#ifdef TIMG_DITHER_NOWAIT
+#define TIMG_DITHER_VMCNT_EVEN "63"
+#define TIMG_DITHER_VMCNT_ODD "63"
+#else
+#define TIMG_DITHER_VMCNT_EVEN "9"
+#define TIMG_DITHER_VMCNT_ODD "7"
+#endif
 // The helper waves (flusher, fetcher) share their SIMDs with diffusing waves: what they issue, the diffusion does not
 // (every row waits for the one above it: the slowest wave sets the pace).  Polling every 128 clocks and moving a
 // boundary row column by column they cost a 64-frame batch 4 % (profiles/r4/dither_ablation.txt); they nap
@@ -1875,9 +1884,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // The wait in front of a step -- and the alignbytes that take the index that landed with it -- are issued in the
             // shadow of the step BEFORE it, behind that step's own requests: the counts are the same.
 #define TIMG_DITHER_WAIT_EVEN(L) \
-    asm volatile("s_waitcnt vmcnt(9) ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
+    asm volatile("s_waitcnt vmcnt(" TIMG_DITHER_VMCNT_EVEN ") ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
 #define TIMG_DITHER_WAIT_ODD(QN, L) \
-    asm volatile("s_waitcnt vmcnt(7) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(QN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
+    asm volatile("s_waitcnt vmcnt(" TIMG_DITHER_VMCNT_ODD ") ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(QN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
 #define TIMG_DITHER_STEP_EVEN(k, Q, QNN, L, LN, S) /* (the step behind it is odd: it waits for the pair after this one) */ \
     step(t + k, Q.y, no_slot, L, std::integral_constant<int, k>(), S(), &Q, [&]() __attribute__((always_inline)) { TIMG_DITHER_WAIT_ODD(QNN, LN); });
 #define TIMG_DITHER_STEP_ODD(k, Q, QN, L, LN, S)                                                               \
@@ -3260,8 +3269,9 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
             g.helper_naps  = hn;
         } else {
             // (profiles/r4/dither_helpers.txt: 64 frames x 4 parts 347 us at 4,4 -- 350 at 8,8, 356 at 16,16, 366 at 32,32;
-            // one frame x 16 parts: the step 0.63 ms at 2,2 against 0.64 at 1,1)
-            g.helper_batch = dither_parts <= 6 ? 4 : 2;
+            // one frame x 16 parts: the step 0.63 ms at 2,2 against 0.64 at 1,1.  Round 6, with a step a quarter shorter
+            // (profiles/r6/dither_helpers.txt): 283 us at 4,4 -- 278 at 8,4 / 8,8 / 16,8, 280-282 at 1,1 / 2,2)
+            g.helper_batch = dither_parts <= 6 ? 8 : 2;
             g.helper_naps  = dither_parts <= 6 ? 4 : 2;
         }
     }

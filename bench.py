@@ -217,6 +217,58 @@ def cpp_dropin():
     return out
 
 
+def live_hbm_traffic(args):
+    """roofline.traffic measured by THIS invocation: the same command line (short, without the extras) twice more as a
+    subprocess under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- each counter in its own
+    pass, no trace domain but --kernel-trace, as MI355X_MICROARCH.md's HBM section prescribes -- and the dominant scale
+    kernel's average per dispatch, FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-byte-a-lane reads as 64
+    bytes), unit KiB.  None when rocprofv3 is missing or a pass fails (the bench line then falls back to the counter file
+    profiles/collect_pmc.sh left, and says so)."""
+    import csv, glob, shutil, subprocess, tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not tool or os.environ.get("TIMG_BENCH_NO_LIVE_PMC"):
+        return None
+    inner = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+             "--no-extras", "--no-dropin", "--no-parity", "--no-live-pmc"]
+    if args.kind:
+        inner += ["--kind", args.kind]
+    if args.frames:
+        inner += ["--frames", str(args.frames)]
+    if args.chunk:
+        inner += ["--chunk", str(args.chunk)]
+    env = dict(os.environ, TMPDIR="/tmp", TIMG_BENCH_NO_LIVE_PMC="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got = {}
+    work = tempfile.mkdtemp(prefix="timg_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            try:
+                subprocess.run([tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + inner,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=170, check=True)
+            except Exception:
+                return None
+            per_kernel = {}
+            for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(fn)):
+                    if r["Counter_Name"] == counter and "ScaleStream" in r["Kernel_Name"]:
+                        k = "ScaleStream" + r["Kernel_Name"].split("ScaleStream")[1].split("(")[0]
+                        per_kernel.setdefault(k, []).append(float(r["Counter_Value"]))
+            if not per_kernel:
+                return None
+            got[counter] = {k: sum(v) / len(v) for k, v in per_kernel.items()}
+        dom = max(got["FETCH_SIZE"], key=lambda k: got["FETCH_SIZE"][k])
+        fetch, write = got["FETCH_SIZE"][dom], got["WRITE_SIZE"].get(dom, 0.0)
+        return {"hbm_bytes_per_launch": int((fetch * 2 + write) * 1024),
+                "counters": {"kernel": dom, "FETCH_SIZE_KiB_raw": round(fetch, 1), "WRITE_SIZE_KiB_raw": round(write, 1),
+                             "correction": "FETCH_SIZE x2 (gfx950: 128-byte requests tallied as 64), WRITE_SIZE as reported; KiB"},
+                "source": "measured in THIS run: bench.py re-ran its own command line (3 steps, no extras) under rocprofv3 --kernel-trace "
+                          "--pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE after the timed region; average per dispatch of " + dom}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +308,9 @@ def main():
                          "(rounds 1-4) instead of timg_hip_sixel_encode_async (two jobs alternate, counts read one step late)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of the CPU sample")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of this same command as "
+                         "subprocesses, after the timed region); the figure then comes from profiles/hbm_traffic_*.json")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch / rendezvous check only: every rank joins the process group, one all-reduce, rank 0 prints "
                          '{"launched_ranks": N}; no device is touched (tests/test_gather_gloo.py runs it on the CPU)')
@@ -701,6 +756,9 @@ def main():
     # (rocprofv3 cannot wrap a run from inside it) into profiles/hbm_traffic_<config>[_<kind>].json -- one file per
     # configuration, from the round named in it; profiles/hbm_traffic.json (metric, S-photo) is the older single file
     tname = args.config + ("_" + args.kind if args.kind and args.kind != base_kind else "")
+    live = None
+    if world == 1 and not args.no_live_pmc and not args.no_extras and result["config"]["scale_kernel"] == "streaming":
+        live = live_hbm_traffic(args)
     for traffic_file in (os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % tname),
                          os.path.join(ROOT, "profiles", "hbm_traffic.json")):
         if not os.path.exists(traffic_file):
@@ -727,6 +785,13 @@ def main():
                 result["roofline"]["traffic_source"] = ("NOT measured in this run: profiles/%s, rocprofv3 --pmc FETCH_SIZE / "
                                                         "WRITE_SIZE passes of this same command (profiles/collect_pmc.sh)"
                                                         % os.path.basename(traffic_file))
+                if live:  # (measured a moment ago, by this invocation: the file keeps the limiter text and the issue roof)
+                    result["roofline"]["traffic"] = live["hbm_bytes_per_launch"] // launches_per_batch
+                    result["roofline"]["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / launches_per_batch / alg_bytes, 3)
+                    result["roofline"]["traffic_measured_in_this_run"] = True
+                    result["roofline"]["traffic_source"] = live["source"]
+                    result["roofline"]["traffic_counters"] = live["counters"]
+                    result["roofline"]["traffic_file_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / launches_per_batch / alg_bytes, 3)
                 if t.get("limiter") and not stale:
                     result["roofline"]["limiter"] = t["limiter"]
                 # the roof that binds this kernel beside the HBM one: the issue time of its vector instructions (counted by
@@ -738,6 +803,12 @@ def main():
                 break
         except Exception:
             pass
+    if live and not result["roofline"].get("traffic_measured_in_this_run"):  # (no counter file for this configuration)
+        result["roofline"]["traffic"] = live["hbm_bytes_per_launch"] // launches_per_batch
+        result["roofline"]["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / launches_per_batch / alg_bytes, 3)
+        result["roofline"]["traffic_measured_in_this_run"] = True
+        result["roofline"]["traffic_source"] = live["source"]
+        result["roofline"]["traffic_counters"] = live["counters"]
 
     if not args.no_extras and args.config == "metric":
         # -- the same kernel with alpha actually present (S-alpha frames, composed over the background):

@@ -46,7 +46,9 @@ struct SixelGeom {
     // r * idx_stride + 2 * (r & 3) + x -- IndexRow().  The diffusion advances a row two columns behind the row above it
     // and stores eight indices at a time; with the rows shifted by two bytes per row (mod 8) every row of a wave
     // completes an aligned group of eight in the SAME step: one 8-byte store per lane every eighth step (K4).
-    int idx_stride;
+    int idx_stride;        // bytes of an index row
+    int idx_shift;         // 0: the index image holds palette indices (a byte a pixel); 1: 15-bit biased CELLS (two bytes a
+                           // pixel: the one-trip diffusion leaves the cell -> index lookup to the band kernel, see K4)
     // the diffusion's helper waves (K4): columns a boundary row is moved by at a time, naps of 128 clocks between polls
     int helper_batch, helper_naps;
 };
@@ -111,7 +113,7 @@ struct SixelBatch {
 };
 
 __device__ __forceinline__ uint32_t IndexRow(const SixelGeom &g, int row) {  // byte offset of pixel 0 of `row`
-    return (uint32_t)row * (uint32_t)g.idx_stride + 2u * ((uint32_t)row & 3u);
+    return (uint32_t)row * (uint32_t)g.idx_stride + ((2u * ((uint32_t)row & 3u)) << g.idx_shift);
 }
 
 __device__ __forceinline__ SixelFrameScratch FrameScratch(const SixelBatch &b, const SixelGeom &g,
@@ -1322,15 +1324,6 @@ constexpr int kDitherSpinLimit = 1 << 22;
 #define TIMG_DITHER_ABL 0
 #endif
 constexpr int kDitherAbl = TIMG_DITHER_ABL;
-// (timing experiment: -DTIMG_DITHER_NOWAIT lets the pixel-pair kernels' steps through without waiting for their pixels -- garbage out;
-// what the waits cost, if anything)
-#ifdef TIMG_DITHER_NOWAIT
-#define TIMG_DITHER_VMCNT_EVEN "63"
-#define TIMG_DITHER_VMCNT_ODD "63"
-#else
-#define TIMG_DITHER_VMCNT_EVEN "9"
-#define TIMG_DITHER_VMCNT_ODD "7"
-#endif
 // The helper waves (flusher, fetcher) share their SIMDs with diffusing waves: what they issue, the diffusion does not
 // (every row waits for the one above it: the slowest wave sets the pace).  Polling every 128 clocks and moving a
 // boundary row column by column they cost a 64-frame batch 4 % (profiles/r4/dither_ablation.txt); they nap
@@ -1532,7 +1525,6 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
 
     // this lane's half of the tables
     const uint32_t tab_base  = odd ? 0u : 32768u;                 // (one trip: b / r, and g 32 KB behind r)
-    const uint8_t *lut8g     = s.lut8;
     const uint32_t *pal_half = pal + (odd ? 256 : 0);             // (two trips)
     // Record <-> term words (a term word is this half's pair of q << 8: 0xGG00RR00 / 0x0000BB00).  Packing, two
     // v_perm: w1 = (1/16, 5/16) of this half [odd: b of both, still without the 3/16]; w2 = the 3/16 [odd: w1's two
@@ -1567,8 +1559,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // At the last step of a block of eight (t + 7) the eight indices of columns t - 8 - 2 rl ... t - 1 - 2 rl are
         // complete: bytes idx_q ... idx_q + 7 of the lane's index row, idx_q = t - 8 - 8 (rl >> 2) -- IndexRow()'s shift
         // of 2 (rl & 3) is what makes it a multiple of eight for every row (rl = row mod 32).
+        // One trip: the image holds the pixels' CELLS, two bytes each (the palette index of a cell is a byte in memory: asked
+        // for here it was a row-scattered load a step -- 36 clocks of issue in the one instruction stream that sets the
+        // kernel's pace; the band kernel, which reads the image once, looks the indices up instead).
+        constexpr uint32_t kIdxBytes = kOneTrip ? 2u : 1u;
+        const int idx_px        = g.idx_stride / (int)kIdxBytes;  // a row's pixels incl. padding
         int idx_q               = -8 - 8 * (rl >> 2);
-        uint32_t idx_addr       = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride + (uint32_t)idx_q;
+        uint32_t idx_addr       = (uint32_t)min(row, H - 1) * (uint32_t)g.idx_stride + (uint32_t)idx_q * kIdxBytes;
         const bool diffuses     = dither && row < H - 1;
         // a lane that never spreads an error (no row, the last row, an exact palette) multiplies by zero:
         // 16 * err = 16 * c - 16 * p as ONE v_pk_mad_u16 of the table bytes
@@ -1632,7 +1629,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         uint32_t s1a = 0, s1b = 0;      // the record that arrived a step ago (a: w1, b: w2)
         PairI16 v_pre = {0, 0};         // this step's pixel with the 1/16 and 5/16 from above added
         uint32_t first_q3 = 0;
-        uint32_t pk_lo = 0, pk_hi = 0;  // the last eight indices, the newest in pk_hi's top byte
+        uint32_t pk_lo = 0, pk_hi = 0;  // the last eight indices, the newest in pk_hi's top byte (two trips)
+        uint32_t pkc[4] = {0, 0, 0, 0};  // the block's eight cells, two a word (one trip)
         uint32_t n_lo = 0, n_hi = 0;    // the boundary record requested a step ago (column t + 1 at step t)
         // The producer's progress counter is read EVERY step, one step before it is looked at (two instructions, no
         // wait: the value has long arrived), so a wave follows its producer as closely as the data allows and the
@@ -1744,8 +1742,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             // scheduled together (split by a branch, the byte reads came back through a v_and each, and their
             // latency covered nothing).
             // the eight indices completed by this block (see idx_q): one store, in the block's last step
-            if constexpr (k == 7) {
-                if (!(kDitherAbl & (8 | 512)) && stores_idx && (unsigned)idx_q < (unsigned)g.idx_stride)
+            // (one trip: the eight cells of the block BEFORE this one, in this block's first step -- the same columns)
+            if constexpr (kOneTrip && k == 0) {
+                if (!(kDitherAbl & (8 | 512)) && stores_idx && (unsigned)idx_q < (unsigned)idx_px)
+                    *reinterpret_cast<uint4 *>(s.index + idx_addr) = make_uint4(pkc[0], pkc[1], pkc[2], pkc[3]);
+            }
+            if constexpr (!kOneTrip && k == 7) {
+                if (!(kDitherAbl & (8 | 512)) && stores_idx && (unsigned)idx_q < (unsigned)idx_px)
                     *reinterpret_cast<uint2 *>(s.index + idx_addr) = make_uint2(pk_lo, pk_hi);
             }
             // the boundary record requested a step ago (column t + 1), and the request for column t + 2
@@ -1783,7 +1786,6 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 const uint32_t at = cell + tab_base;
                 t0 = (kDitherAbl & 16) ? at & 0xffu : tab8[at];          // r / b
                 t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
-                if (!(kDitherAbl & (2 | 512))) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(lidx) : "v"(cell), "s"(lut8g));
                 // (512: what a step would issue if helper waves staged the pixels into LDS and took the cells from it -- one
                 // conflict-free ds_read_b32 and one ds_write_b16 instead of three row-scattered memory instructions)
                 if (kDitherAbl & 512) *(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)(slack + 1024u + 2u * (uint32_t)lane) = (uint16_t)cell;
@@ -1821,6 +1823,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + (k - 1)), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
                 if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
             }
+            if constexpr (kOneTrip) pkc[k >> 1] = (k & 1) ? (cell << 16) | pkc[k >> 1] : cell;
             const uint32_t sa = DownOneRow(w1p, w1p, q_hi);  // (the odd lanes' terms are all in w2)
             q_pt              = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_lo, 0xb1, 0xf, 0xf, true);  // (bound_ctrl: every lane has a source)
             next_wait();
@@ -1883,10 +1886,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             uint32_t no_slot = 0;
             // The wait in front of a step -- and the alignbytes that take the index that landed with it -- are issued in the
             // shadow of the step BEFORE it, behind that step's own requests: the counts are the same.
-#define TIMG_DITHER_WAIT_EVEN(L) \
-    asm volatile("s_waitcnt vmcnt(" TIMG_DITHER_VMCNT_EVEN ") ; ring %2\n\tv_alignbyte_b32 %0, %1, %0, 1\n\tv_alignbyte_b32 %1, %2, %1, 1" : "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
-#define TIMG_DITHER_WAIT_ODD(QN, L) \
-    asm volatile("s_waitcnt vmcnt(" TIMG_DITHER_VMCNT_ODD ") ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(QN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory")
+            // (only the pixel pairs are in flight: the pair an odd step k reads was requested in step k - 6, behind it the
+            // pairs of steps k - 4 and k - 2 -- 2; the cell stores in between only make the wait more conservative)
+#define TIMG_DITHER_WAIT_EVEN(L) (void)0
+#define TIMG_DITHER_WAIT_ODD(QN, L) asm volatile("s_waitcnt vmcnt(2) ; ring %0" : "+v"(QN) : : "memory")
 #define TIMG_DITHER_STEP_EVEN(k, Q, QNN, L, LN, S) /* (the step behind it is odd: it waits for the pair after this one) */ \
     step(t + k, Q.y, no_slot, L, std::integral_constant<int, k>(), S(), &Q, [&]() __attribute__((always_inline)) { TIMG_DITHER_WAIT_ODD(QNN, LN); });
 #define TIMG_DITHER_STEP_ODD(k, Q, QN, L, LN, S)                                                               \
@@ -1906,7 +1909,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         out_steady += out_pace;                 \
         lim_run += 8;                           \
         prog_run += 8;                          \
-        idx_addr += 8u;                         \
+        idx_addr += 8u * kIdxBytes;             \
         idx_q += 8;                             \
     }
             int t = 0;
@@ -1952,10 +1955,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     if constexpr (kOneTrip && (kDitherAbl & 512) != 0)                                        \
         ;                                                                                     \
     else if constexpr (kOneTrip && (kDitherAbl & 128) != 0)                                   \
-        asm volatile("v_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory"); \
-    else if constexpr (kOneTrip)                                                              \
-        asm volatile("s_waitcnt vmcnt(12) ; ring %0 %3\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
-                     : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");               \
+        ;                                                                                     \
+    else if constexpr (kOneTrip) /* (pixels only in flight, as in the two-trip form; the cells are packed by the step) */ \
+        asm volatile("s_waitcnt vmcnt(6) ; ring %0" : "+v"(PN) : : "memory");                 \
     else /* (the index is the value the lookup produced: only the pixels are in flight) */    \
         asm volatile("s_waitcnt vmcnt(6) ; ring %0\n\tv_alignbyte_b32 %1, %2, %1, 1\n\tv_alignbyte_b32 %2, %3, %2, 1" \
                      : "+v"(PN), "+v"(pk_lo), "+v"(pk_hi) : "v"(L) : "memory");
@@ -1976,7 +1978,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         out_steady += out_pace;           \
         lim_run += 8;                     \
         prog_run += 8;                    \
-        idx_addr += 8u;                   \
+        idx_addr += 8u * kIdxBytes;       \
         idx_q += 8;                       \
     }
         int t = 0;
@@ -2269,10 +2271,17 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         for (int gi = 0; gi < kGroups; ++gi)
 #pragma unroll
             for (int r = 0; r < 6; ++r)
-                cw[gi][r] = g0 + gi < g1
-                                ? (uint32_t)*reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 4 * (g0 + gi)) |
-                                      ((uint32_t)*reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 4 * (g0 + gi) + 2) << 16)
-                                : 0u;
+                if (g0 + gi >= g1) {
+                    cw[gi][r] = 0u;
+                } else if (g.idx_shift) {  // four cells (K4, one trip) -> their palette indices
+                    const uint8_t *at = index + IndexRow(g, row0 + r) + 8 * (g0 + gi);
+                    const uint32_t c01 = *reinterpret_cast<const uint32_t *>(at), c23 = *reinterpret_cast<const uint32_t *>(at + 4);
+                    cw[gi][r] = (uint32_t)s.lut8[c01 & 0x7fffu] | ((uint32_t)s.lut8[(c01 >> 16) & 0x7fffu] << 8) |
+                                ((uint32_t)s.lut8[c23 & 0x7fffu] << 16) | ((uint32_t)s.lut8[(c23 >> 16) & 0x7fffu] << 24);
+                } else {
+                    cw[gi][r] = (uint32_t)*reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 4 * (g0 + gi)) |
+                                ((uint32_t)*reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 4 * (g0 + gi) + 2) << 16);
+                }
     }
     // (wide frames) visit(first, ent): a column's six rows as entries in FIXED slots, bit r of `first` set where row r is
     // the first of its colour -- no compaction into an array indexed at run time (that array lived in scratch memory)
@@ -2327,9 +2336,24 @@ __global__ void __launch_bounds__(kT) BandNodesKernel(SixelGeom g, SixelBatch b)
         for (int pi2 = 0; pi2 < kPairs; ++pi2)
 #pragma unroll
             for (int r = 0; r < 6; ++r)
-                c16[pi2][r] = h0 + pi2 < h1 ? *reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 2 * (h0 + pi2))
-                                            : 0u;
+                c16[pi2][r] = h0 + pi2 >= h1 ? 0u
+                              : g.idx_shift  ? *reinterpret_cast<const uint32_t *>(index + IndexRow(g, row0 + r) + 4 * (h0 + pi2))
+                                             : *reinterpret_cast<const uint16_t *>(index + IndexRow(g, row0 + r) + 2 * (h0 + pi2));
         for (int i = tid; i < 256 * nws; i += kT) bitmap[i] = 0;  // (while the index loads are in flight)
+        if (g.idx_shift) {  // the image holds cells (K4, one trip): their palette indices, a pair's twelve lookups in flight together
+#pragma unroll
+            for (int pi2 = 0; pi2 < kPairs; ++pi2)
+                if (h0 + pi2 < h1) {  // (at 800 columns no lane has a second pair)
+                    uint32_t lo[6], hi[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        lo[r] = s.lut8[c16[pi2][r] & 0x7fffu];
+                        hi[r] = s.lut8[(c16[pi2][r] >> 16) & 0x7fffu];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) c16[pi2][r] = lo[r] | (hi[r] << 8);
+                }
+        }
         // the entries of a lane's (up to four) columns: ent[k][r] valid where bit r of first[k] is set
         uint32_t ent[2 * kPairs][6];
         uint32_t first[2 * kPairs];
@@ -3182,7 +3206,17 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     const size_t o_lut8  = carve(nf * 32768);
     const size_t o_pal   = carve(nf * 768);
     const size_t o_meta  = carve(nf * 4 * sizeof(int));
-    g.idx_stride         = (w + 6 + 7) & ~7;
+    // (the launch plan first: the diffusion's lookup form decides what the index image holds)
+    const char *waves_env = getenv("TIMG_HIP_DITHER_WAVES"), *parts_env = getenv("TIMG_HIP_DITHER_PARTS"),
+               *trips_env = getenv("TIMG_HIP_DITHER_TRIPS");
+    const SixelLaunch plan = PlanSixelLaunch(w, g.h6, n_frames, ctx->cu_count, waves_env ? std::max(1, atoi(waves_env)) : 0,
+                                             parts_env ? std::max(0, atoi(parts_env)) : -1, trips_env ? atoi(trips_env) : 0);
+#ifdef TIMG_SIXEL_FIRST_HIT_BUILD
+    g.idx_shift          = 0;  // (the serial checker writes indices)
+#else
+    g.idx_shift          = plan.one_trip ? 1 : 0;
+#endif
+    g.idx_stride         = ((w + 6 + 7) & ~7) << g.idx_shift;
     const size_t o_idx   = carve(nf * (size_t)g.h6 * g.idx_stride);
     const size_t o_bb    = carve(nf * g.bands * g.band_cap);
     const size_t o_bm    = carve(nf * g.bands * 4 * sizeof(int));
@@ -3251,10 +3285,6 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     // for the diffusion: small frames, and the fallback of the multi-CU placement.  Round 1's two-CU version, whose
     // DIFFUSING waves read the bridge in global memory themselves, was not faster; DitherKernel<., true> keeps the
     // memory round trips in helper waves.)
-    const char *waves_env = getenv("TIMG_HIP_DITHER_WAVES"), *parts_env = getenv("TIMG_HIP_DITHER_PARTS"),
-               *trips_env = getenv("TIMG_HIP_DITHER_TRIPS");
-    const SixelLaunch plan = PlanSixelLaunch(w, g.h6, n_frames, ctx->cu_count, waves_env ? std::max(1, atoi(waves_env)) : 0,
-                                             parts_env ? std::max(0, atoi(parts_env)) : -1, trips_env ? atoi(trips_env) : 0);
     const int dither_waves = plan.dither_waves, dither_parts = plan.dither_parts, split_share = plan.split_share;
     const size_t dither_lds = plan.dither_lds, split_lds = plan.split_lds;
     const bool wide_bands   = plan.wide_bands;  // sort buffers in global scratch

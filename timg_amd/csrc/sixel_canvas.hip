@@ -1777,15 +1777,24 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             }
             const uint32_t c5   = AsBits(__builtin_bit_cast(PairU16, v) >> 11);  // 5 bits per channel, biased
             const uint32_t part = __builtin_amdgcn_udot2(__builtin_bit_cast(PairU16, c5), __builtin_bit_cast(PairU16, cell_mul), 0u, false);
-            const uint32_t cell = part | FromPairPartner(part);  // the biased cell, in both lanes of the pair
+            // the biased cell, in both lanes of the pair.  (One trip: a second dot product carries this lane's table base in
+            // its accumulator -- the partner's half is OR-ed into THAT, and the base's add leaves the chain; bit 15 of what
+            // the even lanes store as "the cell" is that base: the band kernel masks it.)
+            const uint32_t cell = kOneTrip ? (__builtin_amdgcn_udot2(__builtin_bit_cast(PairU16, c5), __builtin_bit_cast(PairU16, cell_mul), tab_base, false) |
+                                              FromPairPartner(part))
+                                           : (part | FromPairPartner(part));
             // 16 * c of 16 * err = 16 * c - 16 * p: c is the high byte of v ^ 0x8000 (zero in lanes that never spread: c16_mask)
             const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);
             uint32_t p_cell;  // the cell's palette colour as this lane's pair, times 1 (one trip) or 16
             uint32_t t0 = 0, t1 = 0;
             if constexpr (kOneTrip) {
-                const uint32_t at = cell + tab_base;
-                t0 = (kDitherAbl & 16) ? at & 0xffu : tab8[at];          // r / b
-                t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab8[at + 32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
+                const uint32_t at = cell;  // (= the cell + this lane's table base)
+                // (`at` as the LDS address itself: the kernel's LDS is all dynamic and starts at 0 -- the launch checks that
+                // the kernel has no static LDS -- so no add of the array's link-time address stands between the cell and its read)
+                typedef __attribute__((address_space(3))) uint8_t LdsU8;
+                const LdsU8 *tab_at = (const LdsU8 *)(uintptr_t)(at + (uint32_t)kDitherLdsHead);
+                t0 = (kDitherAbl & 16) ? at & 0xffu : tab_at[0];          // r / b
+                t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab_at[32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
                 // (512: what a step would issue if helper waves staged the pixels into LDS and took the cells from it -- one
                 // conflict-free ds_read_b32 and one ds_write_b16 instead of three row-scattered memory instructions)
                 if (kDitherAbl & 512) *(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)(slack + 1024u + 2u * (uint32_t)lane) = (uint16_t)cell;
@@ -3325,6 +3334,12 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     }
     // the kernels below need more than the default 64 KiB of dynamic LDS
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(dither_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dither_dyn));
+    {  // (the one-trip diffusion addresses its tables from LDS address 0: no static LDS may stand in front of the dynamic block)
+        hipFuncAttributes fa;
+        TIMG_HIP_TRY(ctx, hipFuncGetAttributes(&fa, dither_fn));
+        if (fa.sharedSizeBytes != 0)
+            return ctx->Fail(TIMG_HIP_ERR_DEVICE, "the sixel diffusion kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+    }
     TIMG_HIP_TRY(ctx, hipFuncSetAttribute(wide_bands ? (const void *)BandNodesKernel<true, 256>
                                                      : (const void *)BandNodesKernel<false, kBandLanes>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,

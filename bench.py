@@ -228,6 +228,10 @@ def live_hbm_traffic(args):
     tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not tool or os.environ.get("TIMG_BENCH_NO_LIVE_PMC"):
         return None
+    # (a run that is itself being profiled -- rocprofv3 preloads its tool library and configures it through the
+    # environment -- does not start a profiler inside the profiler: the file figure serves)
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
     inner = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
              "--no-extras", "--no-dropin", "--no-parity", "--no-live-pmc"]
     if args.kind:

@@ -1429,9 +1429,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
     for (int i = tid; i < 8192; i += blockDim.x) {  // four cells a turn; the bias leaves the low 2 bits alone
         const uint4 v = reinterpret_cast<const uint4 *>(s.lut)[i ^ (kCellBias >> 2)];  // idx | r << 8 | g << 16 | b << 24
         if (kOneTrip) {
-            lds[i]         = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);                              // b
-            lds[8192 + i]  = ((v.x >> 8) & 0xffu) | (((v.y >> 8) & 0xffu) << 8) | (((v.z >> 8) & 0xffu) << 16) | (((v.w >> 8) & 0xffu) << 24);    // r
-            lds[16384 + i] = ((v.x >> 16) & 0xffu) | (((v.y >> 16) & 0xffu) << 8) | (((v.z >> 16) & 0xffu) << 16) | (((v.w >> 16) & 0xffu) << 24);  // g
+            // (as SIGNED bytes p - 128 = p ^ 0x80: the step holds a channel as c - 128 and subtracts like from like)
+            lds[i]         = ((v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24)) ^ 0x80808080u;                              // b
+            lds[8192 + i]  = (((v.x >> 8) & 0xffu) | (((v.y >> 8) & 0xffu) << 8) | (((v.z >> 8) & 0xffu) << 16) | (((v.w >> 8) & 0xffu) << 24)) ^ 0x80808080u;    // r
+            lds[16384 + i] = (((v.x >> 16) & 0xffu) | (((v.y >> 16) & 0xffu) << 8) | (((v.z >> 16) & 0xffu) << 16) | (((v.w >> 16) & 0xffu) << 24)) ^ 0x80808080u;  // g
         } else {
             lds[i] = (v.x & 0xffu) | ((v.y & 0xffu) << 8) | ((v.z & 0xffu) << 16) | ((v.w & 0xffu) << 24);
         }
@@ -1573,6 +1574,11 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         // (one trip: times -16, and the byte the odd lane reads second meets a 0; two trips: the table holds 16 * p)
         const uint32_t k_err    = !lane_spreads ? 0u : !kOneTrip ? 0xffffffffu : odd ? 0x0000fff0u : 0xfff0fff0u;
         const uint32_t c16_mask = lane_spreads ? (odd ? 0x00000ff0u : 0x0ff00ff0u) : 0u;
+        // one trip: err = (c - 128) - (p - 128) as a pair of signed 16-bit numbers, and 16 * n * err + sign bias for the four
+        // terms with the 16 * n as LANE constants (0 in a lane that never spreads, 0 in the odd lane's half without a channel)
+        const uint32_t k_lane   = !lane_spreads ? 0u : odd ? 0x0000ffffu : 0xffffffffu;
+        const uint32_t k112 = 0x00700070u & k_lane, k80 = 0x00500050u & k_lane, k48 = 0x00300030u & k_lane, k16 = 0x00100010u & k_lane;
+        const uint32_t sgn_mask = 0x00f000f0u & k_lane;
         // which lanes complete a group of four indices at the steps k & 3 == 3 / k & 3 == 1 of the unrolled body
         const bool stores_idx   = has_row && !odd;
         const bool hands_down   = has_row && rl == kPairRows - 1;  // the row above the next wave's first row
@@ -1784,7 +1790,8 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                                               FromPairPartner(part))
                                            : (part | FromPairPartner(part));
             // 16 * c of 16 * err = 16 * c - 16 * p: c is the high byte of v ^ 0x8000 (zero in lanes that never spread: c16_mask)
-            const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);
+            const PairU16 c16 = __builtin_bit_cast(PairU16, AsBits(__builtin_bit_cast(PairU16, AsBits(v) ^ px_bias) >> 4) & c16_mask);  // (two trips)
+            const PairI16 cs  = v >> 8;  // c - 128 per half (one trip)
             uint32_t p_cell;  // the cell's palette colour as this lane's pair, times 1 (one trip) or 16
             uint32_t t0 = 0, t1 = 0;
             if constexpr (kOneTrip) {
@@ -1793,8 +1800,10 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 // the kernel has no static LDS -- so no add of the array's link-time address stands between the cell and its read)
                 typedef __attribute__((address_space(3))) uint8_t LdsU8;
                 const LdsU8 *tab_at = (const LdsU8 *)(uintptr_t)(at + (uint32_t)kDitherLdsHead);
-                t0 = (kDitherAbl & 16) ? at & 0xffu : tab_at[0];          // r / b
-                t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : tab_at[32768];  // g / (r: a byte the odd lane does not use, it meets k_err's 0)
+                typedef __attribute__((address_space(3))) int8_t LdsI8;
+                const LdsI8 *tab_s = (const LdsI8 *)tab_at;  // (sign-extending reads: p - 128)
+                t0 = (kDitherAbl & 16) ? at & 0xffu : (uint32_t)(int)tab_s[0];          // r / b
+                t1 = (kDitherAbl & 16) ? (at >> 7) & 0xffu : (uint32_t)(int)tab_s[32768];  // g / (r: a byte the odd lane does not use, it meets a 0 multiplier)
                 // (512: what a step would issue if helper waves staged the pixels into LDS and took the cells from it -- one
                 // conflict-free ds_read_b32 and one ds_write_b16 instead of three row-scattered memory instructions)
                 if (kDitherAbl & 512) *(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)(slack + 1024u + 2u * (uint32_t)lane) = (uint16_t)cell;
@@ -1812,7 +1821,13 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 px_slot = fetch(t + kDitherAhead, steady_tag);
                 p_cell  = pal_half[lidx];
             }
-            __builtin_amdgcn_sched_barrier(0);  // (the table reads are on their way: what follows is free)
+            // (Until the index request left the step a pair of sched_barriers held this block behind the table reads.  Without
+            // that request the step is bound by what it ISSUES -- taking the table reads out altogether buys 4 %,
+            // -DTIMG_DITHER_ABL=16 -- and the barriers cost it eight hazard s_nops per two steps that the scheduler fills
+            // when it may: 263 -> 256 us.  -DTIMG_DITHER_BARRIER: the old form.)
+#ifdef TIMG_DITHER_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             {  // LAST step's record and the counter behind it (all lanes, see rec_lo above; column W: a record of zeros)
                 uint32_t at;  // (records are 12 bytes apart: 4-byte aligned only -- two words in one ds_write2_b32)
                 if constexpr (steady)  // (the pair that hands down is inside its row; the others' dummies may overlap each other)
@@ -1850,22 +1865,37 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 asm volatile("" : "+v"(pin));
                 v_pre = AsPair(pin);
             }
+#ifdef TIMG_DITHER_BARRIER
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kOneTrip) p_cell = t0 | (t1 << 16);
-            // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
-            // zero in lanes that never spread (k_err, c16_mask) and outside the columns 0 .. W - 2 of the row
-            const PairU16 p8  = __builtin_bit_cast(PairU16, p_cell);
-            const PairI16 e0  = __builtin_bit_cast(PairI16, p8 * __builtin_bit_cast(PairU16, k_err) + c16);
-            const PairI16 zero  = {0, 0};
-            const PairI16 err   = steady || (unsigned)x < (unsigned)(W - 1) ? e0 : zero;
+#endif
+            const PairI16 zero = {0, 0};
+            uint32_t m7, m5, m3, m1;
             // trunc(err * n / 16) << 8 == (16 * err * n + (err < 0 ? 240 : 0)) & 0xff00: two channels at a time
-            const PairI16 k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
-            const PairI16 sgn = AsPair(AsBits(err >> 15) & 0x00f000f0u);
             // (only what is ADDED as it stands needs its low bytes cleared: the records take the high bytes by v_perm)
-            const uint32_t m7 = AsBits(err * k7 + sgn) & 0xff00ff00u;
-            const uint32_t m5 = AsBits(err * k5 + sgn);
-            const uint32_t m3 = AsBits(err * k3 + sgn);
-            const uint32_t m1 = AsBits(err + sgn);
+            if constexpr (kOneTrip) {
+                // err = c - p from the signed halves (the two table bytes, sign-extended, as one pair: v_perm); the lanes
+                // that never spread and the odd lane's empty half multiply by 0 (|112 * 255 + 240| fits 16 bits)
+                const PairI16 ps  = AsPair(__builtin_amdgcn_perm(t1, t0, 0x05040100u));
+                const PairI16 e1  = cs - ps;
+                const PairI16 err = steady || (unsigned)x < (unsigned)(W - 1) ? e1 : zero;
+                const PairI16 sgn = AsPair(AsBits(err >> 15) & sgn_mask);
+                m7 = AsBits(err * AsPair(k112) + sgn) & 0xff00ff00u;
+                m5 = AsBits(err * AsPair(k80) + sgn);
+                m3 = AsBits(err * AsPair(k48) + sgn);
+                m1 = AsBits(err * AsPair(k16) + sgn);
+            } else {
+                // 16 * err = 16 * c - 16 * p (|16 * err * 7 + 240| fits 16 bits): c is the high byte of v ^ 0x8000;
+                // zero in lanes that never spread (k_err, c16_mask) and outside the columns 0 .. W - 2 of the row
+                const PairU16 p8  = __builtin_bit_cast(PairU16, p_cell);
+                const PairI16 e0  = __builtin_bit_cast(PairI16, p8 * __builtin_bit_cast(PairU16, k_err) + c16);
+                const PairI16 err = steady || (unsigned)x < (unsigned)(W - 1) ? e0 : zero;
+                const PairI16 k7 = {7, 7}, k5 = {5, 5}, k3 = {3, 3};
+                const PairI16 sgn = AsPair(AsBits(err >> 15) & 0x00f000f0u);
+                m7 = AsBits(err * k7 + sgn) & 0xff00ff00u;
+                m5 = AsBits(err * k5 + sgn);
+                m3 = AsBits(err * k3 + sgn);
+                m1 = AsBits(err + sgn);
+            }
             if constexpr ((k & 1) == 0 && !steady) first_q3 = x == 0 ? (m3 & 0xff00ff00u) : first_q3;  // (x == 0 at t == 2 * rl: even steps only)
             // the column's record: moved down a row by the next step, stored for the next wave in that step's shadow
             w1p  = __builtin_amdgcn_perm(m5, m1, sel_w1);

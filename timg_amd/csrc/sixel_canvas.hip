@@ -1524,6 +1524,9 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         }
     }
 
+#ifdef TIMG_DITHER_PRIO
+    __builtin_amdgcn_s_setprio(3);  // (experiment: the diffusing waves above the helper waves they share a SIMD with)
+#endif
     // this lane's half of the tables
     const uint32_t tab_base  = odd ? 0u : 32768u;                 // (one trip: b / r, and g 32 KB behind r)
     const uint32_t *pal_half = pal + (odd ? 256 : 0);             // (two trips)
@@ -1715,6 +1718,20 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
             return v;
         };
         typedef uint32_t PixPair __attribute__((ext_vector_type(2)));
+        // Steady blocks: the pixels of the block's columns from a RUNNING pointer (column t - 2 rl of the lane's row, t the
+        // block's first step: + 32 bytes a block) with the step's distance as the load's immediate offset -- no column,
+        // no 64-bit address arithmetic in the step.
+        const uint8_t *px_run = src_row - 8 * rl;
+        auto fetch_run = [&](auto off_tag) -> uint32_t {
+            uint32_t v;
+            asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(v) : "v"(px_run), "i"(decltype(off_tag)::value));
+            return v;
+        };
+        auto fetch2_run = [&](auto off_tag) -> PixPair {
+            PixPair v;
+            asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v) : "v"(px_run), "i"(decltype(off_tag)::value));
+            return v;
+        };
         auto fetch2 = [&](int t, auto inside_tag) -> PixPair {  // columns t - 2 * rl (even) and the next one, the pair clamped into the row
             uint32_t x;
             if constexpr (decltype(inside_tag)::value)
@@ -1810,15 +1827,26 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                 // (the pixel for kDitherAhead steps on is requested HERE, in the shadow of the table reads, with the
                 // unpacking below: ~48 clocks of LDS latency otherwise spent in s_waitcnt)
                 if constexpr (kPix2) {  // (the pair of this step and the one before it is used up: its next request)
-                    if constexpr ((k & 1) != 0) *pair = fetch2(t - 1 + kDitherAhead, steady_tag);
+                    if constexpr ((k & 1) != 0) {
+                        if constexpr (steady)
+                            *pair = fetch2_run(std::integral_constant<int, (k - 1 + kDitherAhead) * 4>());
+                        else
+                            *pair = fetch2(t - 1 + kDitherAhead, steady_tag);
+                    }
                 } else if (kDitherAbl & 512) {
                     px_slot = *(volatile LdsU32 *)(uintptr_t)(slack + 768u + 4u * (uint32_t)lane);
                 } else if (!(kDitherAbl & 4)) {
-                    px_slot = fetch(t + kDitherAhead, steady_tag);
+                    if constexpr (steady)
+                        px_slot = fetch_run(std::integral_constant<int, (k + kDitherAhead) * 4>());
+                    else
+                        px_slot = fetch(t + kDitherAhead, steady_tag);
                 }
             } else {
                 lidx    = tab8[cell];
-                px_slot = fetch(t + kDitherAhead, steady_tag);
+                if constexpr (steady)
+                    px_slot = fetch_run(std::integral_constant<int, (k + kDitherAhead) * 4>());
+                else
+                    px_slot = fetch(t + kDitherAhead, steady_tag);
                 p_cell  = pal_half[lidx];
             }
             // (Until the index request left the step a pair of sched_barriers held this block behind the table reads.  Without
@@ -1840,12 +1868,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                     rec[1] = w1p;
                 }
                 asm volatile("" ::: "memory");  // (data, then the counter, from one wave: the LDS keeps the order)
-                int pv;
-                if constexpr (steady)
-                    pv = prog_run + (k - 1);
-                else
-                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + (k - 1)), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
-                if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
+                // (the counter every other step, for two records: the consumer looks at it every other step too)
+                if constexpr ((k & 1) != 0) {
+                    int pv;
+                    if constexpr (steady)
+                        pv = prog_run + (k - 1);
+                    else
+                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(pv) : "v"(prog_run + (k - 1)), "s"(prog_lo), "v"(prog_hi));  // (one SGPR per VALU instruction)
+                    if (!(kDitherAbl & 32)) *(volatile LdsU32 *)(uintptr_t)prog_addr = (uint32_t)pv;
+                }
             }
             if constexpr (kOneTrip) pkc[k >> 1] = (k & 1) ? (cell << 16) | pkc[k >> 1] : cell;
             const uint32_t sa = DownOneRow(w1p, w1p, q_hi);  // (the odd lanes' terms are all in w2)
@@ -1946,6 +1977,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         in_addr += 96u;                         \
         out_addr += 96u;                        \
         out_steady += out_pace;                 \
+        px_run += 32;                           \
         lim_run += 8;                           \
         prog_run += 8;                          \
         idx_addr += 8u * kIdxBytes;             \
@@ -2015,6 +2047,7 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         in_addr += 96u;                   \
         out_addr += 96u;                  \
         out_steady += out_pace;           \
+        px_run += 32;                     \
         lim_run += 8;                     \
         prog_run += 8;                    \
         idx_addr += 8u * kIdxBytes;       \

@@ -1349,13 +1349,14 @@ __device__ __forceinline__ void HelperNap(int naps) {
 // after the part it follows, and every wait is bounded (kDitherSpinLimit -> the batch's error word).
 //
 // kOneTrip: the lookup form (sixel_launch.h).  The chain of a step runs pixel -> cell -> palette colour -> error ->
-// the next pixel of the row; with the cell's COLOUR in LDS that is one LDS round trip (the palette index, which
-// only the output needs, is requested from BuildLut's byte table in memory and consumed kDitherAhead steps later);
+// the next pixel of the row; with the cell's COLOUR in LDS (as signed bytes p - 128) that is one LDS round trip, and the
+// palette index, which only the output needs, is not looked up here at all: the index image takes the CELL (two bytes a
+// pixel, SixelGeom::idx_shift) and the band kernel turns cells into indices when it reads them;
 // the two-trip form reads cell -> index -> colour from 34 KB of tables and leaves the LDS to the boundary rows.
 //
 // kPix2: the pixels are requested two at a time (one global_load_dwordx2 every second step).  A wave's 32 rows make
 // every pixel request 32 cache lines, 66 clocks of issue (scratch/ubench/wave_latency.hip: iss_gload_rows) in a step
-// of ~500; a lane's column advances by one per step and starts even, so an even frame width (and 8-byte aligned
+// of ~340; a lane's column advances by one per step and starts even, so an even frame width (and 8-byte aligned
 // rows) makes the pair (x, x + 1) one aligned load that never straddles the row's end.  One-trip form only.
 template <bool kNarrow, bool kSplit, bool kOneTrip, bool kPix2 = false>
 __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g, SixelBatch b) {
@@ -1939,20 +1940,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
         };
 
         if constexpr (kPix2) {
-            // Younger operations when a step begins (loads return in order; the index stores in between only make a wait
-            // more conservative).  Even step k: its pair was requested in step k - 7, behind it 6 index requests and 3
-            // pairs -- 9; odd step k: its index was requested in step k - 8 in front of that step's pair, then 7 indices
-            // and 3 pairs -- 11 (its pixel arrived with the pair, a step ago).
             asm volatile("" ::: "memory");
             PixPair q0 = fetch2(0, std::false_type()), q1 = fetch2(2, std::false_type()), q2 = fetch2(4, std::false_type()),
                     q3 = fetch2(6, std::false_type());
             uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;
             asm volatile("s_waitcnt vmcnt(0) ; ring all" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
             v_pre = ApplyPair(AsPair(__builtin_amdgcn_perm(q0.x, q0.x, sel_hi) ^ px_bias), __builtin_amdgcn_perm(s1a, s1b, sel_u5));
-            // A step reads the NEXT step's pixel (v_pre).  Even step k: that is its own pair's second half; the pair landed
-            // before the step in front of it (the wait below names the index alone).  Odd step k: the first half of the
-            // NEXT pair, requested in step k - 6; behind it 5 index requests (steps k - 5 ... k - 1) and 2 pairs (k - 4,
-            // k - 2) -- 7.  The index consumed by the alignbytes was requested in step k - 8, in front of either.
+            // A step reads the NEXT step's pixel (v_pre).  Even step k: that is its own pair's second half, which landed with
+            // the first.  Odd step k: the first half of the NEXT pair -- see the wait below.  (l0 .. l7: the index ring of
+            // the two-trip form's macros; nothing is requested into it here.)
             uint32_t no_slot = 0;
             // The wait in front of a step -- and the alignbytes that take the index that landed with it -- are issued in the
             // shadow of the step BEFORE it, behind that step's own requests: the counts are the same.
@@ -2013,14 +2009,15 @@ __global__ void __launch_bounds__(kDitherMaxWaves * 64) DitherKernel(SixelGeom g
                      :
                      : "memory");
         v_pre = ApplyPair(AsPair(__builtin_amdgcn_perm(p0, p0, sel_hi) ^ px_bias), __builtin_amdgcn_perm(s1a, s1b, sel_u5));
-        // A step reads the NEXT step's pixel (v_pre), requested in step k - 7: behind it the index and pixel requests of
-        // steps k - 6 ... k - 1 -- 12 (two trips, pixels only: 6).
+        // A step reads the NEXT step's pixel (v_pre), requested in step k - 7: behind it the pixel requests of steps
+        // k - 6 ... k - 1 -- 6 in either lookup form (only pixels are in flight: the one-trip form stores cells, the
+        // two-trip form's index is the value its lookup produced).
         // (no early exit inside the unrolled body: with one the compiler loses count of the
         // loads in flight; the up to 7 extra steps find every lane out of range)
-        // The index that arrived goes into packed_idx -- four per 32-bit store, the newest (pixel x - kDitherAhead) at
-        // the top byte -- INSIDE the wait's asm statement: as a value the compiler could see between its wait and
-        // the step's own request into the same variable, it was given a second register and copied, in flight, at
-        // the back edge (check_ring_isa.py refused the build).
+        // Two trips: the index goes into pk_lo / pk_hi -- the newest (pixel x - kDitherAhead) at the top byte -- INSIDE
+        // the wait's asm statement: as a value the compiler could see between its wait and the step's own request into
+        // the same variable, it was given a second register and copied, in flight, at the back edge (check_ring_isa.py
+        // refused the build).
         // (PN: the pixel of the step the wait stands in front of + 1; L: the index that step's alignbytes take)
 #define TIMG_DITHER_WAIT(PN, L)                                                               \
     if constexpr (kOneTrip && (kDitherAbl & 512) != 0)                                        \

@@ -467,6 +467,105 @@ def test_sixel_pixel_pairs_equal_single_pixels(hip, oracle, monkeypatch, kind, w
         assert got == want, f"pixel requests of {pix}: {len(got)} vs {len(want)} bytes"
 
 
+@pytest.mark.parametrize("kind,w,h,n", [("photo", 800, 450, 3), ("noise", 101, 37, 5), ("alpha", 2, 9, 2)])
+def test_sixel_byte_counts_written_by_the_kernels_or_copied(hip, oracle, monkeypatch, kind, w, h, n):
+    """Round 6: the chain's first kernel clears the error word and its last one writes the frames' byte counts and the
+    error word into the caller's pinned words; TIMG_HIP_SIXEL_COPY_LENGTHS=1 keeps the memset + copy form.  The same bytes
+    and counts, the oracle's, either way -- in a batch, on frames of both lookup forms' sizes (w = 2: the narrow kernel)."""
+    frames = np.stack([np.asarray(synth.make(kind, w, h, seed=41 + i)).reshape(h, w, 4) for i in range(n)])
+    want = [oracle.sixel_encode(frames[i], BG, PAT, 4, 2, lookup_mode=1) for i in range(n)]
+    d = hip.upload(frames)
+    try:
+        for form in ("", "1"):
+            if form:
+                monkeypatch.setenv("TIMG_HIP_SIXEL_COPY_LENGTHS", form)
+            else:
+                monkeypatch.delenv("TIMG_HIP_SIXEL_COPY_LENGTHS", raising=False)
+            outs = hip.sixel_encode(d, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 2), n_frames=n,
+                                    out_cap=hip.sixel_max_bytes(w, h) * 2)
+            for i in range(n):
+                assert outs[i] == want[i], f"form {form!r} frame {i}: {len(outs[i])} vs {len(want[i])} bytes"
+    finally:
+        hip.free(d)
+
+
+@pytest.mark.parametrize("trips", [1, 2])
+@pytest.mark.parametrize("kind,w,h,parts", [
+    ("photo", 800, 450, -1),   # the bench frame: four parts of four row groups
+    ("noise", 800, 450, 1),    # ... in one workgroup (five waves beside the colour tables, twelve beside the small ones)
+    ("alpha", 320, 203, -1),   # seven row groups: one workgroup
+    ("photo", 100, 56, -1),    # narrower than a wave's skew + the index delay (no column is ever "steady")
+    ("noise", 33, 6, -1),
+    ("photo", 3, 130, -1),
+    ("alpha", 801, 77, -1),    # odd width: the last group of four indices is completed by junk in the row's padding
+    ("photo", 802, 64, -1), ("photo", 803, 64, -1),
+    ("photo", 1920, 1080, -1), # a full-HD frame alone: twelve parts of three row groups (small tables)
+    ("noise", 1000, 500, -1),
+    ("photo", 4095, 40, -1),   # the widest frame: one wave, ONE boundary row beside the colour tables (it follows itself)
+    ("photo", 2600, 100, -1),  # one wave going round four times on that one row
+    ("photo", 64, 1100, 3),    # parts of 12 / 12 / 11 row groups
+])
+def test_sixel_both_lookup_forms(hip, oracle, monkeypatch, kind, w, h, parts, trips):
+    """DitherKernel<., ., kOneTrip>: the palette colour of a cell in ONE LDS round trip on the serial chain (96 KB of
+    colour tables, the palette index from memory kDitherAhead steps later) or in two (cell -> index -> colour, 34 KB).
+    sixel_launch.h picks by geometry; TIMG_HIP_DITHER_TRIPS forces either -- both give the oracle's bytes for every
+    placement (one workgroup, parts, a single wave that follows itself)."""
+    monkeypatch.setenv("TIMG_HIP_DITHER_TRIPS", str(trips))
+    if parts >= 0:
+        monkeypatch.setenv("TIMG_HIP_DITHER_PARTS", str(parts))
+    fb = synth.make(kind, w, h, seed=23)
+    got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3),
+                           out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+    want = oracle.sixel_encode(fb, BG, PAT, 5, 3, lookup_mode=1)
+    if got != want:
+        n = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
+        raise AssertionError(f"len {len(got)} vs {len(want)}, first diff at {n}: "
+                             f"{got[max(0, n - 20):n + 20]!r} vs {want[max(0, n - 20):n + 20]!r}")
+
+
+@pytest.mark.parametrize("kind,w,h,parts", [
+    ("photo", 800, 450, -1), ("noise", 800, 450, 1), ("alpha", 320, 203, -1), ("photo", 100, 56, -1), ("noise", 34, 6, -1),
+    ("photo", 4, 130, -1), ("photo", 802, 64, -1), ("photo", 64, 1100, 3), ("noise", 1000, 500, -1),
+])
+def test_sixel_pixel_pairs_equal_single_pixels(hip, oracle, monkeypatch, kind, w, h, parts):
+    """DitherKernel<., ., true, kPix2>: frames of even width request their pixels two at a time (one 8-byte load
+    every second step); TIMG_HIP_DITHER_PIX=1 keeps the one-pixel requests.  Same bytes, the oracle's, in both -- and a
+    frame whose rows are only 4-byte aligned (a view into a wider image) takes the one-pixel form by itself."""
+    if parts >= 0:
+        monkeypatch.setenv("TIMG_HIP_DITHER_PARTS", str(parts))
+    fb = synth.make(kind, w, h, seed=29)
+    want = oracle.sixel_encode(fb, BG, PAT, 5, 3, lookup_mode=1)
+    for pix in ("2", "1"):
+        monkeypatch.setenv("TIMG_HIP_DITHER_PIX", pix)
+        got = hip.sixel_encode(fb, w, h, pad_blend=timg_amd.Blend.make(BG, PAT, 5, 3),
+                               out_cap=hip.sixel_max_bytes(w, h) * 4)[0]
+        assert got == want, f"pixel requests of {pix}: {len(got)} vs {len(want)} bytes"
+
+
+@pytest.mark.parametrize("kind,w,h,n", [("photo", 800, 450, 3), ("noise", 101, 37, 5), ("alpha", 2, 9, 2)])
+def test_sixel_byte_counts_written_by_the_kernels_or_copied(hip, oracle, monkeypatch, kind, w, h, n):
+    """Round 6: the chain's first kernel clears the error word and its last one writes the frames' byte counts and the
+    error word into the caller's pinned words; TIMG_HIP_SIXEL_COPY_LENGTHS=1 keeps the memset + copy form.  The same bytes
+    and counts, the oracle's, either way -- in a batch, on frames of both lookup forms' sizes (w = 2: the narrow kernel)."""
+    import torch
+    fbs = [synth.make(kind, w, h, seed=41 + i) for i in range(n)]
+    want = [oracle.sixel_encode(fb, BG, PAT, 4, 2, lookup_mode=1) for fb in fbs]
+    dev = torch.from_numpy(np.stack([np.frombuffer(fb, dtype=np.uint8).reshape(h, w, 4) for fb in fbs])).cuda()
+    cap = hip.sixel_max_bytes(w, h) * 2
+    for form in ("", "1"):
+        if form:
+            monkeypatch.setenv("TIMG_HIP_SIXEL_COPY_LENGTHS", form)
+        else:
+            monkeypatch.delenv("TIMG_HIP_SIXEL_COPY_LENGTHS", raising=False)
+        out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+        lens = hip.sixel_encode(dev.data_ptr(), w, h, n_frames=n, pad_blend=timg_amd.Blend.make(BG, PAT, 4, 2),
+                                out=out.data_ptr(), out_cap=cap)
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert lens[i] == len(want[i]), f"form {form!r} frame {i}: {lens[i]} vs {len(want[i])} bytes"
+            assert out[i, :lens[i]].cpu().numpy().tobytes() == want[i], f"form {form!r} frame {i}"
+
+
 @pytest.mark.parametrize("trips", [1, 2])
 @pytest.mark.parametrize("pix", [1, 2])
 @pytest.mark.parametrize("kind,w,h,parts,view", [

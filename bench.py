@@ -589,7 +589,8 @@ def main():
                         p.scale(c)
                         e1 = record(p.stream)
                         p.encode()
-                    e2 = record(p.stream)
+                    # (one event between two launches: the next launch's e0 ends this one's encode stage; pipeline.py)
+                    e2 = record(p.stream) if (p.fused or k == n_launches_max - 1 or k + 1 >= len(chunks)) else None
                     if timed_events is not None:
                         timed_events.append((e0, e1, e2, p.last_scale_ms))
                     if use_async:
@@ -674,7 +675,9 @@ def main():
     # the library's own events around every piece's scale launches, summed) and the rest of the step
     fused = pipe.fused
     scale_ms = [ms if e1 is None else e0.elapsed_time(e1) for e0, e1, _, ms in events]
-    encode_ms = [e0.elapsed_time(e2) - sc for (e0, _, e2, _), sc in zip(events, scale_ms)]
+    # (a launch without an end event of its own ends where the next launch on its stream begins)
+    encode_ms = [e0.elapsed_time(e2 if e2 is not None else events[i + 1][0]) - sc
+                 for i, ((e0, _, e2, _), sc) in enumerate(zip(events, scale_ms))]
     sizes = [c.shape[0] for c in chunks] * args.steps if strong else [chunk] * len(events)
     full = [s for s, n in zip(scale_ms, sizes) if n == chunk]  # (a ragged tail launch is not the roofline's launch)
     roof_frames = chunk

@@ -259,7 +259,8 @@ size_t timg_hip_sixel_max_bytes(int w, int h); /* 1024 + w*round6(h)*5, :123 */
  * Streams: the encoder's scratch memory belongs to the context, one call at a time.  Calls on ONE stream follow each
  * other in stream order; a sixel call (blocking or not) on ANOTHER stream of the same context is ordered behind the
  * call in flight by the library itself (an event wait on the device, nobody blocks) -- correct, not concurrent: callers
- * that want two encodes to overlap use two contexts. */
+ * that want two encodes to overlap use two contexts.  A job belongs to its context (like a scaler): destroy it before
+ * the context; destroying a job waits for the call it still holds. */
 typedef struct timg_hip_sixel_job timg_hip_sixel_job;
 int timg_hip_sixel_job_create(timg_hip_ctx *ctx, int max_frames, timg_hip_sixel_job **out);
 void timg_hip_sixel_job_destroy(timg_hip_sixel_job *job);

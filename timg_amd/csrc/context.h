@@ -91,7 +91,8 @@ struct timg_hip_ctx {
     // an asynchronous one (timg_hip_sixel_encode_async) has not: `sixel_done` is recorded behind its last kernel on
     // `sixel_stream`.  The next sixel call on ANOTHER stream waits for it on the device (hipStreamWaitEvent); one that
     // must grow the scratch waits for it on the host before the old block is freed.
-    hipEvent_t sixel_done   = nullptr;
+    hipEvent_t sixel_done   = nullptr;   // (unused since round 6: the event is the last job's, sixel_last_job->done)
+    struct timg_hip_sixel_job *sixel_last_job = nullptr;  // the asynchronous call in flight, or the last one (cleared by its destroy)
     hipStream_t sixel_stream = nullptr;
     bool sixel_in_flight    = false;
 

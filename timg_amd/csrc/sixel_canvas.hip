@@ -3309,12 +3309,14 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
     // An earlier ASYNCHRONOUS call may still be running on this scratch (context.h: sixel_done).  On the same stream the
     // kernels below queue behind it; on another stream they are made to (on the device: nobody blocks); and before the
     // scratch GROWS -- Reserve frees the old block -- the host waits for that call, whatever stream it is on.
-    if (ctx->sixel_in_flight) {
+    // (The event is the JOB's: the call in flight recorded it behind its last kernel, and a job that is destroyed waits
+    // for its call and takes itself out of the context first -- one event record a call instead of two: 5 us of a step.)
+    if (ctx->sixel_in_flight && ctx->sixel_last_job) {
         if (off > ctx->dev[5].bytes) {
-            TIMG_HIP_TRY(ctx, hipEventSynchronize(ctx->sixel_done));
+            TIMG_HIP_TRY(ctx, hipEventSynchronize(ctx->sixel_last_job->done));
             ctx->sixel_in_flight = false;
         } else if (ctx->sixel_stream != st) {
-            TIMG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->sixel_done, 0));
+            TIMG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->sixel_last_job->done, 0));
         }
     }
     TIMG_HIP_TRY(ctx, ctx->dev[5].Reserve(off));
@@ -3528,8 +3530,7 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         if (!direct)
             TIMG_HIP_TRY(ctx, hipMemcpyAsync(job->len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
         TIMG_HIP_TRY(ctx, hipEventRecord(job->done, st));
-        if (!ctx->sixel_done) TIMG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->sixel_done, hipEventDisableTiming));
-        TIMG_HIP_TRY(ctx, hipEventRecord(ctx->sixel_done, st));  // (the context's own event: the job may be destroyed first)
+        ctx->sixel_last_job  = job;
         ctx->sixel_stream    = st;
         ctx->sixel_in_flight = true;
         job->n       = n_frames;
@@ -3542,6 +3543,7 @@ int TIMG_SIXEL_IMPL(timg_hip_ctx *ctx, const uint8_t *fb, int w, int h, int stri
         TIMG_HIP_TRY(ctx, hipMemcpyAsync(len_h, b.out_len, sizeof(unsigned long long) * (nf + 1), hipMemcpyDeviceToHost, st));
     TIMG_HIP_TRY(ctx, hipStreamSynchronize(st));
     ctx->sixel_in_flight = false;  // (this call waited behind whatever was in flight, and has finished itself)
+    ctx->sixel_last_job  = nullptr;
     if ((int)len_h[nf] != 0)
         return ctx->Fail(TIMG_HIP_ERR_DEVICE, "sixel diffusion: a workgroup gave up waiting for its neighbour");
     if (hook_ms) {
@@ -3594,7 +3596,15 @@ extern "C" int timg_hip_sixel_job_create(timg_hip_ctx *ctx, int max_frames, timg
 }
 extern "C" void timg_hip_sixel_job_destroy(timg_hip_sixel_job *j) {
     if (!j) return;
-    if (j->pending) (void)hipEventSynchronize(j->done);  // (the copy into len_h must not land in freed memory)
+    if (j->pending) (void)hipEventSynchronize(j->done);  // (the kernels' writes into len_h must not land in freed memory)
+    if (j->ctx) {  // (the context orders later calls behind this job's event: not behind a destroyed one)
+        std::lock_guard<std::mutex> lock(j->ctx->mu);
+        if (j->ctx->sixel_last_job == j) {
+            if (!j->pending && j->done) (void)hipEventSynchronize(j->done);  // (waited for already: returns at once)
+            j->ctx->sixel_last_job  = nullptr;
+            j->ctx->sixel_in_flight = false;
+        }
+    }
     if (j->done) (void)hipEventDestroy(j->done);
     if (j->len_h) (void)hipHostFree(j->len_h);
     delete j;

@@ -169,7 +169,11 @@ def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, time
                     p.scale(src)
                     e1 = record_event(p.stream) if record_event else None
                     p.encode()
-                e2 = record_event(p.stream) if record_event else None
+                # (ONE event between two steps of a pipeline: the next step's e0 ends this step's encode stage -- an event
+                # record is ~5 us of the stream's time, and a step is bracketed by three of them already; only a step
+                # with no step behind it on its stream, a fused step and several pipelines record their own)
+                lean = n_pipes == 1 and world == 1 and not getattr(p, "fused", False) and k + n_pipes < n_steps
+                e2 = record_event(p.stream) if (record_event and not lean) else None
                 if timed_events is not None and record_event:
                     timed_events.append((e0, e1, e2, getattr(p, "last_scale_ms", None)))
                 if use_async:

@@ -915,6 +915,17 @@ def main():
                                             cb["sixel_only_source_mpx_per_s_by_threads"].items()}
     if rank == 0 and not args.no_dropin and not args.no_extras and args.config == "metric":
         result["cpp_dropin"] = cpp_dropin()
+    # The ONE JSON line is the last line of stdout: libraries that write through C stdio (RCCL prints a version banner on
+    # stdout at its first communicator -- fully buffered into a pipe, it came out at process exit, BEHIND the line) are
+    # flushed first, on every rank, and the ranks meet before rank 0 prints.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     parity_failed = parity is not None and not parity["ok"]

@@ -1,5 +1,6 @@
 """Random sixel geometries / contents against the oracle (byte equality), plus run-to-run
-determinism of a batch: `ulimit -c 0; timeout 80 python scratch/sixel_stress.py [seconds]`."""
+determinism of a batch: `ulimit -c 0; timeout 80 python scratch/sixel_stress.py [seconds [seed [widest]]]`
+(widest: the last width class reaches up to it, default 2200; 4095 = the device's limit)."""
 import sys, time, random
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, timg_amd, oracle_lib
@@ -7,12 +8,13 @@ from timg_amd import synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 o = oracle_lib.Oracle()
 hip = timg_amd.TimgHip(0)
-random.seed(2024)
+random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+widest = int(sys.argv[3]) if len(sys.argv) > 3 else 2200
 BG, PAT = (30, 30, 46, 255), (200, 190, 180, 255)
 t0, n, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     kind = random.choice(["photo", "noise", "alpha", "photo"])
-    w = random.choice([random.randint(1, 40), random.randint(41, 400), random.randint(401, 1365), random.randint(1366, 2200)])
+    w = random.choice([random.randint(1, 40), random.randint(41, 400), random.randint(401, 1365), random.randint(1366, widest)])
     h = random.choice([random.randint(1, 30), random.randint(31, 200), random.randint(201, 700)])
     if w * h > 500_000: h = max(1, 500_000 // w)
     fb = synth.make(kind, w, h, seed=random.randint(0, 1 << 30))

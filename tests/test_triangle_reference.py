@@ -67,3 +67,40 @@ def test_oracle_triangle_is_a_triangle_filter(oracle, kind, sw, sh, dw, dh):
 def test_hip_triangle_is_a_triangle_filter(hip, kind, sw, sh, dw, dh):
     src = _frame(kind, sw, sh)
     _check(hip.scale(src, dw, dh, filter=2), float64_triangle(src, dw, dh))
+
+
+# ---- a THIRD-PARTY triangle filter that IS in the image: Pillow's Image.resize(BILINEAR) ------------------------------
+# Not libswscale (absent: the a2 row stays "unpinned"), but an independent, widely deployed implementation of the same
+# definition -- a triangle kernel widened to 1/scale source pixels when shrinking, weights normalised.  Where the two can
+# differ by construction: Pillow filters in two 8-bit passes (the horizontal result is rounded to bytes before the
+# vertical pass: up to 0.5 LSB more) with 22-bit fixed-point weights, and it TRUNCATES the kernel at the image border
+# where stb's machinery clamps (folds the outside taps onto the edge pixel) -- so the comparison is of the interior, on
+# opaque frames (Pillow filters straight alpha, the stb machinery alpha-weighted colour), with a bound of 1 LSB.
+PIL_CASES = [("photo", 640, 480, 200, 113), ("noise", 200, 150, 67, 50), ("photo", 1920, 1080, 400, 225),
+             ("photo", 64, 48, 160, 120), ("photo", 3840, 2160, 800, 450)]
+
+
+def _pillow_bilinear(src, dw, dh):
+    Image = pytest.importorskip("PIL.Image")
+    return np.asarray(Image.fromarray(np.ascontiguousarray(src[..., :3])).resize((dw, dh), Image.BILINEAR)).astype(np.int32)
+
+
+def _check_against_pillow(got, src, dw, dh):
+    d = np.abs(got[..., :3].astype(np.int32) - _pillow_bilinear(src, dw, dh))
+    assert d[2:-2, 2:-2].max() <= 1, "interior pixels: within 1 LSB of Pillow's BILINEAR"
+    assert (got[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("kind,sw,sh,dw,dh", PIL_CASES)
+def test_oracle_triangle_against_pillow_bilinear(oracle, kind, sw, sh, dw, dh):
+    src = synth.make(kind, sw, sh, seed=3)
+    src[..., 3] = 255
+    _check_against_pillow(oracle.scale(src, dw, dh, filter=2), src, dw, dh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,sw,sh,dw,dh", PIL_CASES)
+def test_hip_triangle_against_pillow_bilinear(hip, kind, sw, sh, dw, dh):
+    src = synth.make(kind, sw, sh, seed=3)
+    src[..., 3] = 255
+    _check_against_pillow(hip.scale(src, dw, dh, filter=2), src, dw, dh)

@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--batched-streams", type=int, default=3,
                     help="after the timed region, time the same K steps again on this many concurrent batched "
                          "streams and report it as `batched_streams` (0 = skip; metric configuration only)")
+    ap.add_argument("--partitioned", type=int, default=12,
+                    help="CUs of every XCD kept free of the scale kernel in the `partitioned_streams` extra (0 = skip; "
+                         "metric configuration, one rank)")
     ap.add_argument("--frames", type=int, default=0, help="override the configuration's frame count")
     ap.add_argument("--chunk", type=int, default=0,
                     help="frames per batched launch (c4, c5).  0 = the fewest equal launches of at most 256 frames: the sixel "
@@ -902,6 +905,40 @@ def main():
             "value": round(world * cfg["frames"] * in_w * in_h * k_extra / 1e6 / dt, 1), "unit": "Mpixels/s",
             "note": "same workload, batches on independent streams overlap; not the contract's timed region",
         }
+
+    if args.partitioned > 0 and world == 1 and not strong and not args.no_extras and mode == "sixel" and args.config == "metric":
+        # Same K steps with the chip PARTITIONED between the two calls (extra information, outside the timed region above):
+        # the scale call on a stream whose kernels stay off `--partitioned` CUs of every XCD, the sixel chain on an
+        # unrestricted stream of the greatest priority (timg_hip_stream_create, PartitionedSixelPipeline): step k + 1's scale
+        # kernel runs beside step k's histogram / median cut / table / diffusion, which find the reserved CUs free.  On one
+        # stream -- or two plain ones -- the scale kernel holds every CU until its last workgroup retires
+        # (profiles/r6/overlap_streams.txt).  Kernel durations are NOT comparable with the roofline object in this mode
+        # (the scale kernel has fewer CUs and shares the bus); the last step's frames are compared with the timed region's.
+        from timg_amd.pipeline import PartitionedSixelPipeline
+        pp = PartitionedSixelPipeline(hips[0], chunk, in_w, in_h, out_w, out_h, blend, reserved_cus_per_xcd=args.partitioned)
+        try:
+            pp.run(src, max(args.warmup, 2))
+            k_part = max(args.steps, 6)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pp.run(src, k_part)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            same = None
+            if pipe.lengths is not None and pipe.out is not None:
+                same = all(pp.frame_bytes(i) == pipe.frame_bytes(i) for i in (0, chunk // 2, chunk - 1))
+            result["partitioned_streams"] = {
+                "reserved_cus_per_xcd": args.partitioned, "scale_kernel_cus": 256 - 8 * (args.partitioned // 4 * 4),
+                "steps": k_part, "ms_per_step": round(dt / k_part * 1e3, 3),
+                "value": round(chunk * in_w * in_h * k_part / 1e6 / dt, 1), "unit": "Mpixels/s",
+                "bytes_equal_to_the_timed_regions": same,
+                "note": "same workload, ONE batch stream: the scale call of step k+1 on a CU-masked stream beside the sixel chain "
+                        "of step k; not the contract's timed region",
+            }
+        except Exception as exc:  # (an extra: the line must come out)
+            result["partitioned_streams"] = {"error": repr(exc)}
+        finally:
+            pp.close()
 
     if rank == 0 and not args.no_cpu_baseline and mode == "sixel":
         cores = args.cpu_threads or (os.cpu_count() or 1)

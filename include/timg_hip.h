@@ -64,6 +64,24 @@ int timg_hip_memcpy_d2h(timg_hip_ctx *ctx, void *dst, const void *src, size_t n,
 int timg_hip_sync(timg_hip_ctx *ctx, void *stream);
 int timg_hip_memcpy_d2d(timg_hip_ctx *ctx, void *dst, const void *src, size_t n, void *stream);
 
+/* ---- streams for a partitioned pipeline (round 6; not a reference interface) ---------------------------------------
+ * Every entry point takes the caller's stream.  A caller that has no HIP binding of its own -- or wants what plain HIP
+ * streams do not give it -- gets streams here:
+ *   reserved_cus_per_xcd > 0: the stream's kernels run on all CUs of the device EXCEPT that many of each of its 8 XCDs
+ *     (hipExtStreamCreateWithCUMask; rounded down to a multiple of 4 = one CU of each of an XCD's four shader engines:
+ *     a mask that takes unequal numbers of CUs from the engines slows a launch down to its smallest engine).  The use:
+ *     the scale call of batch k + 1 on such a stream, the sixel chain of batch k on an unrestricted one -- the chain's
+ *     latency-bound kernels (histogram, median cut, table, diffusion) then find free CUs while the scale kernel, which
+ *     otherwise holds every CU's registers and LDS until its last workgroup retires, runs beside them
+ *     (profiles/r6/partitioned_streams.txt: 1.32 -> 1.16 ms per 64-frame step with 12 CUs of every XCD kept free).
+ *   high_priority != 0: created with the device's greatest stream priority.
+ * The context owns the stream: timg_hip_stream_destroy (after the work on it has finished) or timg_hip_destroy ends it.
+ * Ordering BETWEEN streams is the caller's (events of its own binding, or timg_hip_stream_wait_stream below, which
+ * makes `waiter`'s later work wait for what `signaller` holds now). */
+int timg_hip_stream_create(timg_hip_ctx *ctx, int reserved_cus_per_xcd, int high_priority, void **stream);
+int timg_hip_stream_destroy(timg_hip_ctx *ctx, void *stream);
+int timg_hip_stream_wait_stream(timg_hip_ctx *ctx, void *waiter, void *signaller);
+
 /* ---- synthetic frames (the measurement plan's inputs) ---------------
  * Not a reference interface: hzeller/timg has no frame generator.  These are the S-noise /
  * S-photo / S-alpha RGBA8 frames the BASELINE configurations are defined on, generated in

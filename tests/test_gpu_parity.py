@@ -354,6 +354,52 @@ def test_sixel_async_encode_is_the_blocking_call_read_late(hip, oracle):
         hip.free(d)
 
 
+def test_partitioned_streams_write_the_same_bytes(hip, oracle):
+    """timg_hip_stream_create (round 6): the scale call on a stream whose kernels stay off 12 CUs of every XCD, the sixel
+    chain on an unrestricted stream of the greatest priority, step k + 1's scale beside step k's chain
+    (PartitionedSixelPipeline).  Five steps over frames with alpha: every frame of the last step is the restatement's of
+    the reference scaler's output, and what the two plain calls on one stream write.  Then the API's edges: a reserve
+    that is not a multiple of four is rounded down, one that leaves no CU is refused, a stream of another owner is not
+    destroyed."""
+    import torch
+    from timg_amd.pipeline import PartitionedSixelPipeline
+    n, sw, sh, dw, dh = 6, 640, 360, 200, 112
+    frames = np.stack([synth.make("alpha" if i % 2 else "photo", sw, sh, 700 + i) for i in range(n)])
+    blend = timg_amd.Blend.make(BG, PAT, 5, 3)
+    src = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    p = PartitionedSixelPipeline(hip, n, sw, sh, dw, dh, blend, reserved_cus_per_xcd=12)
+    lens = p.run(src, 5)
+    got = [p.frame_bytes(i) for i in range(n)]
+    assert len(lens) == n
+    # the two plain calls, blocking, on the context's own stream
+    sc = hip.scaler(sw, sh, dw, dh)
+    scaled = torch.empty((n, dh, dw, 4), dtype=torch.uint8, device="cuda")
+    hip.scale_blend(sc, src.data_ptr(), scaled.data_ptr(), n, blend)
+    hip.sync()
+    plain = hip.sixel_encode(scaled.data_ptr(), dw, dh, pad_blend=blend, n_frames=n)
+    scaled_host = scaled.cpu().numpy()
+    for i in range(n):
+        assert got[i] == plain[i], i
+        want_px = oracle.alpha_compose(oracle.scale(frames[i], dw, dh), BG, PAT, 5, 3, 0)[0]
+        assert np.array_equal(scaled_host[i], want_px), i
+        assert got[i] == oracle.sixel_encode(want_px, BG, PAT, 5, 3, lookup_mode=1), i
+    sc.close()
+    p.close()
+    a = hip.stream_create(reserved_cus_per_xcd=7)   # -> 4 CUs of every XCD
+    b = hip.stream_create(reserved_cus_per_xcd=3)   # -> none: a plain stream
+    hip.stream_wait_stream(a, b)
+    hip.stream_wait_stream(0, a)                     # (0 = the context's own stream)
+    hip.sync(a)
+    hip.stream_destroy(a)
+    hip.stream_destroy(b)
+    with pytest.raises(timg_amd.TimgHipError) as e:
+        hip.stream_create(reserved_cus_per_xcd=32)
+    assert e.value.code == -5
+    with pytest.raises(timg_amd.TimgHipError):
+        hip.stream_destroy(torch.cuda.Stream().cuda_stream)
+
+
 def test_sixel_calls_on_two_streams_of_one_context_are_ordered_by_the_library(hip, oracle):
     """a call of timg_hip_sixel_encode_async leaves kernels running on the context's scratch after it has
     returned; nothing but stream order kept the NEXT sixel call off that scratch -- so a call on another stream, a

@@ -96,6 +96,11 @@ struct timg_hip_ctx {
     hipStream_t sixel_stream = nullptr;
     bool sixel_in_flight    = false;
 
+    // streams handed out by timg_hip_stream_create (CU-masked / prioritised), ended with the context at the latest;
+    // the event timg_hip_stream_wait_stream orders two of them with (recorded and waited for under `mu`)
+    std::vector<hipStream_t> owned_streams;
+    hipEvent_t order_event = nullptr;
+
     timg_hip_ctx() {
         for (auto &p : pin) p.pinned = true;
     }

@@ -71,6 +71,9 @@ def load_library():
     L.timg_hip_memcpy_d2h.argtypes = [vp, vp, vp, c_size_t, vp]
     L.timg_hip_sync.argtypes = [vp, vp]
     L.timg_hip_memcpy_d2d.argtypes = [vp, vp, vp, c_size_t, vp]
+    L.timg_hip_stream_create.argtypes = [vp, c_int, c_int, POINTER(vp)]
+    L.timg_hip_stream_destroy.argtypes = [vp, vp]
+    L.timg_hip_stream_wait_stream.argtypes = [vp, vp, vp]
     L.timg_hip_synth_frames.argtypes = [vp, c_int, c_int, c_int, c_uint32, c_int, c_int, vp, c_size_t, c_int, vp]
     L.timg_hip_scaler_create.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(vp)]
     L.timg_hip_scaler_destroy.argtypes = [vp]
@@ -238,6 +241,20 @@ class TimgHip:
 
     def sync(self, stream=None):
         self._check(self.L.timg_hip_sync(self.ctx, c_void_p(stream) if stream else None))
+
+    def stream_create(self, reserved_cus_per_xcd: int = 0, high_priority: bool = False) -> int:
+        """A stream of the context (timg_hip_stream_create): its kernels stay off `reserved_cus_per_xcd` CUs of every XCD
+        (a multiple of 4), or it has the device's greatest priority.  Returns the raw hipStream_t."""
+        st = c_void_p()
+        self._check(self.L.timg_hip_stream_create(self.ctx, reserved_cus_per_xcd, 1 if high_priority else 0, byref(st)))
+        return st.value
+
+    def stream_destroy(self, stream: int):
+        self._check(self.L.timg_hip_stream_destroy(self.ctx, c_void_p(stream)))
+
+    def stream_wait_stream(self, waiter: int, signaller: int):
+        """`waiter`'s later work waits for everything `signaller` holds now (device-side; nobody blocks)."""
+        self._check(self.L.timg_hip_stream_wait_stream(self.ctx, c_void_p(waiter), c_void_p(signaller)))
 
     def synth_frames(self, kind: str, w: int, h: int, seed: int = 0, first_frame: int = 0, n_frames: int = 1,
                      dst: int | None = None, frame_stride: int = 0, stream=None):

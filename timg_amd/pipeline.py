@@ -130,6 +130,61 @@ class GridPipeline:
         self.scaler.close()
 
 
+class PartitionedSixelPipeline:
+    """scale -> sixel encode with the two calls on TWO streams of one context (timg_hip_stream_create): the scale
+    stream's kernels stay off `reserved_cus_per_xcd` CUs of every XCD, the encode stream is unrestricted and has the
+    greater priority.  Step k + 1's scale kernel then runs beside the latency-bound kernels of step k's sixel chain
+    (histogram, median cut, table, diffusion), which find the reserved CUs free; on one stream -- or two plain ones --
+    the scale kernel holds every CU until its last workgroup retires (profiles/r6/overlap_streams.txt).  The scaled
+    frames, the output and the job are double-buffered; a step's byte counts are read after the next step has been
+    enqueued.  Same bytes as GridPipeline (tests/test_gpu_parity.py)."""
+
+    def __init__(self, hip: TimgHip, n_frames: int, in_w: int, in_h: int, out_w: int, out_h: int,
+                 blend: Blend | None = None, reserved_cus_per_xcd: int = 12, device: str = "cuda"):
+        self.hip, self.n, self.blend = hip, n_frames, blend
+        self.out_w, self.out_h = out_w, out_h
+        self.reserved = reserved_cus_per_xcd
+        self.scaler = hip.scaler(in_w, in_h, out_w, out_h)
+        self.cap = hip.sixel_max_bytes(out_w, out_h)
+        self.scaled = [torch.empty((n_frames, out_h, out_w, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.outs = [torch.empty((n_frames, self.cap), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.jobs = [hip.sixel_job(n_frames) for _ in range(2)]
+        self.scale_stream = hip.stream_create(reserved_cus_per_xcd=reserved_cus_per_xcd)
+        self.encode_stream = hip.stream_create(high_priority=True)
+        self.lengths, self.out = None, None
+
+    def run(self, src: torch.Tensor, n_steps: int):
+        """n_steps passes over `src`; returns when the last step's byte counts have been read."""
+        hip = self.hip
+        for k in range(n_steps):
+            sl = k & 1
+            # (scaled[sl] / outs[sl] / jobs[sl] were step k - 2's: that step was waited for one iteration ago)
+            hip.scale_blend(self.scaler, src.data_ptr(), self.scaled[sl].data_ptr(), self.n, self.blend, stream=self.scale_stream)
+            hip.stream_wait_stream(self.encode_stream, self.scale_stream)
+            hip.sixel_encode_async(self.jobs[sl], self.scaled[sl].data_ptr(), self.out_w, self.out_h, self.outs[sl].data_ptr(),
+                                   self.cap, n_frames=self.n, pad_blend=self.blend, stream=self.encode_stream)
+            if k >= 1:
+                hip.sixel_encode_wait(self.jobs[sl ^ 1], self.n)
+        if n_steps > 0:
+            last = (n_steps - 1) & 1
+            self.lengths = hip.sixel_encode_wait(self.jobs[last], self.n)
+            self.out = self.outs[last]
+        hip.sync(self.scale_stream)
+        hip.sync(self.encode_stream)
+        return self.lengths
+
+    def frame_bytes(self, i: int) -> bytes:
+        return self.out[i, :self.lengths[i]].cpu().numpy().tobytes()
+
+    def close(self):
+        for j in self.jobs:
+            self.hip.sixel_job_destroy(j)
+        self.jobs = []
+        self.hip.stream_destroy(self.scale_stream)
+        self.hip.stream_destroy(self.encode_stream)
+        self.scaler.close()
+
+
 def run_batched_streams(pipes, src, n_steps, n_pipes, world=1, gather=None, timed_events=None,
                         record_event=None, async_encode=True):
     """n_steps passes of the hot path over `src`, step k on pipeline k % n_pipes, every pipeline

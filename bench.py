@@ -918,7 +918,7 @@ def main():
         pp = PartitionedSixelPipeline(hips[0], chunk, in_w, in_h, out_w, out_h, blend, reserved_cus_per_xcd=args.partitioned)
         try:
             pp.run(src, max(args.warmup, 2))
-            k_part = max(args.steps, 6)
+            k_part = max(args.steps, 24)  # (a pipeline of two stages: its first and last step overlap nothing)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pp.run(src, k_part)

@@ -217,6 +217,12 @@ def cpp_dropin():
     return out
 
 
+def under_a_profiler():
+    """rocprofv3 preloads its tool library and configures it through the environment"""
+    return (any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ)
+            or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))
+
+
 def live_hbm_traffic(args):
     """roofline.traffic measured by THIS invocation: the same command line (short, without the extras) twice more as a
     subprocess under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- each counter in its own
@@ -230,7 +236,7 @@ def live_hbm_traffic(args):
         return None
     # (a run that is itself being profiled -- rocprofv3 preloads its tool library and configures it through the
     # environment -- does not start a profiler inside the profiler: the file figure serves)
-    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+    if under_a_profiler():
         return None
     inner = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
              "--no-extras", "--no-dropin", "--no-parity", "--no-live-pmc"]
@@ -520,6 +526,11 @@ def main():
 
     n_pipes = max(1, args.pipelines) if not strong else 1
     n_extra = 0 if (strong or args.no_extras or args.config != "metric") else max(0, args.batched_streams)
+    # (a run under rocprofv3 is usually there for the per-kernel averages of the TIMED region: the two extras that run the same
+    # kernels CONCURRENTLY -- several batches in flight, the partitioned chip -- would mix their stretched launches into them)
+    profiled = under_a_profiler()
+    if profiled:
+        n_extra = 0
     hips = [timg_amd.TimgHip(local_rank) for _ in range(max(n_pipes, n_extra, 1))]
     pipes = [GridPipeline(h, chunk, in_w, in_h, out_w, out_h, mode, blend, pieces=args.pieces) for h in hips]
     if args.kernel:
@@ -892,6 +903,9 @@ def main():
         result["ms_per_step_with_d2h_overlapped"] = round((time.perf_counter() - t0) / args.steps * 1e3, 3)
         del dev_out, host_buf
 
+    if profiled and not args.no_extras and not strong and args.config == "metric":
+        result["concurrent_extras"] = ("batched_streams / partitioned_streams skipped: this run is under a profiler, whose per-kernel "
+                                       "averages they would mix their concurrent launches into")
     if n_extra > 1:
         # Same K steps on n_extra concurrent batched streams (extra information, outside the
         # timed region above): the serial stages of the sixel canvas keep only part of the chip busy (the
@@ -906,7 +920,7 @@ def main():
             "note": "same workload, batches on independent streams overlap; not the contract's timed region",
         }
 
-    if args.partitioned > 0 and world == 1 and not strong and not args.no_extras and mode == "sixel" and args.config == "metric":
+    if args.partitioned > 0 and not profiled and world == 1 and not strong and not args.no_extras and mode == "sixel" and args.config == "metric":
         # Same K steps with the chip PARTITIONED between the two calls (extra information, outside the timed region above):
         # the scale call on a stream whose kernels stay off `--partitioned` CUs of every XCD, the sixel chain on an
         # unrestricted stream of the greatest priority (timg_hip_stream_create, PartitionedSixelPipeline): step k + 1's scale

@@ -6,6 +6,7 @@
 #include <new>
 
 #include "context.h"
+#include "cu_mask.h"
 
 using timg_amd::DevBlend;
 using timg_amd::DevPlan;
@@ -210,26 +211,17 @@ int timg_hip_sync(timg_hip_ctx *ctx, void *stream) {
     return TIMG_HIP_OK;
 }
 
-// ---- streams for a partitioned pipeline (timg_hip.h) ----------------------------------------------------------
-// The CU mask as the driver reads it on a multi-XCD device (the kernel driver's own description of its mask walk): bit n
-// of the mask is a CU of XCD n % 8, and an XCD's bits go round its four shader engines -- its bit j is CU j / 4 of
-// engine j % 4.  So "the last 4 r' bits of every XCD" (bits n with n / 8 >= 32 - 4 r') are r' CUs of every engine of every
-// XCD.  Measured on the metric step (scratch/r6_cumask.py): reserving 4 / 8 / 12 / 16 CUs an XCD 1.23 / 1.28 / 1.16 /
-// 1.18 ms against 1.32 on one stream; 3, 5, 9 ... (engines left with unequal CU counts) 1.25-1.33.
+// ---- streams for a partitioned pipeline (timg_hip.h; the mask's layout: cu_mask.h) ---------------------------------
 int timg_hip_stream_create(timg_hip_ctx *ctx, int reserved_cus_per_xcd, int high_priority, void **stream) {
     if (!ctx || !stream || reserved_cus_per_xcd < 0) return TIMG_HIP_ERR_ARG;
     TIMG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    constexpr int kXcds = 8, kEngines = 4;
-    const int per_xcd  = ctx->cu_count / kXcds;
-    const int reserved = reserved_cus_per_xcd / kEngines * kEngines;
+    uint32_t mask[timg_amd::kCuMaskWords];
+    const int reserved = timg_amd::BuildCuMask(ctx->cu_count, reserved_cus_per_xcd, mask);
+    if (reserved < 0)
+        return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "timg_hip_stream_create: %d CUs of every XCD reserved on a device of %d CUs",
+                         reserved_cus_per_xcd, ctx->cu_count);
     hipStream_t st = nullptr;
     if (reserved > 0) {
-        if (ctx->cu_count != per_xcd * kXcds || per_xcd % kEngines != 0 || reserved >= per_xcd || ctx->cu_count > 1024)
-            return ctx->Fail(TIMG_HIP_ERR_UNSUPP, "timg_hip_stream_create: %d CUs reserved of %d an XCD (%d CUs)", reserved,
-                             per_xcd, ctx->cu_count);
-        uint32_t mask[32] = {0};
-        for (int n = 0; n < ctx->cu_count; ++n)
-            if (n / kXcds < per_xcd - reserved) mask[n >> 5] |= 1u << (n & 31);
         TIMG_HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&st, (uint32_t)((ctx->cu_count + 31) / 32), mask));
         // (a masked stream has the default priority: the extension takes no priority argument)
     } else {

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "cu_mask.h"
 #include "gfx_layout.h"
 #include "h2_strips.h"
 #include "resample_plan.h"
@@ -151,4 +152,9 @@ extern "C" int timg_hip_debug_h2_tiling(int sw, int sh, int in_fmt, int dw, int 
         halves[3 * i] = t.halves[i].ox0, halves[3 * i + 1] = t.halves[i].ox1, halves[3 * i + 2] = t.halves[i].cx0;
     }
     return (int)t.strips.size();
+}
+
+// the CU mask of timg_hip_stream_create (cu_mask.h): words[32]; returns the CUs of every XCD kept free, or -1
+extern "C" int timg_hip_debug_cu_mask(int cu_count, int reserved_cus_per_xcd, uint32_t *words) {
+    return timg_amd::BuildCuMask(cu_count, reserved_cus_per_xcd, words);
 }

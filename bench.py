@@ -912,7 +912,7 @@ def main():
         # median cut one CU per frame, the diffusion four), so consecutive batches overlap on the chip.  Kernel durations are NOT comparable with the
         # roofline object in this mode (concurrent kernels share the chip).
         run_steps(max(args.warmup, n_extra), None, n_extra)
-        k_extra = max(args.steps, 2 * n_extra)
+        k_extra = max(args.steps, 24)  # (steady state: with a handful of steps the pipelines' first and last steps overlap nothing)
         dt = timed(k_extra, n_extra)
         result["batched_streams"] = {
             "streams": n_extra, "steps": k_extra, "ms_per_step": round(dt / k_extra * 1e3, 3),

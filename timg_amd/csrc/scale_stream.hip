@@ -753,6 +753,21 @@ template <int M, bool kOvf> struct MKernelShape {
 #endif
     static constexpr int kStage = kWaves == 4 ? 1 : 2;              // staging rows
 };
+// wave priorities of the two-column horizontal-first kernel's phases: the tap chain, then the vertical sums and the next row's
+// decode (the one-column kernel measured 1.4 % SLOWER with the same pair at 52 taps: it has none)
+#ifndef TIMG_H_PRIO_T
+#define TIMG_H_PRIO_T 1
+#endif
+#ifndef TIMG_H_PRIO_V
+#define TIMG_H_PRIO_V 0
+#endif
+// wave priorities of the matrix kernel's two phases (s_setprio; see the horizontal pass's call)
+#ifndef TIMG_M_PRIO
+#define TIMG_M_PRIO 0
+#endif
+#ifndef TIMG_M_PRIO_H
+#define TIMG_M_PRIO_H 1
+#endif
 template <int M, bool kOvf>
 __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const StreamTables &tab, const MTables &mt,
                                                  const DevBlend &blend, const FrameBatch &batch,
@@ -971,6 +986,9 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
         TIMG_M_MARK(tr_vert)
         const int code = (ctl.flags >> 4) & 7;
         if (code == 0) return true;  // wave- and block-uniform
+#ifdef TIMG_M_PRIO_S  // (experiment: the priority of the staging phase in front of the barrier)
+        __builtin_amdgcn_s_setprio(TIMG_M_PRIO_S);
+#endif
 
         // an output row is complete: its column sums go to a staging row
         float *row = stage + (size_t)(ev & (kStageM - 1)) * stage_cols * 4;
@@ -1042,6 +1060,12 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
         BlockSync();
         TIMG_M_MARK(tr_stage)
         if (fail) return false;
+        // Wave priority by phase (profiles/r6/scale_prio.txt): a wave in the horizontal pass goes first at its SIMD's
+        // issue port -- its workgroup's other waves are parked at the barrier behind this pass, while a wave in the
+        // vertical loop that is held up a little only takes its loaded rows later.  2 % of the launch (0.617 -> 0.603-0.608
+        // ms, S-alpha 0.869 -> 0.849-0.852); the other way round (vertical phase high) 1 % slower; priority from the staging
+        // stores on: the same as from here.
+        __builtin_amdgcn_s_setprio(TIMG_M_PRIO_H);
 #if !defined(TIMG_MABL) || TIMG_MABL < 1
         if (M == kOpaque)
             HorizontalRowOpaque(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y,
@@ -1050,6 +1074,7 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
             HorizontalRowM<M>(plan, blend, batch, si, f, row, hw, hbase, hrow, hgroups, ctl.done_y, flag, need_straight, &ok);
 #endif
         TIMG_M_MARK(tr_horiz)
+        __builtin_amdgcn_s_setprio(TIMG_M_PRIO);
         if (kStageM == 1) BlockSync();  // the single staging row is free again
         TIMG_M_MARK(tr_bar2)
         ++ev;
@@ -1070,6 +1095,7 @@ __device__ __forceinline__ void ScaleStreamMBody(const DevPlan &plan, const Stre
     static_assert(kDepth == 3 || kDepth == 4 || kDepth == 8, "ring written out for 3, 4 or 8 rows");
     u4v q0, q1, q2, q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = q4, q6 = q4, q7 = q4;
     TIMG_M_MARK(tr_pro)
+    if (TIMG_M_PRIO != 0) __builtin_amdgcn_s_setprio(TIMG_M_PRIO);
     issue_next_row(q0);
     issue_next_row(q1);
     issue_next_row(q2);
@@ -1616,6 +1642,10 @@ ScaleStreamH2Kernel(DevPlan plan, StreamTables tab, const int2 *pairs, DevBlend 
         }
         if (__any(amin < amin_limit || tiny)) return false;  // (the workgroup is this one wave)
 
+        // Wave priority by phase (profiles/r6/scale_prio.txt): a wave in its tap chain -- dependent LDS reads and sums --
+        // goes first at the SIMD's issue port, one that decodes its next row or runs the vertical sums yields: 2-2.5 % of
+        // the launch (8K S-alpha: 3.83-3.87 -> 3.73-3.79 ms); decode high 1.6 %, three levels (chain 2, vertical 1) slower.
+        __builtin_amdgcn_s_setprio(TIMG_H_PRIO_T);
         // the lane's chain over the window of BOTH columns: steps alternate between two planes of the row buffer
         const int nb      = n0l + par;
         const float *b_ev = buf + slot(nb), *b_od = buf + slot(nb + 2);
@@ -1642,6 +1672,7 @@ ScaleStreamH2Kernel(DevPlan plan, StreamTables tab, const int2 *pairs, DevBlend 
         h[2] = keep23.x + FromPartner(give23.x);
         h[3] = keep23.y + FromPartner(give23.y);
 
+        __builtin_amdgcn_s_setprio(TIMG_H_PRIO_V);
         // vertical: feed the active output rows of this lane's column, finish the one that completes
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
